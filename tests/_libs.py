@@ -1,0 +1,197 @@
+"""ctypes doors for the test-side libraries (TEST INFRASTRUCTURE).
+
+* oracle/libmcraw_oracle.so      -- own scalar C restatement of the reference codecs
+* oracle/_ref/libmcraw_ref_*.so  -- the real reference codec (built only where
+                                    /root/reference exists; travels to the GPU box prebuilt)
+* motioncam_decoder_amd/synth/libmcraw_synth.so -- encoder / image generator
+
+The product library (libmcraw_hip.so) is loaded by motioncam_decoder_amd itself.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+SYNTH_DIR = os.path.join(ROOT, "motioncam_decoder_amd", "synth")
+
+u8p = C.POINTER(C.c_uint8)
+u16p = C.POINTER(C.c_uint16)
+
+
+def _cpu_has(flag):
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    return flag in line.split()
+    except OSError:
+        pass
+    return False
+
+
+def _ensure(path, cmd, cwd):
+    if not os.path.exists(path):
+        subprocess.run(cmd, cwd=cwd, check=True, stdout=subprocess.DEVNULL)
+    return path
+
+
+_oracle = None
+_ref = None
+_synth = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        p = _ensure(os.path.join(ORACLE_DIR, "libmcraw_oracle.so"), ["make", "-s"], ORACLE_DIR)
+        lib = C.CDLL(p)
+        for name in ("mcraw_oracle_decode7", "mcraw_oracle_decode6"):
+            fn = getattr(lib, name)
+            fn.restype = C.c_size_t
+            fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        lib.mcraw_oracle_block7.restype = C.c_int
+        lib.mcraw_oracle_block7.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.mcraw_oracle_block6.restype = C.c_int
+        lib.mcraw_oracle_block6.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        lib.mcraw_oracle_len_used7.restype = C.c_size_t
+        lib.mcraw_oracle_len_used7.argtypes = [C.c_void_p, C.c_size_t]
+        lib.mcraw_oracle_time_batch.restype = C.c_double
+        lib.mcraw_oracle_time_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                C.c_int, C.c_int, C.c_int]
+        _oracle = lib
+    return _oracle
+
+
+def ref_path():
+    for v in (("v3",) if _cpu_has("avx2") else ()) + ("v2",):
+        p = os.path.join(ORACLE_DIR, "_ref", "libmcraw_ref_%s.so" % v)
+        if os.path.exists(p):
+            return p
+    return None
+
+
+def ref():
+    """The real reference codec, or None when it was never built (no /root/reference)."""
+    global _ref
+    if _ref is None:
+        p = ref_path()
+        if p is None and os.path.isdir("/root/reference/lib"):
+            subprocess.run(["make", "-s", "ref"], cwd=ORACLE_DIR, check=True, stdout=subprocess.DEVNULL)
+            p = ref_path()
+        if p is None:
+            return None
+        lib = C.CDLL(p)
+        for name in ("mcraw_ref_decode7", "mcraw_ref_decode6"):
+            fn = getattr(lib, name)
+            fn.restype = C.c_size_t
+            fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+        lib.mcraw_ref_time_batch.restype = C.c_double
+        lib.mcraw_ref_time_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                             C.c_int, C.c_int, C.c_int]
+        _ref = lib
+    return _ref
+
+
+def synth():
+    global _synth
+    if _synth is None:
+        p = os.path.join(SYNTH_DIR, "libmcraw_synth.so")
+        if not os.path.exists(p):
+            subprocess.run(["gcc", "-O3", "-march=x86-64-v3", "-fPIC", "-std=c11", "-shared", "-o", p,
+                            os.path.join(SYNTH_DIR, "mcraw_synth.c"), "-lm"], check=True)
+        lib = C.CDLL(p)
+        lib.mcraw_synth_bound7.restype = C.c_size_t
+        lib.mcraw_synth_bound7.argtypes = [C.c_int, C.c_int]
+        lib.mcraw_synth_bound6.restype = C.c_size_t
+        lib.mcraw_synth_bound6.argtypes = [C.c_int, C.c_int]
+        for name in ("mcraw_synth_encode7", "mcraw_synth_encode6"):
+            fn = getattr(lib, name)
+            fn.restype = C.c_size_t
+            fn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        lib.mcraw_synth_image.restype = None
+        lib.mcraw_synth_image.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                          C.c_uint64]
+        lib.mcraw_synth_pack_block7.restype = C.c_int
+        lib.mcraw_synth_pack_block7.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        _synth = lib
+    return _synth
+
+
+# ---------------------------------------------------------------- helpers
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def encode7(img, min_bits=None, flags=0):
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    h, w = img.shape
+    s = synth()
+    buf = np.zeros(s.mcraw_synth_bound7(w, h), dtype=np.uint8)
+    mb = None if min_bits is None else np.ascontiguousarray(min_bits, dtype=np.uint8)
+    n = s.mcraw_synth_encode7(_ptr(buf), buf.size, _ptr(img), w, h, _ptr(mb), flags)
+    assert n > 0
+    return buf[:n].copy()
+
+
+def encode6(img, min_bits=None, flags=0):
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    h, w = img.shape
+    s = synth()
+    buf = np.zeros(s.mcraw_synth_bound6(w, h), dtype=np.uint8)
+    mb = None if min_bits is None else np.ascontiguousarray(min_bits, dtype=np.uint8)
+    n = s.mcraw_synth_encode6(_ptr(buf), buf.size, _ptr(img), w, h, _ptr(mb), flags)
+    assert n > 0
+    return buf[:n].copy()
+
+
+def synth_image(w, h, nbits, dist, sigma, seed):
+    img = np.empty((h, w), dtype=np.uint16)
+    synth().mcraw_synth_image(_ptr(img), w, h, nbits, dist, float(sigma), seed)
+    return img
+
+
+def _decode(fn, buf, w, h, rows_alloc=None, fill=0xA5A5):
+    """Call a 5-argument decode entry; returns (ret, out[h_alloc, w])."""
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    rows = rows_alloc if rows_alloc is not None else h
+    out = np.full((rows, w), fill, dtype=np.uint16)
+    ret = fn(_ptr(out), w, h, _ptr(buf), buf.size)
+    return ret, out
+
+
+def oracle_decode7(buf, w, h, **kw):
+    return _decode(oracle().mcraw_oracle_decode7, buf, w, h, **kw)
+
+
+def oracle_decode6(buf, w, h, **kw):
+    return _decode(oracle().mcraw_oracle_decode6, buf, w, h, **kw)
+
+
+def ref_decode7(buf, w, h, **kw):
+    # the reference writes width*encodedHeight: give it 4 spare rows
+    kw.setdefault("rows_alloc", h + 4)
+    return _decode(ref().mcraw_ref_decode7, buf, w, h, **kw)
+
+
+def ref_decode6(buf, w, h, **kw):
+    return _decode(ref().mcraw_ref_decode6, buf, w, h, **kw)
+
+
+def natural_image_np(w, h, nbits, sigma, seed):
+    """SURVEY 8(d) "Nat" distribution, numpy flavour (used for golden vectors)."""
+    rng = np.random.default_rng(seed)
+    maxv = (1 << nbits) - 1
+    x = np.arange(w)[None, :]
+    y = np.arange(h)[:, None]
+    field = 0.8 * maxv * (0.5 + 0.45 * np.sin(x / 211.0) * np.cos(y / 173.0)) + maxv / 16.0
+    img = field + rng.normal(0.0, sigma, size=(h, w))
+    return np.clip(np.rint(img), 0, maxv).astype(np.uint16)
+
+
+def uniform_image_np(w, h, nbits, seed):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 1 << nbits, size=(h, w), dtype=np.uint16)
