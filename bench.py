@@ -1,0 +1,304 @@
+#!/usr/bin/env python3
+"""bench.py -- MCRAW frame-decode throughput on MI355X (one process per GPU).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the decode path (mcraw_decode_batch through the C ABI,
+kernels k7_walk -> k7_meta -> k7_scan -> k7_tiles) over one batch of synthetic
+frames that are already resident in HBM.  Workload = BASELINE.json config 3:
+240 frames of 3840x2160 12-bit, current (type 7) encoding, per GPU.  Frames
+shard by index, no collective on the data path (weak scaling: every rank decodes
+its own 240 frames); torch.distributed only carries the barrier and the max of
+the per-rank times.
+
+Prints ONE JSON line on rank 0 (see the keys at the bottom).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=240, help="frames per GPU per step")
+    ap.add_argument("--distinct", type=int, default=48, help="distinct synthetic frames generated per rank")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--nbits", type=int, default=12)
+    ap.add_argument("--sigma", type=float, default=12.0)
+    ap.add_argument("--dist", choices=["nat", "u"], default="nat")
+    ap.add_argument("--no-also", action="store_true", help="skip the second (other distribution) measurement")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=6.0)
+    return ap.parse_args()
+
+
+def synth_lib():
+    import _libs as L
+    return L
+
+
+def make_frames(L, n, w, h, nbits, dist, sigma, seed0):
+    """n distinct (image, encoded buffer) pairs, generated and encoded in parallel on the host."""
+    def one(i):
+        img = L.synth_image(w, h, nbits, 1 if dist == "nat" else 0, sigma, seed0 + i)
+        return img, L.encode7(img)
+    with ThreadPoolExecutor(max_workers=max(1, min(os.cpu_count() or 1, 32))) as ex:
+        return list(ex.map(one, range(n)))
+
+
+class Workload:
+    """A batch of `frames` type-7 frames resident in HBM (inputs at distinct addresses)."""
+
+    def __init__(self, torch, M, L, dev, args, dist, seed0):
+        self.w, self.h = args.width, args.height
+        self.frames = args.frames
+        self.pairs = make_frames(L, min(args.distinct, args.frames), self.w, self.h, args.nbits, dist, args.sigma, seed0)
+        lens = [p[1].size for p in self.pairs]
+        d = len(self.pairs)
+        stride = [(x + 255) // 256 * 256 for x in lens]
+        offs, o = [], 0
+        for i in range(self.frames):
+            offs.append(o)
+            o += stride[i % d]
+        self.t_in = torch.empty(o, dtype=torch.uint8, device=dev)
+        for i in range(self.frames):
+            src = torch.from_numpy(self.pairs[i % d][1])
+            self.t_in[offs[i]: offs[i] + lens[i % d]].copy_(src, non_blocking=False)
+        self.out_stride = self.w * self.h * 2
+        self.t_out = torch.zeros(self.frames * self.out_stride, dtype=torch.uint8, device=dev)
+        descs = [(self.t_in.data_ptr() + offs[i], lens[i % d], self.w, self.h, M.TYPE_BLOCK,
+                  self.t_out.data_ptr() + i * self.out_stride, self.w * self.h) for i in range(self.frames)]
+        self.descs = M.Context.make_frames(descs)
+        orc = L.oracle()
+        used = [orc.mcraw_oracle_len_used7(L._ptr(p[1]), p[1].size) for p in self.pairs]
+        assert all(u > 0 for u in used)
+        self.in_bytes = sum(used[i % d] for i in range(self.frames))      # algorithmic input bytes / step
+        self.out_bytes = self.frames * self.out_stride                    # algorithmic output bytes / step
+        self.pixels = self.frames * self.w * self.h
+        self.bpp = 8.0 * sum(lens) / (d * self.w * self.h)
+
+    def verify(self, torch, idx):
+        """Round trip: decoded frame == the image the encoder was given."""
+        d = len(self.pairs)
+        for i in idx:
+            got = self.t_out[i * self.out_stride:(i + 1) * self.out_stride].cpu().numpy().view(np.uint16)
+            if not np.array_equal(got.reshape(self.h, self.w), self.pairs[i % d][0]):
+                return False
+        return True
+
+
+def run_timed(torch, dist_mod, ctx, M, wl, steps, warmup, world):
+    stream = torch.cuda.current_stream().cuda_stream
+    # first pass with statuses: every frame must decode
+    written, status = ctx.decode_batch(wl.descs, mem=M.MEM_DEVICE, stream=stream, want_status=True)
+    assert all(s == 0 for s in status), "decode failed: %s" % [hex(s) for s in status if s][:4]
+    assert all(wr == wl.w * wl.h for wr in written)
+    ok = wl.verify(torch, [0, wl.frames // 2, wl.frames - 1])
+    for _ in range(max(0, warmup - 1)):
+        ctx.decode_batch(wl.descs, mem=M.MEM_DEVICE, stream=stream, want_status=False)
+    torch.cuda.synchronize()
+    for k in M.KERNELS:
+        ctx.kernel_ms(k, reset=True)
+    if world > 1:
+        dist_mod.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.decode_batch(wl.descs, mem=M.MEM_DEVICE, stream=stream, want_status=False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist_mod.barrier()
+    t1 = time.perf_counter()
+    st = ctx.synchronize(wl.frames)
+    ok = ok and all(s == 0 for s in st) and wl.verify(torch, [1, wl.frames - 2])
+    kms = {k: ctx.kernel_ms(k, reset=True) for k in ("k7_walk", "k7_meta", "k7_scan", "k7_tiles")}
+    return t1 - t0, kms, ok
+
+
+def cpu_baseline(L, wl, seconds):
+    """The reference codec (oracle/_ref, built from the reference's own sources) or, when that
+    build is absent, the oracle port, timed on this host: frame-parallel over all cores, and
+    single-threaded (the reference itself is single-threaded)."""
+    ref = L.ref()
+    if ref is not None:
+        kind, fn = "reference", ref.mcraw_ref_time_batch
+    else:
+        kind = "port"
+        native = os.path.join(ROOT, "oracle", "libmcraw_oracle_native.so")
+        try:
+            subprocess.run(["gcc", "-O3", "-march=native", "-fPIC", "-std=c11", "-shared", "-o", native,
+                            os.path.join(ROOT, "oracle", "mcraw_oracle.c"), "-lpthread"], check=True)
+            lib = C.CDLL(native)
+        except Exception:
+            lib = L.oracle()
+        fn = lib.mcraw_oracle_time_batch
+        fn.restype = C.c_double
+        fn.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+    bufs = [p[1] for p in wl.pairs][:32]
+    n = len(bufs)
+    ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+    lens = (C.c_size_t * n)(*[b.size for b in bufs])
+    cores = os.cpu_count() or 1
+    res = {}
+    for label, th in (("all", cores), ("one", 1)):
+        t = fn(7, wl.w, wl.h, ptrs, lens, n, th, 1)  # one calibration pass
+        if t <= 0:
+            return None
+        reps = max(1, int(seconds / t))
+        t = fn(7, wl.w, wl.h, ptrs, lens, n, th, reps)
+        res[label] = (n * reps * wl.w * wl.h) / t / 1e6
+        res[label + "_s"] = t
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": round(res["all"], 1), "unit": "MPixels/s", "cores": cores, "kind": kind,
+            "value_1thread": round(res["one"], 1), "cpu": model,
+            "sample": "%d distinct %dx%d %d-bit frames of this workload, decode only (inputs in RAM), "
+                      "%.1f s on %d threads + %.1f s on 1 thread" % (n, wl.w, wl.h, 12, res["all_s"], cores, res["one_s"])}
+
+
+def traffic_from_profile(workload_key):
+    """HBM bytes per k7_tiles launch from the committed rocprofv3 --pmc summary, if present."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(p) as f:
+            t = json.load(f)
+        e = t.get(workload_key)
+        return e.get("hbm_bytes_per_launch") if e else None
+    except Exception:
+        return None
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist_mod
+
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist_mod.init_process_group("nccl", device_id=dev)
+
+    import motioncam_decoder_amd as M
+    from motioncam_decoder_amd import build as B
+    if rank == 0 or world == 1:
+        if not os.path.exists(M.lib_path()):
+            B.build_hip()
+        B.build_synth()
+    if world > 1:
+        dist_mod.barrier()
+    L = synth_lib()
+    ctx = M.Context(local)
+    ctx.profile(True)
+
+    dists = [args.dist] + ([] if (args.no_also or world > 1) else [("u" if args.dist == "nat" else "nat")])
+    results = {}
+    for d in dists:
+        wl = Workload(torch, M, L, dev, args, d, 1000 * 3 + rank * args.frames)
+        el, kms, ok = run_timed(torch, dist_mod, ctx, M, wl, args.steps, args.warmup, world)
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
+        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        if world > 1:
+            dist_mod.all_reduce(okt, op=dist_mod.ReduceOp.MIN)
+        results[d] = dict(wl=wl, elapsed=float(t.item()), kms=kms, ok=bool(okt.item()))
+
+    if rank == 0:
+        r = results[args.dist]
+        wl = r["wl"]
+
+        def summarize(r):
+            wl = r["wl"]
+            tile_ms, tile_n = r["kms"]["k7_tiles"]
+            per_launch_ms = tile_ms / max(tile_n, 1)
+            bytes_launch = wl.in_bytes + wl.out_bytes
+            ach = bytes_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+            return {
+                "mpix_s": world * wl.pixels * args.steps / r["elapsed"] / 1e6,
+                "ms_per_step": 1e3 * r["elapsed"] / args.steps,
+                "tiles_ms_per_launch": per_launch_ms,
+                "achieved_gbs": ach,
+                "bytes_per_launch": bytes_launch,
+                "bpp": wl.bpp,
+                "kernels_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in r["kms"].items()},
+            }
+
+        s = summarize(r)
+        wname = "%dx%d %d-bit type-7 x %d frames/GPU, %s" % (args.width, args.height, args.nbits, args.frames,
+                                                             "Nat (smooth field + noise sigma %g)" % args.sigma if args.dist == "nat" else "U (uniform)")
+        key = "%dx%d_%dbit_%d_%s" % (args.width, args.height, args.nbits, args.frames, args.dist)
+        out = {
+            "metric": "MPixels/s unpacked (4K 12-bit MCRAW frame decode)",
+            "value": round(s["mpix_s"], 1),
+            "unit": "MPixels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(s["ms_per_step"], 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u16",
+            "data": "synthetic: %d seeded distinct frames per rank (own encoder), replicated to %d frames at distinct "
+                    "HBM addresses; inputs resident in HBM before the timed region" % (len(wl.pairs), args.frames),
+            "bit_exact": r["ok"],
+            "frames_per_s": round(world * args.frames * args.steps / r["elapsed"], 1),
+            "config": {"workload": wname, "frames_per_gpu": args.frames, "width": args.width, "height": args.height,
+                       "bits": args.nbits, "encoding": 7, "input_bpp": round(s["bpp"], 2), "sharding": "frame index, no collective"},
+            "roofline": {"bound": "hbm", "kernel": "k7_tiles", "achieved": round(s["achieved_gbs"], 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(s["achieved_gbs"] / HBM_PEAK_GBS, 4),
+                         "traffic": traffic_from_profile(key),
+                         "algorithmic_bytes_per_launch": s["bytes_per_launch"],
+                         "avg_launch_ms": round(s["tiles_ms_per_launch"], 4)},
+            "kernels_ms_per_step": {k: round(v, 4) for k, v in s["kernels_ms_per_step"].items()},
+        }
+        for d in dists[1:]:
+            s2 = summarize(results[d])
+            out["also_" + d] = {"mpix_s": round(s2["mpix_s"], 1), "ms_per_step": round(s2["ms_per_step"], 4),
+                                "input_bpp": round(s2["bpp"], 2), "achieved_gbs": round(s2["achieved_gbs"], 1),
+                                "frac": round(s2["achieved_gbs"] / HBM_PEAK_GBS, 4), "bit_exact": results[d]["ok"]}
+        if world == 1 and not args.no_cpu:
+            try:
+                out["cpu_baseline"] = cpu_baseline(L, wl, args.cpu_seconds)
+            except Exception as e:  # the baseline is a report, never a reason to lose the GPU line
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist_mod.barrier()
+        dist_mod.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,118 @@
+/*
+ * mcraw_hip.h -- C ABI of the MI355X (gfx950) MCRAW frame-decode path.
+ *
+ * This is the drop-in boundary: the entry points a maintainer of
+ * mirsadm/motioncam-decoder binds instead of the CPU codec.  Plain pointers
+ * and sizes only; no C++ or torch types.  INTEGRATION.md shows the
+ * reference-side change (lib/Decoder.cpp:224-231).
+ *
+ * There is NO CPU fallback behind these symbols: without a HIP device every
+ * entry point fails (returns 0 / a negative status).
+ */
+#ifndef MCRAW_HIP_H
+#define MCRAW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCRAW_TYPE_LEGACY 6 /* lib/Decoder.cpp:20 MOTIONCAM_COMPRESSION_TYPE_LEGACY */
+#define MCRAW_TYPE_BLOCK  7 /* lib/Decoder.cpp:21 MOTIONCAM_COMPRESSION_TYPE        */
+
+/* Per-frame status bits reported by mcraw_decode_batch (0 = decoded). */
+#define MCRAW_OK            0
+#define MCRAW_E_ARGS        0x0001 /* bad width/height/type/pointer                      */
+#define MCRAW_E_HEADER      0x0002 /* offsets > len, encodedWidth%64, encodedWidth<width */
+                                   /*   (reference returns 0: lib/RawData.cpp:547-554)   */
+#define MCRAW_E_TRUNCATED   0x0004 /* a block or record crosses `len` (the reference     */
+                                   /*   skips it and leaves stale samples, :419-420)     */
+#define MCRAW_E_SIDESTREAM  0x0008 /* side-stream entry count < blocks, or bits > 16     */
+#define MCRAW_E_CAPACITY    0x0010 /* out_capacity < width * rows                        */
+#define MCRAW_E_DEVICE      0x0100 /* HIP runtime error                                  */
+
+/* Where the `in` / `out` pointers of a batch live. */
+#define MCRAW_MEM_DEVICE 0 /* HBM of the context's device: no copies, decode only      */
+#define MCRAW_MEM_HOST   1 /* host memory: staged H2D / D2H on the context's streams,   */
+                           /*   copies of one sub-batch overlap decode of the previous  */
+
+typedef struct mcraw_ctx mcraw_ctx;
+
+/* One frame of a batch.  Mirrors the arguments of motioncam::raw::Decode /
+ * DecodeLegacy (lib/include/motioncam/RawData.hpp:25-37) plus the explicit
+ * output capacity the reference lacks. */
+typedef struct mcraw_frame {
+    const uint8_t *in;   /* compressed frame buffer (BUFFER item payload)          */
+    size_t len;          /* its length in bytes                                    */
+    int32_t width;       /* frame JSON "width"   (lib/Decoder.cpp:216)             */
+    int32_t height;      /* frame JSON "height"  (lib/Decoder.cpp:217)             */
+    int32_t type;        /* frame JSON "compressionType": 6 or 7 (:218)            */
+    int32_t reserved;
+    uint16_t *out;       /* row-major uint16 LE mosaic, width * height             */
+    size_t out_capacity; /* in uint16 elements                                     */
+} mcraw_frame;
+
+/* ---- context ------------------------------------------------------------ */
+
+/* Create a decode context on HIP device `device` (-1: env MCRAW_DEVICE, else
+ * the current device).  Returns 0 or a negative hipError. */
+int mcraw_ctx_create(int device, mcraw_ctx **ctx);
+void mcraw_ctx_destroy(mcraw_ctx *ctx);
+const char *mcraw_last_error(void);
+
+/* ---- drop-in single-frame entry points ---------------------------------- */
+
+/* Replace motioncam::raw::Decode (lib/RawData.cpp:528-612) and
+ * motioncam::raw::DecodeLegacy (lib/RawData_Legacy.cpp:445-495): same five
+ * arguments, same return convention (uint16 elements written, 0 = failure).
+ * Host pointers; `output` must hold width*height elements.  They run on a
+ * process-wide default context (device: MCRAW_DEVICE or 0). */
+size_t mcraw_decode7(uint16_t *output, int width, int height, const uint8_t *input, size_t len);
+size_t mcraw_decode6(uint16_t *output, int width, int height, const uint8_t *input, size_t len);
+
+/* ---- batched entry point (replaces the per-frame loop, lib/Decoder.cpp:184-235,
+ *      example.cpp:187-195) ------------------------------------------------ */
+
+/* Decode `nframes` independent frames.  `mem` says where in/out live.
+ * `stream` is a hipStream_t (NULL = the context's own stream); with
+ * MCRAW_MEM_DEVICE all work is enqueued on it and the call returns without
+ * synchronising unless `written`/`status` are requested:
+ *   written[i] : uint16 elements produced for frame i (0 on failure), or NULL
+ *   status[i]  : MCRAW_* bits for frame i, or NULL
+ * Passing either forces a stream synchronisation before returning.
+ * Returns 0, or a negative value when the batch could not be submitted. */
+int mcraw_decode_batch(mcraw_ctx *ctx, const mcraw_frame *frames, int nframes, int mem,
+                       void *stream, size_t *written, int32_t *status);
+
+/* Wait for everything submitted on the context; fetch the statuses of the
+ * last batch (status may be NULL).  Returns 0 or negative. */
+int mcraw_ctx_synchronize(mcraw_ctx *ctx, int32_t *status, int nframes);
+
+/* ---- measurement -------------------------------------------------------- */
+
+/* Kernel ids for mcraw_ctx_kernel_ms. */
+#define MCRAW_K7_WALK    0 /* side-stream chain resolve           */
+#define MCRAW_K7_META    1 /* side-stream record decode           */
+#define MCRAW_K7_SCAN    2 /* payload offset scan                 */
+#define MCRAW_K7_TILES   3 /* tile decode (the roofline kernel)   */
+#define MCRAW_K6_MAPS    4 /* legacy: per-chunk transition maps   */
+#define MCRAW_K6_RESOLVE 5 /* legacy: map composition             */
+#define MCRAW_K6_ROWS    6 /* legacy: record decode               */
+#define MCRAW_K_COUNT    7
+
+/* Enable (1) / disable (0) hipEvent bracketing of every kernel launch on the
+ * launch stream.  mcraw_ctx_kernel_ms returns, for kernel `id`, the summed
+ * duration (ms) and launch count since the last reset (synchronises). */
+int mcraw_ctx_profile(mcraw_ctx *ctx, int enable);
+int mcraw_ctx_kernel_ms(mcraw_ctx *ctx, int id, double *ms, int *launches, int reset);
+
+/* Pinned host memory for MCRAW_MEM_HOST batches (hipHostMalloc / hipHostFree). */
+void *mcraw_host_alloc(size_t bytes);
+void mcraw_host_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MCRAW_HIP_H */

@@ -1,0 +1,154 @@
+"""motioncam_decoder_amd -- MI355X (gfx950) MCRAW frame-decode path.
+
+Python is plumbing only: this module loads the C-ABI shared library
+(``lib/libmcraw_hip.so``, declared in ``include/mcraw_hip.h``) with ctypes and
+hands it device pointers (e.g. ``torch.Tensor.data_ptr()``).  The product is
+the HIP library and the C++ ``motioncam::Decoder`` facade under ``host/``.
+
+There is no CPU decode path here: if the HIP library is missing or no GPU is
+present, every decode call raises.
+"""
+import ctypes as C
+import os
+
+__all__ = ["lib_path", "load", "Context", "Frame", "McrawError", "TYPE_LEGACY", "TYPE_BLOCK",
+           "MEM_DEVICE", "MEM_HOST", "KERNELS", "ABI_SYMBOLS"]
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+
+TYPE_LEGACY = 6
+TYPE_BLOCK = 7
+MEM_DEVICE = 0
+MEM_HOST = 1
+
+# status bits (include/mcraw_hip.h)
+E_ARGS, E_HEADER, E_TRUNCATED, E_SIDESTREAM, E_CAPACITY, E_DEVICE = 0x1, 0x2, 0x4, 0x8, 0x10, 0x100
+
+KERNELS = {"k7_walk": 0, "k7_meta": 1, "k7_scan": 2, "k7_tiles": 3, "k6_maps": 4, "k6_resolve": 5, "k6_rows": 6}
+
+# every symbol include/mcraw_hip.h declares
+ABI_SYMBOLS = [
+    "mcraw_ctx_create", "mcraw_ctx_destroy", "mcraw_last_error", "mcraw_decode7", "mcraw_decode6",
+    "mcraw_decode_batch", "mcraw_ctx_synchronize", "mcraw_ctx_profile", "mcraw_ctx_kernel_ms",
+    "mcraw_host_alloc", "mcraw_host_free",
+]
+
+
+class McrawError(RuntimeError):
+    pass
+
+
+class Frame(C.Structure):
+    """struct mcraw_frame (include/mcraw_hip.h)."""
+    _fields_ = [("in_", C.c_void_p), ("len", C.c_size_t), ("width", C.c_int32), ("height", C.c_int32),
+                ("type", C.c_int32), ("reserved", C.c_int32), ("out", C.c_void_p), ("out_capacity", C.c_size_t)]
+
+
+def lib_path():
+    return os.path.join(_PKG, "lib", "libmcraw_hip.so")
+
+
+_lib = None
+
+
+def load():
+    """Load libmcraw_hip.so; raises McrawError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise McrawError("HIP decode library not built: %s (run `python -m motioncam_decoder_amd.build`); "
+                         "there is no CPU fallback" % p)
+    lib = C.CDLL(p)
+    lib.mcraw_ctx_create.restype = C.c_int
+    lib.mcraw_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.mcraw_ctx_destroy.restype = None
+    lib.mcraw_ctx_destroy.argtypes = [C.c_void_p]
+    lib.mcraw_last_error.restype = C.c_char_p
+    lib.mcraw_last_error.argtypes = []
+    for name in ("mcraw_decode7", "mcraw_decode6"):
+        fn = getattr(lib, name)
+        fn.restype = C.c_size_t
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    lib.mcraw_decode_batch.restype = C.c_int
+    lib.mcraw_decode_batch.argtypes = [C.c_void_p, C.POINTER(Frame), C.c_int, C.c_int, C.c_void_p,
+                                       C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
+    lib.mcraw_ctx_synchronize.restype = C.c_int
+    lib.mcraw_ctx_synchronize.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
+    lib.mcraw_ctx_profile.restype = C.c_int
+    lib.mcraw_ctx_profile.argtypes = [C.c_void_p, C.c_int]
+    lib.mcraw_ctx_kernel_ms.restype = C.c_int
+    lib.mcraw_ctx_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]
+    lib.mcraw_host_alloc.restype = C.c_void_p
+    lib.mcraw_host_alloc.argtypes = [C.c_size_t]
+    lib.mcraw_host_free.restype = None
+    lib.mcraw_host_free.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+class Context:
+    """Owner of one ``mcraw_ctx`` (one HIP device)."""
+
+    def __init__(self, device=-1):
+        self._lib = load()
+        h = C.c_void_p()
+        rc = self._lib.mcraw_ctx_create(device, C.byref(h))
+        if rc != 0 or not h.value:
+            raise McrawError("mcraw_ctx_create failed (%d): %s" % (rc, self._lib.mcraw_last_error().decode()))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mcraw_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def make_frames(descs):
+        """descs: iterable of (in_ptr, len, width, height, type, out_ptr, out_capacity)."""
+        descs = list(descs)
+        arr = (Frame * len(descs))()
+        for i, (inp, ln, w, h, t, outp, cap) in enumerate(descs):
+            arr[i] = Frame(inp, ln, w, h, t, 0, outp, cap)
+        return arr
+
+    def decode_batch(self, frames, mem=MEM_DEVICE, stream=None, want_status=True):
+        """frames: ctypes array from make_frames.  Returns (written, status) lists when
+        want_status (synchronises), else None (asynchronous on `stream`)."""
+        n = len(frames)
+        if want_status:
+            written = (C.c_size_t * n)()
+            status = (C.c_int32 * n)()
+            rc = self._lib.mcraw_decode_batch(self._h, frames, n, mem, stream, written, status)
+        else:
+            rc = self._lib.mcraw_decode_batch(self._h, frames, n, mem, stream, None, None)
+        if rc != 0:
+            raise McrawError("mcraw_decode_batch failed (%d): %s" % (rc, self._lib.mcraw_last_error().decode()))
+        if want_status:
+            return list(written), list(status)
+        return None
+
+    def synchronize(self, nframes=0):
+        status = (C.c_int32 * max(nframes, 1))()
+        rc = self._lib.mcraw_ctx_synchronize(self._h, status if nframes else None, nframes)
+        if rc != 0:
+            raise McrawError("mcraw_ctx_synchronize failed (%d): %s" % (rc, self._lib.mcraw_last_error().decode()))
+        return list(status)[:nframes]
+
+    def profile(self, enable=True):
+        self._lib.mcraw_ctx_profile(self._h, 1 if enable else 0)
+
+    def kernel_ms(self, name, reset=False):
+        ms = C.c_double()
+        n = C.c_int()
+        rc = self._lib.mcraw_ctx_kernel_ms(self._h, KERNELS[name], C.byref(ms), C.byref(n), 1 if reset else 0)
+        if rc != 0:
+            raise McrawError("mcraw_ctx_kernel_ms failed (%d)" % rc)
+        return ms.value, n.value

@@ -1,0 +1,811 @@
+// mcraw_abi.hip -- host side of the C ABI declared in include/mcraw_hip.h.
+//
+// Owns the HIP context of the decode path: streams, a ring of batch slots
+// (pinned upload buffer + HBM arena + completion event), per-batch planning
+// (geometry, workspace carving, flat work-item tables) and the kernel launches.
+// Replaces the per-frame dispatch of lib/Decoder.cpp:216-234 with one batched
+// submit.  There is no CPU decode fallback in this file or anywhere behind it.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/mcraw_hip.h"
+#include "mcraw_plan.h"
+
+namespace mcraw {
+void launch_k7_walk(const Plan7 *plans, int nframes, hipStream_t st);
+void launch_k7_meta(const Plan7 *plans, const uint32_t *item_base, int nframes, uint32_t nitems, hipStream_t st);
+void launch_k7_scan(const Plan7 *plans, int nframes, hipStream_t st);
+void launch_k7_tiles(const Plan7 *plans, const uint32_t *item_base, int nframes, uint32_t nitems, hipStream_t st);
+void launch_k6_maps(const Plan6 *plans, const uint32_t *item_base, int nframes, uint32_t nitems, hipStream_t st);
+void launch_k6_resolve(const Plan6 *plans, const uint32_t *super_base, int nframes, uint32_t nsuper_items,
+                       hipStream_t st);
+void launch_k6_rows(const Plan6 *plans, const uint32_t *item_base, int nframes, uint32_t nitems, hipStream_t st);
+} // namespace mcraw
+
+using namespace mcraw;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(hipError_t e, const char *what)
+{
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return -static_cast<int>(e ? e : hipErrorUnknown);
+}
+
+#define HIP_TRY(expr)                                                                                                  \
+    do {                                                                                                               \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess)                                                                                          \
+            return fail(e_, #expr);                                                                                    \
+    } while (0)
+
+constexpr int NSLOT = 4;
+constexpr size_t ALIGN = 256;
+
+inline size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Buf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct Slot {
+    Buf pinned;  // host upload image of the batch tables
+    Buf arena;   // HBM: tables + workspace
+    Buf dev_in;  // HBM staging of inputs  (MCRAW_MEM_HOST)
+    Buf dev_out; // HBM staging of outputs (MCRAW_MEM_HOST)
+    Buf status_host; // pinned: statuses copied back
+    hipEvent_t done = nullptr;
+    hipStream_t stream = nullptr; // the slot's own stream (host-memory pipeline)
+    bool busy = false;
+};
+
+struct KStat {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    double ms = 0.0;
+    int launches = 0;
+};
+
+} // namespace
+
+struct mcraw_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Slot slots[NSLOT];
+    int next_slot = 0;
+    bool profile = false;
+    KStat kstat[MCRAW_K_COUNT];
+    std::vector<hipEvent_t> event_pool;
+    // last device-memory batch, for mcraw_ctx_synchronize
+    int last_slot = -1;
+    int last_n = 0;
+    size_t last_status_off = 0;
+    std::mutex mu;
+};
+
+namespace {
+
+int ensure(Buf &b, size_t bytes, bool pinned)
+{
+    if (bytes <= b.cap)
+        return 0;
+    size_t want = std::max(bytes, b.cap + b.cap / 2);
+    want = up(want, 1 << 20);
+    if (b.p) {
+        if (pinned)
+            HIP_TRY(hipHostFree(b.p));
+        else
+            HIP_TRY(hipFree(b.p));
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    if (pinned)
+        HIP_TRY(hipHostMalloc(&b.p, want, hipHostMallocDefault));
+    else
+        HIP_TRY(hipMalloc(&b.p, want));
+    b.cap = want;
+    return 0;
+}
+
+hipEvent_t get_event(mcraw_ctx *c)
+{
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess)
+        return nullptr;
+    return e;
+}
+
+struct KTimer { // brackets one launch with events on the launch stream
+    mcraw_ctx *c;
+    int id;
+    hipStream_t st;
+    hipEvent_t a = nullptr, b = nullptr;
+    KTimer(mcraw_ctx *c_, int id_, hipStream_t st_) : c(c_), id(id_), st(st_)
+    {
+        if (c->profile) {
+            a = get_event(c);
+            b = get_event(c);
+            if (a && b)
+                (void)hipEventRecord(a, st);
+        }
+    }
+    ~KTimer()
+    {
+        if (a && b) {
+            (void)hipEventRecord(b, st);
+            c->kstat[id].pending.emplace_back(a, b);
+        }
+    }
+};
+
+// Geometry the host plans a type-7 frame with unless the header says otherwise.
+struct Geom7 {
+    uint32_t encW, encH;
+};
+
+struct Batch {
+    std::vector<Plan7> p7;
+    std::vector<int> idx7; // frame index in the caller's array
+    std::vector<Plan6> p6;
+    std::vector<int> idx6;
+};
+
+// Carve `bytes` out of a running arena offset.
+inline size_t carve(size_t &off, size_t bytes)
+{
+    size_t o = off;
+    off = up(off + bytes, ALIGN);
+    return o;
+}
+
+struct Layout { // byte offsets inside the slot arena / upload image
+    size_t status = 0;                                   // int32[n]
+    size_t plans7 = 0, meta_base = 0, tile_base = 0;     // Plan7[n7], u32[n7+1] x2
+    size_t plans6 = 0, map_base = 0, super_base = 0, row_base = 0;
+    size_t upload_bytes = 0;                             // tables end here, workspace follows
+    size_t total = 0;
+};
+
+int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::vector<Geom7> *geom_override,
+           const uint8_t *const *dev_in, uint16_t *const *dev_out, hipStream_t st, size_t *status_off)
+{
+    // ---- plan on the host -------------------------------------------------
+    std::vector<int32_t> status(n, 0);
+    Batch B;
+    for (int i = 0; i < n; i++) {
+        const mcraw_frame &f = frames[i];
+        const uint8_t *in = dev_in ? dev_in[i] : f.in;
+        uint16_t *out = dev_out ? dev_out[i] : f.out;
+        if (!in || !out || f.width <= 0 || f.height <= 0 || f.len == 0 || f.len >= (1ull << 32) ||
+            (f.type != MCRAW_TYPE_BLOCK && f.type != MCRAW_TYPE_LEGACY) ||
+            static_cast<uint64_t>(f.width) * static_cast<uint64_t>(f.height) >= (1ull << 31)) {
+            status[i] = MCRAW_E_ARGS;
+            continue;
+        }
+        const bool fast = (reinterpret_cast<uintptr_t>(out) % 16 == 0) && (f.width % 8 == 0);
+        if (f.type == MCRAW_TYPE_BLOCK) {
+            Plan7 p{};
+            p.in = in;
+            p.out = out;
+            p.len = static_cast<uint32_t>(f.len);
+            p.width = f.width;
+            if (geom_override) {
+                p.encW = (*geom_override)[i].encW;
+                p.encH = (*geom_override)[i].encH;
+            } else {
+                p.encW = static_cast<uint32_t>(up(f.width, 64));
+                p.encH = static_cast<uint32_t>(up(f.height, 4));
+            }
+            p.rows = static_cast<int32_t>(std::min<uint32_t>(static_cast<uint32_t>(f.height), p.encH));
+            if (static_cast<uint64_t>(p.encW) * p.encH >= (1ull << 31)) {
+                status[i] = MCRAW_E_HEADER;
+                continue;
+            }
+            if (f.out_capacity < static_cast<size_t>(f.width) * static_cast<size_t>(p.rows)) {
+                status[i] = MCRAW_E_CAPACITY;
+                continue;
+            }
+            p.tilesX = p.encW / 64;
+            p.nblk = 4 * p.tilesX * (p.encH / 4);
+            p.ngroups = (p.nblk + GROUP_BLOCKS - 1) / GROUP_BLOCKS;
+            p.fast_store = fast ? 1u : 0u;
+            B.p7.push_back(p);
+            B.idx7.push_back(i);
+        } else {
+            Plan6 p{};
+            p.in = in;
+            p.out = out;
+            p.len = static_cast<uint32_t>(f.len);
+            p.width = f.width;
+            p.height = f.height;
+            if (f.out_capacity < static_cast<size_t>(f.width) * static_cast<size_t>(f.height)) {
+                status[i] = MCRAW_E_CAPACITY;
+                continue;
+            }
+            p.padded = static_cast<uint32_t>(up(f.width, 32));
+            p.recs_per_row = 2 * p.padded / 32;
+            p.nrec = p.recs_per_row * static_cast<uint32_t>(f.height);
+            p.nchunks = static_cast<uint32_t>((f.len + CHUNK6 - 1) / CHUNK6);
+            p.nsuper = (p.nchunks + SUPER6 - 1) / SUPER6;
+            p.fast_store = fast ? 1u : 0u;
+            B.p6.push_back(p);
+            B.idx6.push_back(i);
+        }
+    }
+    const int n7 = static_cast<int>(B.p7.size()), n6 = static_cast<int>(B.p6.size());
+
+    // ---- lay out the upload image and the workspace ------------------------
+    Layout L;
+    size_t off = 0;
+    L.status = carve(off, sizeof(int32_t) * n);
+    L.plans7 = carve(off, sizeof(Plan7) * n7);
+    L.meta_base = carve(off, sizeof(uint32_t) * (n7 + 1));
+    L.tile_base = carve(off, sizeof(uint32_t) * (n7 + 1));
+    L.plans6 = carve(off, sizeof(Plan6) * n6);
+    L.map_base = carve(off, sizeof(uint32_t) * (n6 + 1));
+    L.super_base = carve(off, sizeof(uint32_t) * (n6 + 1));
+    L.row_base = carve(off, sizeof(uint32_t) * (n6 + 1));
+    L.upload_bytes = off;
+
+    std::vector<size_t> w_rec(n7), w_bits(n7), w_refs(n7), w_grp(n7);
+    for (int k = 0; k < n7; k++) {
+        const Plan7 &p = B.p7[k];
+        const size_t R = p.ngroups;
+        w_rec[k] = carve(off, sizeof(uint32_t) * 2 * R);
+        w_bits[k] = carve(off, R * 64);
+        w_refs[k] = carve(off, R * 64 * sizeof(uint16_t));
+        w_grp[k] = carve(off, sizeof(uint32_t) * (R + 1));
+    }
+    std::vector<size_t> w_cmap(n6), w_smap(n6), w_centry(n6), w_sentry(n6);
+    for (int k = 0; k < n6; k++) {
+        const Plan6 &p = B.p6[k];
+        w_cmap[k] = carve(off, sizeof(uint32_t) * PHASES6 * p.nchunks);
+        w_smap[k] = carve(off, sizeof(uint32_t) * PHASES6 * p.nsuper);
+        w_centry[k] = carve(off, sizeof(uint32_t) * p.nchunks);
+        w_sentry[k] = carve(off, sizeof(uint32_t) * p.nsuper);
+    }
+    L.total = off;
+
+    if (int rc = ensure(s.arena, L.total, false))
+        return rc;
+    if (int rc = ensure(s.pinned, L.upload_bytes, true))
+        return rc;
+    uint8_t *dev = static_cast<uint8_t *>(s.arena.p);
+    uint8_t *img = static_cast<uint8_t *>(s.pinned.p);
+
+    std::memcpy(img + L.status, status.data(), sizeof(int32_t) * n);
+    uint32_t *meta_base = reinterpret_cast<uint32_t *>(img + L.meta_base);
+    uint32_t *tile_base = reinterpret_cast<uint32_t *>(img + L.tile_base);
+    uint32_t nmeta = 0, ntile = 0;
+    for (int k = 0; k < n7; k++) {
+        Plan7 &p = B.p7[k];
+        p.rec_off = reinterpret_cast<uint32_t *>(dev + w_rec[k]);
+        p.bits = dev + w_bits[k];
+        p.refs = reinterpret_cast<uint16_t *>(dev + w_refs[k]);
+        p.grp_off = reinterpret_cast<uint32_t *>(dev + w_grp[k]);
+        p.status = reinterpret_cast<int32_t *>(dev + L.status) + B.idx7[k];
+        meta_base[k] = nmeta;
+        tile_base[k] = ntile;
+        nmeta += (2 * p.ngroups + 3) / 4; // 4 records per workgroup
+        ntile += p.ngroups;
+    }
+    meta_base[n7] = nmeta;
+    tile_base[n7] = ntile;
+    if (n7)
+        std::memcpy(img + L.plans7, B.p7.data(), sizeof(Plan7) * n7);
+
+    uint32_t *map_base = reinterpret_cast<uint32_t *>(img + L.map_base);
+    uint32_t *super_base = reinterpret_cast<uint32_t *>(img + L.super_base);
+    uint32_t *row_base = reinterpret_cast<uint32_t *>(img + L.row_base);
+    uint32_t nmap = 0, nsup = 0, nrow = 0;
+    for (int k = 0; k < n6; k++) {
+        Plan6 &p = B.p6[k];
+        p.cmap = reinterpret_cast<uint32_t *>(dev + w_cmap[k]);
+        p.smap = reinterpret_cast<uint32_t *>(dev + w_smap[k]);
+        p.centry = reinterpret_cast<uint32_t *>(dev + w_centry[k]);
+        p.sentry = reinterpret_cast<uint32_t *>(dev + w_sentry[k]);
+        p.status = reinterpret_cast<int32_t *>(dev + L.status) + B.idx6[k];
+        map_base[k] = nmap;
+        super_base[k] = nsup;
+        row_base[k] = nrow;
+        nmap += (p.nchunks + 11) / 12; // k6_maps: 12 chunks per workgroup
+        nsup += p.nsuper;
+        nrow += (p.nchunks + 3) / 4; // k6_rows: one chunk per wave
+    }
+    map_base[n6] = nmap;
+    super_base[n6] = nsup;
+    row_base[n6] = nrow;
+    if (n6)
+        std::memcpy(img + L.plans6, B.p6.data(), sizeof(Plan6) * n6);
+
+    HIP_TRY(hipMemcpyAsync(dev, img, L.upload_bytes, hipMemcpyHostToDevice, st));
+
+    // ---- launches -----------------------------------------------------------
+    if (n7) {
+        const Plan7 *dp = reinterpret_cast<const Plan7 *>(dev + L.plans7);
+        {
+            KTimer t(c, MCRAW_K7_WALK, st);
+            launch_k7_walk(dp, n7, st);
+        }
+        {
+            KTimer t(c, MCRAW_K7_META, st);
+            launch_k7_meta(dp, reinterpret_cast<const uint32_t *>(dev + L.meta_base), n7, nmeta, st);
+        }
+        {
+            KTimer t(c, MCRAW_K7_SCAN, st);
+            launch_k7_scan(dp, n7, st);
+        }
+        {
+            KTimer t(c, MCRAW_K7_TILES, st);
+            launch_k7_tiles(dp, reinterpret_cast<const uint32_t *>(dev + L.tile_base), n7, ntile, st);
+        }
+    }
+    if (n6) {
+        const Plan6 *dp = reinterpret_cast<const Plan6 *>(dev + L.plans6);
+        {
+            KTimer t(c, MCRAW_K6_MAPS, st);
+            launch_k6_maps(dp, reinterpret_cast<const uint32_t *>(dev + L.map_base), n6, nmap, st);
+        }
+        {
+            KTimer t(c, MCRAW_K6_RESOLVE, st);
+            launch_k6_resolve(dp, reinterpret_cast<const uint32_t *>(dev + L.super_base), n6, nsup, st);
+        }
+        {
+            KTimer t(c, MCRAW_K6_ROWS, st);
+            launch_k6_rows(dp, reinterpret_cast<const uint32_t *>(dev + L.row_base), n6, nrow, st);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    *status_off = L.status;
+    return 0;
+}
+
+int acquire_slot(mcraw_ctx *c, Slot **out)
+{
+    Slot &s = c->slots[c->next_slot];
+    c->next_slot = (c->next_slot + 1) % NSLOT;
+    if (s.busy) {
+        HIP_TRY(hipEventSynchronize(s.done));
+        s.busy = false;
+    }
+    *out = &s;
+    return 0;
+}
+
+// Fetch statuses of a finished-or-running batch (synchronises on the slot).
+int fetch_status(mcraw_ctx *c, Slot &s, size_t status_off, int n, hipStream_t st, int32_t *status)
+{
+    if (int rc = ensure(s.status_host, sizeof(int32_t) * std::max(n, 1), true))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(s.status_host.p, static_cast<uint8_t *>(s.arena.p) + status_off, sizeof(int32_t) * n,
+                           hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::memcpy(status, s.status_host.p, sizeof(int32_t) * n);
+    (void)c;
+    return 0;
+}
+
+size_t written_of(const mcraw_frame &f, int32_t status, uint32_t encH)
+{
+    if (status != 0)
+        return 0;
+    if (f.type == MCRAW_TYPE_BLOCK) // width * min(height, encodedHeight): RawData.cpp:611 when they agree
+        return static_cast<size_t>(f.width) * std::min<size_t>(static_cast<size_t>(f.height), encH);
+    return static_cast<size_t>(f.width) * static_cast<size_t>(f.height); // RawData_Legacy.cpp:494
+}
+
+// Decode a batch whose buffers are in HBM; optionally resolve statuses
+// (synchronising) and re-plan frames whose header geometry differs from the
+// host's assumption.
+int decode_device(mcraw_ctx *c, const mcraw_frame *frames, int n, hipStream_t st, size_t *written, int32_t *status_out)
+{
+    Slot *sp = nullptr;
+    if (int rc = acquire_slot(c, &sp))
+        return rc;
+    Slot &s = *sp;
+    size_t status_off = 0;
+    if (int rc = submit(c, s, frames, n, nullptr, nullptr, nullptr, st, &status_off))
+        return rc;
+    HIP_TRY(hipEventRecord(s.done, st));
+    s.busy = true;
+    c->last_slot = static_cast<int>(sp - c->slots);
+    c->last_n = n;
+    c->last_status_off = status_off;
+    if (!written && !status_out)
+        return 0;
+
+    std::vector<int32_t> status(n);
+    if (int rc = fetch_status(c, s, status_off, n, st, status.data()))
+        return rc;
+    std::vector<uint32_t> encH(n);
+    for (int i = 0; i < n; i++)
+        encH[i] = static_cast<uint32_t>(up(std::max(frames[i].height, 1), 4));
+
+    // frames coded with a geometry other than ceil64(w) x ceil4(h): read the
+    // real header and run them again with it
+    std::vector<int> redo;
+    for (int i = 0; i < n; i++)
+        if (status[i] == E_GEOMETRY)
+            redo.push_back(i);
+    if (!redo.empty()) {
+        std::vector<mcraw_frame> rf(redo.size());
+        std::vector<Geom7> rg(redo.size());
+        for (size_t k = 0; k < redo.size(); k++) {
+            rf[k] = frames[redo[k]];
+            uint32_t hdr[4] = {0, 0, 0, 0};
+            HIP_TRY(hipMemcpyAsync(hdr, rf[k].in, 16, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            rg[k] = {hdr[0], hdr[1]};
+        }
+        Slot *s2 = nullptr;
+        if (int rc = acquire_slot(c, &s2))
+            return rc;
+        size_t off2 = 0;
+        if (int rc = submit(c, *s2, rf.data(), static_cast<int>(rf.size()), &rg, nullptr, nullptr, st, &off2))
+            return rc;
+        HIP_TRY(hipEventRecord(s2->done, st));
+        s2->busy = true;
+        std::vector<int32_t> st2(rf.size());
+        if (int rc = fetch_status(c, *s2, off2, static_cast<int>(rf.size()), st, st2.data()))
+            return rc;
+        for (size_t k = 0; k < redo.size(); k++) {
+            status[redo[k]] = st2[k] == E_GEOMETRY ? MCRAW_E_HEADER : st2[k];
+            encH[redo[k]] = rg[k].encH;
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        if (status_out)
+            status_out[i] = status[i];
+        if (written)
+            written[i] = written_of(frames[i], status[i], encH[i]);
+    }
+    return 0;
+}
+
+// Host-memory batch: sub-batches cycle over the slots' own streams so that the
+// H2D copy of one sub-batch overlaps decode and D2H of the previous ones
+// (BASELINE config 3: "pinned H2D + decode overlapped on HIP streams").
+int decode_host(mcraw_ctx *c, const mcraw_frame *frames, int n, size_t *written, int32_t *status_out)
+{
+    constexpr size_t SUB_BYTES = 96ull << 20; // compressed + decoded bytes per sub-batch
+    struct Pending {
+        Slot *s;
+        int first, count;
+        size_t status_off;
+    };
+    std::vector<Pending> pend;
+    std::vector<int32_t> status(n, 0);
+    int first = 0;
+    while (first < n) {
+        size_t bytes = 0;
+        int count = 0;
+        while (first + count < n) {
+            const mcraw_frame &f = frames[first + count];
+            size_t fb = f.len + (f.width > 0 && f.height > 0 ? static_cast<size_t>(f.width) * f.height * 2 : 0);
+            if (count > 0 && bytes + fb > SUB_BYTES)
+                break;
+            bytes += fb;
+            count++;
+        }
+        Slot *sp = nullptr;
+        if (int rc = acquire_slot(c, &sp))
+            return rc;
+        Slot &s = *sp;
+        hipStream_t st = s.stream;
+        size_t in_bytes = 0, out_bytes = 0;
+        for (int i = 0; i < count; i++) {
+            const mcraw_frame &f = frames[first + i];
+            in_bytes += up(f.len, ALIGN);
+            if (f.width > 0 && f.height > 0)
+                out_bytes += up(static_cast<size_t>(f.width) * f.height * 2, ALIGN);
+        }
+        if (int rc = ensure(s.dev_in, in_bytes + ALIGN, false))
+            return rc;
+        if (int rc = ensure(s.dev_out, out_bytes + ALIGN, false))
+            return rc;
+        std::vector<const uint8_t *> din(count);
+        std::vector<uint16_t *> dout(count);
+        size_t io = 0, oo = 0;
+        for (int i = 0; i < count; i++) {
+            const mcraw_frame &f = frames[first + i];
+            din[i] = static_cast<uint8_t *>(s.dev_in.p) + io;
+            dout[i] = reinterpret_cast<uint16_t *>(static_cast<uint8_t *>(s.dev_out.p) + oo);
+            if (f.in && f.len)
+                HIP_TRY(hipMemcpyAsync(const_cast<uint8_t *>(din[i]), f.in, f.len, hipMemcpyHostToDevice, st));
+            else
+                din[i] = nullptr;
+            io += up(f.len, ALIGN);
+            if (f.width > 0 && f.height > 0)
+                oo += up(static_cast<size_t>(f.width) * f.height * 2, ALIGN);
+            if (!f.out)
+                dout[i] = nullptr;
+        }
+        size_t status_off = 0;
+        if (int rc = submit(c, s, frames + first, count, nullptr, din.data(), dout.data(), st, &status_off))
+            return rc;
+        for (int i = 0; i < count; i++) {
+            const mcraw_frame &f = frames[first + i];
+            if (!dout[i] || !din[i] || f.width <= 0 || f.height <= 0)
+                continue;
+            size_t nbytes = std::min(f.out_capacity, static_cast<size_t>(f.width) * f.height) * 2;
+            HIP_TRY(hipMemcpyAsync(f.out, dout[i], nbytes, hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRY(hipEventRecord(s.done, st));
+        s.busy = true;
+        pend.push_back({sp, first, count, status_off});
+        // more sub-batches than slots: drain the oldest before its slot is reused
+        if (pend.size() >= static_cast<size_t>(NSLOT)) {
+            Pending &p = pend.front();
+            if (int rc = fetch_status(c, *p.s, p.status_off, p.count, p.s->stream, status.data() + p.first))
+                return rc;
+            pend.erase(pend.begin());
+        }
+        first += count;
+    }
+    for (Pending &p : pend)
+        if (int rc = fetch_status(c, *p.s, p.status_off, p.count, p.s->stream, status.data() + p.first))
+            return rc;
+
+    // geometry mismatches: the header is readable on the host here
+    for (int i = 0; i < n; i++) {
+        uint32_t encH = static_cast<uint32_t>(up(std::max(frames[i].height, 1), 4));
+        if (status[i] == E_GEOMETRY) {
+            const mcraw_frame &f = frames[i];
+            uint32_t hdr[4];
+            std::memcpy(hdr, f.in, 16);
+            std::vector<Geom7> g{{hdr[0], hdr[1]}};
+            Slot *sp = nullptr;
+            if (int rc = acquire_slot(c, &sp))
+                return rc;
+            Slot &s = *sp;
+            hipStream_t st = s.stream;
+            if (int rc = ensure(s.dev_in, f.len + ALIGN, false))
+                return rc;
+            if (int rc = ensure(s.dev_out, static_cast<size_t>(f.width) * f.height * 2 + ALIGN, false))
+                return rc;
+            const uint8_t *din = static_cast<uint8_t *>(s.dev_in.p);
+            uint16_t *dout = static_cast<uint16_t *>(s.dev_out.p);
+            HIP_TRY(hipMemcpyAsync(s.dev_in.p, f.in, f.len, hipMemcpyHostToDevice, st));
+            size_t so = 0;
+            if (int rc = submit(c, s, &f, 1, &g, &din, &dout, st, &so))
+                return rc;
+            size_t nbytes = std::min(f.out_capacity, static_cast<size_t>(f.width) * f.height) * 2;
+            HIP_TRY(hipMemcpyAsync(f.out, dout, nbytes, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipEventRecord(s.done, st));
+            s.busy = true;
+            int32_t st2 = 0;
+            if (int rc = fetch_status(c, s, so, 1, st, &st2))
+                return rc;
+            status[i] = st2 == E_GEOMETRY ? MCRAW_E_HEADER : st2;
+            encH = hdr[1];
+        }
+        if (status_out)
+            status_out[i] = status[i];
+        if (written)
+            written[i] = written_of(frames[i], status[i], encH);
+    }
+    return 0;
+}
+
+mcraw_ctx *g_default = nullptr;
+std::mutex g_default_mu;
+
+mcraw_ctx *default_ctx()
+{
+    std::lock_guard<std::mutex> lk(g_default_mu);
+    if (!g_default) {
+        mcraw_ctx *c = nullptr;
+        if (mcraw_ctx_create(-1, &c) != 0)
+            return nullptr;
+        g_default = c;
+    }
+    return g_default;
+}
+
+size_t decode_one(int type, uint16_t *output, int width, int height, const uint8_t *input, size_t len)
+{
+    mcraw_ctx *c = default_ctx();
+    if (!c)
+        return 0;
+    mcraw_frame f{};
+    f.in = input;
+    f.len = len;
+    f.width = width;
+    f.height = height;
+    f.type = type;
+    f.out = output;
+    f.out_capacity = width > 0 && height > 0 ? static_cast<size_t>(width) * static_cast<size_t>(height) : 0;
+    size_t written = 0;
+    int32_t status = 0;
+    if (mcraw_decode_batch(c, &f, 1, MCRAW_MEM_HOST, nullptr, &written, &status) != 0)
+        return 0;
+    return written;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------ C ABI
+
+extern "C" {
+
+const char *mcraw_last_error(void) { return g_err.c_str(); }
+
+int mcraw_ctx_create(int device, mcraw_ctx **out)
+{
+    if (!out)
+        return -1;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_err = "mcraw: no HIP device available (the decode path has no CPU fallback)";
+        return e != hipSuccess ? -static_cast<int>(e) : -static_cast<int>(hipErrorNoDevice);
+    }
+    if (device < 0) {
+        const char *env = std::getenv("MCRAW_DEVICE");
+        if (env && *env)
+            device = std::atoi(env);
+        else
+            HIP_TRY(hipGetDevice(&device));
+    }
+    if (device >= ndev) {
+        g_err = "mcraw: device index out of range";
+        return -static_cast<int>(hipErrorInvalidDevice);
+    }
+    HIP_TRY(hipSetDevice(device));
+    mcraw_ctx *c = new mcraw_ctx();
+    c->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (Slot &s : c->slots) {
+        HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    }
+    *out = c;
+    return 0;
+}
+
+void mcraw_ctx_destroy(mcraw_ctx *c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (Slot &s : c->slots) {
+        if (s.pinned.p) (void)hipHostFree(s.pinned.p);
+        if (s.status_host.p) (void)hipHostFree(s.status_host.p);
+        if (s.arena.p) (void)hipFree(s.arena.p);
+        if (s.dev_in.p) (void)hipFree(s.dev_in.p);
+        if (s.dev_out.p) (void)hipFree(s.dev_out.p);
+        if (s.done) (void)hipEventDestroy(s.done);
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+    }
+    for (KStat &k : c->kstat)
+        for (auto &p : k.pending) {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+    for (hipEvent_t e : c->event_pool)
+        (void)hipEventDestroy(e);
+    if (c->stream)
+        (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int mcraw_decode_batch(mcraw_ctx *c, const mcraw_frame *frames, int nframes, int mem, void *stream, size_t *written,
+                       int32_t *status)
+{
+    if (!c || (!frames && nframes > 0) || nframes < 0) {
+        g_err = "mcraw_decode_batch: bad arguments";
+        return -1;
+    }
+    if (nframes == 0)
+        return 0;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    if (mem == MCRAW_MEM_DEVICE)
+        return decode_device(c, frames, nframes, stream ? static_cast<hipStream_t>(stream) : c->stream, written, status);
+    if (mem == MCRAW_MEM_HOST)
+        return decode_host(c, frames, nframes, written, status);
+    g_err = "mcraw_decode_batch: unknown memory kind";
+    return -1;
+}
+
+int mcraw_ctx_synchronize(mcraw_ctx *c, int32_t *status, int nframes)
+{
+    if (!c)
+        return -1;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    for (Slot &s : c->slots)
+        if (s.busy) {
+            HIP_TRY(hipEventSynchronize(s.done));
+            s.busy = false;
+        }
+    if (status && c->last_slot >= 0) {
+        Slot &s = c->slots[c->last_slot];
+        int n = std::min(nframes, c->last_n);
+        if (int rc = fetch_status(c, s, c->last_status_off, n, c->stream, status))
+            return rc;
+        for (int i = 0; i < n; i++)
+            if (status[i] == E_GEOMETRY)
+                status[i] = MCRAW_E_HEADER; // asynchronous submits are not re-planned
+    }
+    return 0;
+}
+
+size_t mcraw_decode7(uint16_t *output, int width, int height, const uint8_t *input, size_t len)
+{
+    return decode_one(MCRAW_TYPE_BLOCK, output, width, height, input, len);
+}
+
+size_t mcraw_decode6(uint16_t *output, int width, int height, const uint8_t *input, size_t len)
+{
+    return decode_one(MCRAW_TYPE_LEGACY, output, width, height, input, len);
+}
+
+int mcraw_ctx_profile(mcraw_ctx *c, int enable)
+{
+    if (!c)
+        return -1;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->profile = enable != 0;
+    return 0;
+}
+
+int mcraw_ctx_kernel_ms(mcraw_ctx *c, int id, double *ms, int *launches, int reset)
+{
+    if (!c || id < 0 || id >= MCRAW_K_COUNT)
+        return -1;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    KStat &k = c->kstat[id];
+    for (auto &p : k.pending) {
+        HIP_TRY(hipEventSynchronize(p.second));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, p.first, p.second));
+        k.ms += t;
+        k.launches++;
+        c->event_pool.push_back(p.first);
+        c->event_pool.push_back(p.second);
+    }
+    k.pending.clear();
+    if (ms)
+        *ms = k.ms;
+    if (launches)
+        *launches = k.launches;
+    if (reset) {
+        k.ms = 0.0;
+        k.launches = 0;
+    }
+    return 0;
+}
+
+void *mcraw_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess)
+        return nullptr;
+    return p;
+}
+
+void mcraw_host_free(void *p)
+{
+    if (p)
+        (void)hipHostFree(p);
+}
+
+} // extern "C"

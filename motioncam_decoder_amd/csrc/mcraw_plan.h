@@ -1,0 +1,60 @@
+// mcraw_plan.h -- structures shared by the host side of the C ABI (mcraw_abi.hip)
+// and the gfx950 kernels (mcraw_type7.hip, mcraw_type6.hip).
+#pragma once
+#include <stdint.h>
+
+namespace mcraw {
+
+// Internal status bit on top of include/mcraw_hip.h: the coded geometry in the
+// frame header differs from the one the host planned with (ceil64(width) x
+// ceil4(height)); the host re-plans that frame from the real header.
+constexpr int32_t E_GEOMETRY = 0x1000;
+
+constexpr int GROUP_BLOCKS = 64;   // blocks per side-stream record = per decode group
+constexpr int GROUP_TILES = 16;    // 64x4 tiles per group
+constexpr int SPAN_MAX = 64 * 128; // largest payload span of one group (all raw-16)
+
+// Per-frame plan of the current ("type 7") encoding; lives in HBM for the
+// duration of one batch.  All workspace pointers are device pointers.
+struct Plan7 {
+    const uint8_t *in;   // frame buffer (lib/RawData.cpp:528 `input`)
+    uint16_t *out;       // width x rows mosaic
+    uint32_t len;
+    int32_t width;       // output columns kept (crop of encW, :598-608)
+    int32_t rows;        // output rows kept = min(height, encH)
+    uint32_t encW, encH; // coded geometry the plan assumes (:500-511)
+    uint32_t tilesX;     // encW / 64
+    uint32_t nblk;       // N = 4 * tilesX * encH/4  (payload blocks = side-stream entries used)
+    uint32_t ngroups;    // R = ceil(N / 64)
+    uint32_t fast_store; // 1: out 16-B aligned and width % 8 == 0
+    uint32_t *rec_off;   // [2][R] byte offset of every side-stream record header
+    uint8_t *bits;       // [R*64] decoded `bits` stream  (:557)
+    uint16_t *refs;      // [R*64] decoded `refs` stream  (:560)
+    uint32_t *grp_off;   // [R+1]  payload byte offset of every 64-block group (:562 + prefix of LEN)
+    int32_t *status;     // this frame's status word
+};
+
+// Per-frame plan of the legacy ("type 6") encoding.
+struct Plan6 {
+    const uint8_t *in;
+    uint16_t *out;
+    uint32_t len;
+    int32_t width, height;
+    uint32_t padded;       // ceil32(width)                        (lib/RawData_Legacy.cpp:34-36)
+    uint32_t recs_per_row; // 2 * padded / 32
+    uint32_t nrec;         // height * recs_per_row
+    uint32_t nchunks;      // ceil(len / CHUNK6)
+    uint32_t nsuper;       // ceil(nchunks / SUPER6)
+    uint32_t fast_store;
+    uint32_t *cmap;        // [nchunks][17] per-chunk transition map  (exit phase | count)
+    uint32_t *smap;        // [nsuper][17]  per-super-chunk map
+    uint32_t *centry;      // [nchunks]     resolved entry of every chunk (phase | first record)
+    uint32_t *sentry;      // [nsuper]      resolved entry of every super-chunk
+    int32_t *status;
+};
+
+constexpr int CHUNK6 = 1024; // bytes of legacy stream per transition-map chunk
+constexpr int SUPER6 = 64;   // chunks per super-chunk
+constexpr int PHASES6 = 17;  // entry offsets 0,2,..,32 (record stride <= 34, all even)
+
+} // namespace mcraw

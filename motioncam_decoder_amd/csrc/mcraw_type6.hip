@@ -1,0 +1,312 @@
+// mcraw_type6.hip -- gfx950 kernels for the legacy MCRAW frame encoding
+// (compressionType 6).  Replaces motioncam::raw::DecodeLegacy,
+// lib/RawData_Legacy.cpp:445-495.
+//
+// The legacy stream is ONE chain of 16-sample records with inline 2-byte
+// headers (RawData_Legacy.cpp:377-442): record i+1 starts where record i ends.
+// A frame holds ~w*h/16 of them, so the chain is resolved in parallel with
+// transition maps: record strides are even and <= 34 bytes, so a fixed 1 KiB
+// chunk of the stream can be entered at only 17 offsets ("phases" 0,2,..,32).
+//
+//   k6_maps    per chunk, per phase: walk to the chunk end -> (exit phase, records started)
+//   k6_super   compose 64 chunk maps into one super-chunk map
+//   k6_frame   follow the true phase over the super-chunks   -> entry of every super-chunk
+//   k6_chunks  follow it over a super-chunk's 64 chunks      -> entry of every chunk
+//   k6_rows    per chunk: list its records from the true entry, then unpack them
+//              (MSB-first bitstreams, RawData_Legacy.cpp:38-370), add the references,
+//              interleave even/odd columns (:483-486) and crop the padded row (:490)
+#include "mcraw_dev.h"
+
+#include "../../include/mcraw_hip.h"
+
+namespace mcraw {
+
+constexpr uint32_t DEAD = 31; // phase value: the chain ended (a record crossed `len`)
+
+// Payload bytes of a record whose header nibble is `b` (RawData_Legacy.cpp:13-32).
+__device__ __forceinline__ uint32_t len6_of(uint32_t b) { return b <= 10u ? 2u * b : 32u; }
+
+// ------------------------------------------------------------------ k6_maps
+constexpr int MAP_CH_PER_WAVE = 3; // 3 x 17 phases = 51 of 64 lanes
+constexpr int MAP_CH_PER_WG = 4 * MAP_CH_PER_WAVE;
+
+__global__ __launch_bounds__(256) void k6_maps(const Plan6 *__restrict__ plans, const uint32_t *__restrict__ item_base,
+                                               int nframes)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_bytes[4][MAP_CH_PER_WAVE * CHUNK6];
+
+    const int f = find_frame(blockIdx.x, item_base, nframes);
+    const Plan6 *P = plans + f;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t c0 = ((blockIdx.x - item_base[f]) * 4u + wave) * MAP_CH_PER_WAVE;
+    const uint32_t nchunks = P->nchunks, len = P->len;
+    if (c0 >= nchunks)
+        return;
+    const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
+
+    // 3 KiB of stream for this wave (reads past `len` give 0)
+    uint4 *dst = reinterpret_cast<uint4 *>(s_bytes[wave]);
+#pragma unroll
+    for (int q = 0; q < MAP_CH_PER_WAVE; q++)
+        dst[q * 64 + lane] = ld_b128(rs, (c0 + q) * CHUNK6 + lane * 16u);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0);
+
+    const uint32_t sub = lane / PHASES6, ph = lane - sub * PHASES6;
+    const uint32_t c = c0 + sub;
+    if (sub >= MAP_CH_PER_WAVE || c >= nchunks)
+        return;
+    const uint8_t *bytes = s_bytes[wave] + sub * CHUNK6;
+    const uint32_t cs = c * CHUNK6;
+    uint32_t pos = 2u * ph, count = 0, exitph = 0;
+    while (pos < CHUNK6) {
+        const uint32_t L = len6_of(bytes[pos] >> 4);
+        // RawData_Legacy.cpp:387-388,398-399: a record must end before len-1
+        if (cs + pos + 2u + L >= len) {
+            exitph = DEAD;
+            break;
+        }
+        pos += 2u + L;
+        count++;
+    }
+    if (exitph != DEAD)
+        exitph = (pos - CHUNK6) >> 1;
+    P->cmap[c * PHASES6 + ph] = exitph | (count << 8);
+}
+
+// ------------------------------------------------------------------ k6_super
+__global__ __launch_bounds__(64) void k6_super(const Plan6 *__restrict__ plans, const uint32_t *__restrict__ super_base,
+                                               int nframes)
+{
+    __shared__ uint32_t s_map[SUPER6 * PHASES6];
+    const int f = find_frame(blockIdx.x, super_base, nframes);
+    const Plan6 *P = plans + f;
+    const uint32_t sc = blockIdx.x - super_base[f];
+    const uint32_t first = sc * SUPER6;
+    const uint32_t cnt = min(static_cast<uint32_t>(SUPER6), P->nchunks - first);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t *src = P->cmap + static_cast<size_t>(first) * PHASES6;
+    for (uint32_t i = lane; i < cnt * PHASES6; i += 64u)
+        s_map[i] = src[i];
+    __syncthreads();
+    if (lane >= PHASES6)
+        return;
+    uint32_t p = lane, n = 0;
+    for (uint32_t c = 0; c < cnt && p != DEAD; c++) {
+        const uint32_t m = s_map[c * PHASES6 + p];
+        n += m >> 8;
+        p = m & 255u;
+    }
+    P->smap[sc * PHASES6 + lane] = p | (n << 8);
+}
+
+// ------------------------------------------------------------------ k6_frame
+constexpr int FRAME_PIECE = 512; // super-chunk maps staged per pass
+
+__global__ __launch_bounds__(64) void k6_frame(const Plan6 *__restrict__ plans)
+{
+    __shared__ uint32_t s_map[FRAME_PIECE * PHASES6];
+    __shared__ uint32_t s_entry[FRAME_PIECE];
+    const Plan6 *P = plans + blockIdx.x;
+    const uint32_t lane = threadIdx.x, nsuper = P->nsuper;
+    uint32_t p = 0, n = 0; // the stream starts with a record at byte 0 (RawData_Legacy.cpp:476)
+    for (uint32_t base = 0; base < nsuper; base += FRAME_PIECE) {
+        const uint32_t cnt = min(static_cast<uint32_t>(FRAME_PIECE), nsuper - base);
+        const uint32_t *src = P->smap + static_cast<size_t>(base) * PHASES6;
+        for (uint32_t i = lane; i < cnt * PHASES6; i += 64u)
+            s_map[i] = src[i];
+        __syncthreads();
+        if (lane == 0) {
+            for (uint32_t s = 0; s < cnt; s++) {
+                s_entry[s] = p | (n << 8);
+                if (p != DEAD) {
+                    const uint32_t m = s_map[s * PHASES6 + p];
+                    n += m >> 8;
+                    p = m & 255u;
+                }
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = lane; i < cnt; i += 64u)
+            P->sentry[base + i] = s_entry[i];
+        p = __shfl(p, 0, 64);
+        n = __shfl(n, 0, 64);
+        __syncthreads();
+    }
+    // fewer records than height * recs_per_row inside `len`: the reference would
+    // skip the rest and return stale rows (RawData_Legacy.cpp:387-388)
+    if (lane == 0 && n < P->nrec)
+        atomicOr(P->status, MCRAW_E_TRUNCATED);
+}
+
+// ------------------------------------------------------------------ k6_chunks
+__global__ __launch_bounds__(64) void k6_chunks(const Plan6 *__restrict__ plans, const uint32_t *__restrict__ super_base,
+                                                int nframes)
+{
+    __shared__ uint32_t s_map[SUPER6 * PHASES6];
+    __shared__ uint32_t s_entry[SUPER6];
+    const int f = find_frame(blockIdx.x, super_base, nframes);
+    const Plan6 *P = plans + f;
+    if (*P->status != 0)
+        return;
+    const uint32_t sc = blockIdx.x - super_base[f];
+    const uint32_t first = sc * SUPER6;
+    const uint32_t cnt = min(static_cast<uint32_t>(SUPER6), P->nchunks - first);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t *src = P->cmap + static_cast<size_t>(first) * PHASES6;
+    for (uint32_t i = lane; i < cnt * PHASES6; i += 64u)
+        s_map[i] = src[i];
+    __syncthreads();
+    if (lane == 0) {
+        const uint32_t e = P->sentry[sc];
+        uint32_t p = e & 255u, n = e >> 8;
+        for (uint32_t c = 0; c < cnt; c++) {
+            s_entry[c] = p | (n << 8);
+            if (p != DEAD) {
+                const uint32_t m = s_map[c * PHASES6 + p];
+                n += m >> 8;
+                p = m & 255u;
+            }
+        }
+    }
+    __syncthreads();
+    if (lane < cnt)
+        P->centry[first + lane] = s_entry[lane];
+}
+
+// ------------------------------------------------------------------ k6_rows
+constexpr int ROW_STAGE = CHUNK6 + 64; // a record may start at byte 1022 and run 34 bytes; +8 for the bit window
+constexpr int ROW_MAXREC = CHUNK6 / 2;
+
+// 16 residuals of one record: an MSB-first bitstream of `sb`-bit fields
+// (sb = header nibble for <= 10, 16 for the big-endian raw form, RawData_Legacy.cpp:360-370).
+__device__ __forceinline__ void unpack16(const uint32_t *__restrict__ words, uint32_t boff, uint32_t sb,
+                                         uint32_t out[16])
+{
+#pragma unroll
+    for (uint32_t k = 0; k < 16u; k++) {
+        const uint32_t o = k * sb;            // bit offset of sample k in the payload
+        const uint32_t byte = boff + (o >> 3);
+        const uint32_t wi = byte >> 2;        // aligned dword pair holding the field
+        const uint32_t hi = __builtin_bswap32(words[wi]), lo = __builtin_bswap32(words[wi + 1u]);
+        const uint32_t bo = 8u * (byte & 3u) + (o & 7u);
+        const uint64_t win = ((static_cast<uint64_t>(hi) << 32) | lo) << bo;
+        out[k] = sb ? static_cast<uint32_t>(win >> (64u - sb)) : 0u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, const uint32_t *__restrict__ item_base,
+                                               int nframes)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_bytes[4][ROW_STAGE + 16];
+    __shared__ uint16_t s_rec[4][ROW_MAXREC];
+
+    const int f = find_frame(blockIdx.x, item_base, nframes);
+    const Plan6 *P = plans + f;
+    if (*P->status != 0)
+        return;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t c = (blockIdx.x - item_base[f]) * 4u + wave;
+    if (c >= P->nchunks)
+        return;
+    const uint32_t entry = __builtin_amdgcn_readfirstlane(P->centry[c]);
+    const uint32_t ph = entry & 255u, i0 = entry >> 8;
+    const uint32_t nrec = P->nrec, len = P->len;
+    if (ph == DEAD || i0 >= nrec)
+        return;
+    const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
+    const uint32_t cs = c * CHUNK6;
+
+    uint4 *dst = reinterpret_cast<uint4 *>(s_bytes[wave]);
+    dst[lane] = ld_b128(rs, cs + lane * 16u);
+    if (lane < (ROW_STAGE + 16 - CHUNK6) / 16)
+        dst[64 + lane] = ld_b128(rs, cs + CHUNK6 + lane * 16u);
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+
+    // list the records that start in this chunk (wave-uniform scalar walk)
+    const uint8_t *bytes = s_bytes[wave];
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(s_bytes[wave]);
+    uint32_t pos = 2u * ph, n = 0;
+    while (pos < CHUNK6 && i0 + n < nrec) {
+        const uint32_t hb = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(bytes[pos])) >> 4;
+        const uint32_t L = len6_of(hb);
+        if (cs + pos + 2u + L >= len)
+            break; // k6_frame has already failed the frame if records are missing
+        if (lane == 0)
+            s_rec[wave][n] = static_cast<uint16_t>(pos);
+        pos += 2u + L;
+        n++;
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+
+    const uint32_t rpr = P->recs_per_row;
+    const int32_t width = P->width;
+    const bool fast = P->fast_store != 0u;
+    const uint32_t pair0 = i0 >> 1;
+    const uint32_t npairs = ((i0 + n + 1u) >> 1) - pair0;
+    for (uint32_t q = lane; q < npairs; q += 64u) {
+        const uint32_t ra = 2u * (pair0 + q), rb = ra + 1u; // even-column and odd-column record
+        const bool hasA = ra >= i0 && ra < i0 + n;
+        const bool hasB = rb >= i0 && rb < i0 + n;
+        uint32_t va[16], vb[16];
+        uint32_t refA = 0, refB = 0;
+        if (hasA) {
+            const uint32_t ro = s_rec[wave][ra - i0];
+            const uint32_t hb = bytes[ro] >> 4;                     // RawData_Legacy.cpp:372-375
+            refA = ((static_cast<uint32_t>(bytes[ro]) & 15u) << 8) | bytes[ro + 1u];
+            unpack16(words, ro + 2u, hb <= 10u ? hb : 16u, va);
+        }
+        if (hasB) {
+            const uint32_t ro = s_rec[wave][rb - i0];
+            const uint32_t hb = bytes[ro] >> 4;
+            refB = ((static_cast<uint32_t>(bytes[ro]) & 15u) << 8) | bytes[ro + 1u];
+            unpack16(words, ro + 2u, hb <= 10u ? hb : 16u, vb);
+        }
+        const uint32_t y = ra / rpr;
+        const uint32_t x = ((ra - y * rpr) >> 1) * 32u; // RawData_Legacy.cpp:479-486
+        uint16_t *row = P->out + static_cast<size_t>(y) * static_cast<size_t>(width);
+        if (hasA && hasB && fast && x + 32u <= static_cast<uint32_t>(width)) {
+            uint32_t o[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                o[i] = ((va[i] + refA) & 0xffffu) | ((vb[i] + refB) << 16);
+            uint4 *d4 = reinterpret_cast<uint4 *>(row + x);
+            d4[0] = make_uint4(o[0], o[1], o[2], o[3]);
+            d4[1] = make_uint4(o[4], o[5], o[6], o[7]);
+            d4[2] = make_uint4(o[8], o[9], o[10], o[11]);
+            d4[3] = make_uint4(o[12], o[13], o[14], o[15]);
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < 16u; i++) {
+                if (hasA && x + 2u * i < static_cast<uint32_t>(width))
+                    row[x + 2u * i] = static_cast<uint16_t>(va[i] + refA);
+                if (hasB && x + 2u * i + 1u < static_cast<uint32_t>(width))
+                    row[x + 2u * i + 1u] = static_cast<uint16_t>(vb[i] + refB);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ launchers
+
+void launch_k6_maps(const Plan6 *plans, const uint32_t *item_base, int nframes, uint32_t nitems, hipStream_t st)
+{
+    hipLaunchKernelGGL(k6_maps, dim3(nitems), dim3(256), 0, st, plans, item_base, nframes);
+}
+
+void launch_k6_resolve(const Plan6 *plans, const uint32_t *super_base, int nframes, uint32_t nsuper_items,
+                       hipStream_t st)
+{
+    hipLaunchKernelGGL(k6_super, dim3(nsuper_items), dim3(64), 0, st, plans, super_base, nframes);
+    hipLaunchKernelGGL(k6_frame, dim3(nframes), dim3(64), 0, st, plans);
+    hipLaunchKernelGGL(k6_chunks, dim3(nsuper_items), dim3(64), 0, st, plans, super_base, nframes);
+}
+
+void launch_k6_rows(const Plan6 *plans, const uint32_t *item_base, int nframes, uint32_t nitems, hipStream_t st)
+{
+    hipLaunchKernelGGL(k6_rows, dim3(nitems), dim3(256), 0, st, plans, item_base, nframes);
+}
+
+} // namespace mcraw

@@ -1,0 +1,59 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol that
+include/mcraw_hip.h declares.  No compute calls (no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import motioncam_decoder_amd as M
+from motioncam_decoder_amd import build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build_hip()
+    return M.load()
+
+
+def test_header_symbols_all_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "mcraw_hip.h")).read()
+    declared = set(re.findall(r"\b(mcraw_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(M.ABI_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_code_object_is_gfx950():
+    raw = open(M.lib_path(), "rb").read()
+    assert b"gfx950" in raw
+    for k in (b"k7_tiles", b"k7_walk", b"k7_meta", b"k7_scan", b"k6_maps", b"k6_rows"):
+        assert k in raw, k
+
+
+def test_no_cpu_fallback_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = ctypes.c_void_p()
+    assert lib.mcraw_ctx_create(0, ctypes.byref(h)) != 0
+    assert not h.value
+    assert b"no CPU fallback" in lib.mcraw_last_error() or lib.mcraw_last_error()
+    with pytest.raises(M.McrawError):
+        M.Context(0)
+    # the drop-in single-frame entry fails (returns 0) instead of decoding on the CPU
+    import numpy as np
+    out = np.zeros(128 * 8, np.uint16)
+    buf = np.zeros(64, np.uint8)
+    assert lib.mcraw_decode7(out.ctypes.data, 128, 8, buf.ctypes.data, buf.size) == 0
+
+
+def test_product_does_not_link_oracle():
+    # the shipped library must not reference the oracle or the reference build
+    raw = open(M.lib_path(), "rb").read()
+    assert b"mcraw_oracle" not in raw and b"mcraw_ref_" not in raw
+    for f in os.listdir(os.path.join(ROOT, "motioncam_decoder_amd", "csrc")):
+        src = open(os.path.join(ROOT, "motioncam_decoder_amd", "csrc", f)).read()
+        assert "oracle" not in src.lower(), f

@@ -1,0 +1,76 @@
+"""GPU (-m gpu): malformed frames fail cleanly -- nonzero status, 0 written, no fault,
+and well-formed neighbours in the same batch still decode."""
+import numpy as np
+import pytest
+
+import _libs as L
+import motioncam_decoder_amd as M
+
+pytestmark = pytest.mark.gpu
+
+
+def _u32(v):
+    return np.frombuffer(np.uint32(v).tobytes(), np.uint8)
+
+
+def test_malformed_type7_frames(gpu_ctx):
+    from _gpu import decode_batch_device
+    img = L.natural_image_np(256, 16, 12, 12.0, 3)
+    good = L.encode7(img)
+    bits_off = int(np.frombuffer(good[8:12].tobytes(), np.uint32)[0])
+    cases = [("good", good, 0)]
+    cases.append(("cut1", good[:-1], M.E_TRUNCATED))
+    cases.append(("cut_half", good[: good.size // 2], None))
+    cases.append(("tiny", good[:8], None))
+    b = good.copy(); b[0:4] = _u32(100); cases.append(("encW%64", b, M.E_HEADER))
+    b = good.copy(); b[0:4] = _u32(64); cases.append(("encW<w", b, M.E_HEADER))
+    b = good.copy(); b[8:12] = _u32(1 << 30); cases.append(("bitsOff>len", b, M.E_HEADER))
+    b = good.copy(); b[12:16] = _u32(1 << 30); cases.append(("refsOff>len", b, M.E_HEADER))
+    b = good.copy(); b[bits_off + 4] |= 0x0F; cases.append(("bits>16", b, M.E_SIDESTREAM))
+    b = good.copy(); b[bits_off:bits_off + 4] = _u32(3); cases.append(("count<N", b, M.E_SIDESTREAM))
+    b = good.copy(); b[4:8] = _u32(1 << 20); cases.append(("encH huge", b, None))
+    cases.append(("good2", good, 0))
+    items = [(7, 256, 16, c[1]) for c in cases]
+    written, status, outs = decode_batch_device(gpu_ctx, items)
+    for (name, _, want), wr, st, out in zip(cases, written, status, outs):
+        if want == 0:
+            assert st == 0 and wr == 256 * 16 and np.array_equal(out, img), name
+        else:
+            assert st != 0 and wr == 0, (name, st, wr)
+            if want is not None:
+                assert st & want, (name, hex(st))
+
+
+def test_malformed_legacy_frames(gpu_ctx):
+    from _gpu import decode_batch_device
+    img = L.natural_image_np(160, 24, 10, 4.0, 9)
+    good = L.encode6(img)
+    cases = [("good", good, True), ("no_trailing_byte", good[:-1], False), ("half", good[: good.size // 2], False),
+             ("two_bytes", good[:2], False), ("good2", good, True)]
+    written, status, outs = decode_batch_device(gpu_ctx, [(6, 160, 24, c[1]) for c in cases])
+    for (name, _, ok), wr, st, out in zip(cases, written, status, outs):
+        if ok:
+            assert st == 0 and wr == 160 * 24 and np.array_equal(out, img), name
+        else:
+            assert st & M.E_TRUNCATED and wr == 0, (name, st)
+
+
+def test_bad_arguments(gpu_ctx):
+    from _gpu import decode_batch_device
+    img = L.natural_image_np(128, 8, 12, 12.0, 1)
+    buf = L.encode7(img)
+    written, status, _ = decode_batch_device(gpu_ctx, [(5, 128, 8, buf), (7, 128, 8, buf)])
+    assert status[0] & M.E_ARGS and written[0] == 0
+    assert status[1] == 0 and written[1] == 128 * 8
+
+
+def test_header_geometry_differs_from_rounded_size(gpu_ctx):
+    # a frame coded wider/taller than ceil64(w) x ceil4(h) is re-planned from its real header
+    from _gpu import decode_batch_device
+    big = L.natural_image_np(320, 24, 12, 12.0, 11)
+    buf = L.encode7(big)          # encW=320, encH=24
+    ret, want = L.oracle_decode7(buf, 200, 16)   # caller keeps a 200x16 window
+    assert ret == 200 * 16
+    written, status, outs = decode_batch_device(gpu_ctx, [(7, 200, 16, buf)])
+    assert status == [0] and written == [200 * 16]
+    assert np.array_equal(outs[0], want) and np.array_equal(want, big[:16, :200])
