@@ -60,6 +60,14 @@ def load():
     if not os.path.exists(p):
         raise McrawError("HIP decode library not built: %s (run `python -m motioncam_decoder_amd.build`); "
                          "there is no CPU fallback" % p)
+    # A process that also uses torch must share ONE HIP runtime with it: torch bundles its
+    # own libamdhip64 (same SONAME as /opt/rocm's).  Loading torch first makes this library
+    # bind to the runtime torch initialises; the other order maps two runtimes and the
+    # second one sees no device.  (A C++ host without torch simply uses /opt/rocm's.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(p)
     lib.mcraw_ctx_create.restype = C.c_int
     lib.mcraw_ctx_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]

@@ -25,13 +25,16 @@ __device__ __forceinline__ uint32_t cls7_of(uint32_t b)
 
 // Bounds-checked byte-buffer descriptor over one frame buffer: reads past
 // `len` return 0 instead of faulting (corrupt offsets cannot leave the frame).
+// The range check of a raw buffer works on whole dwords, so the record count is
+// `len` rounded up to 4: the last 1-3 bytes of an odd-sized frame stay readable
+// (the dword that holds them lies inside the 4-byte aligned allocation).
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t frame_rsrc(const uint8_t *in, uint32_t len)
 {
     // descriptor inputs must be provably wave-uniform (no waterfall loops)
     uint64_t a = reinterpret_cast<uint64_t>(in);
     uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(a));
     uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(a >> 32));
-    uint32_t n = __builtin_amdgcn_readfirstlane(len);
+    uint32_t n = __builtin_amdgcn_readfirstlane((len + 3u) & ~3u);
     void *p = reinterpret_cast<void *>((static_cast<uint64_t>(hi) << 32) | lo);
     return __builtin_amdgcn_make_buffer_rsrc(p, 0, static_cast<int>(n), 0x00020000);
 }
