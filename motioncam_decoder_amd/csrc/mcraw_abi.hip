@@ -19,10 +19,7 @@
 #include "mcraw_plan.h"
 
 namespace mcraw {
-void launch_k7_walk(const Plan7 *plans, int nframes, hipStream_t st);
-void launch_k7_meta(const Plan7 *plans, const uint32_t *item_base, int nframes, uint32_t nitems, hipStream_t st);
-void launch_k7_scan(const Plan7 *plans, int nframes, hipStream_t st);
-void launch_k7_tiles(const Plan7 *plans, const uint32_t *item_base, int nframes, uint32_t nitems, hipStream_t st);
+void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st);
 void launch_k6_maps(const Plan6 *plans, const uint32_t *item_base, int nframes, uint32_t nitems, hipStream_t st);
 void launch_k6_resolve(const Plan6 *plans, const uint32_t *super_base, int nframes, uint32_t nsuper_items,
                        hipStream_t st);
@@ -64,6 +61,11 @@ struct Slot {
     Buf dev_in;  // HBM staging of inputs  (MCRAW_MEM_HOST)
     Buf dev_out; // HBM staging of outputs (MCRAW_MEM_HOST)
     Buf status_host; // pinned: statuses copied back
+    // Device statuses are kept in plan order (type-7 frames, then legacy frames) so a kernel
+    // finds its word from its frame index alone; `order` maps them back to the caller's
+    // frame indices and `host_status` holds what the host decided on its own (bad arguments).
+    std::vector<int> order;
+    std::vector<int32_t> host_status;
     hipEvent_t done = nullptr;
     hipStream_t stream = nullptr; // the slot's own stream (host-memory pipeline)
     bool busy = false;
@@ -174,7 +176,7 @@ inline size_t carve(size_t &off, size_t bytes)
 
 struct Layout { // byte offsets inside the slot arena / upload image
     size_t status = 0;                                   // int32[n]
-    size_t plans7 = 0, meta_base = 0, tile_base = 0;     // Plan7[n7], u32[n7+1] x2
+    size_t plans7 = 0;                                   // Plan7[n7]
     size_t plans6 = 0, map_base = 0, super_base = 0, row_base = 0;
     size_t upload_bytes = 0;                             // tables end here, workspace follows
     size_t total = 0;
@@ -251,25 +253,23 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     // ---- lay out the upload image and the workspace ------------------------
     Layout L;
     size_t off = 0;
-    L.status = carve(off, sizeof(int32_t) * n);
+    L.status = carve(off, sizeof(int32_t) * (n7 + n6 + 1));
     L.plans7 = carve(off, sizeof(Plan7) * n7);
-    L.meta_base = carve(off, sizeof(uint32_t) * (n7 + 1));
-    L.tile_base = carve(off, sizeof(uint32_t) * (n7 + 1));
     L.plans6 = carve(off, sizeof(Plan6) * n6);
     L.map_base = carve(off, sizeof(uint32_t) * (n6 + 1));
     L.super_base = carve(off, sizeof(uint32_t) * (n6 + 1));
     L.row_base = carve(off, sizeof(uint32_t) * (n6 + 1));
     L.upload_bytes = off;
 
-    std::vector<size_t> w_rec(n7), w_bits(n7), w_refs(n7), w_grp(n7);
-    for (int k = 0; k < n7; k++) {
-        const Plan7 &p = B.p7[k];
-        const size_t R = p.ngroups;
-        w_rec[k] = carve(off, sizeof(uint32_t) * 2 * R);
-        w_bits[k] = carve(off, R * 64);
-        w_refs[k] = carve(off, R * 64 * sizeof(uint16_t));
-        w_grp[k] = carve(off, sizeof(uint32_t) * (R + 1));
-    }
+    // type-7 workspace: one stride for every frame (the largest frame's), so the
+    // kernels address it from (frame, group) alone
+    size_t Rmax = 0;
+    for (const Plan7 &p : B.p7)
+        Rmax = std::max<size_t>(Rmax, p.ngroups);
+    const size_t w_rec = carve(off, sizeof(uint32_t) * 2 * Rmax * n7);
+    const size_t w_bits = carve(off, Rmax * 64 * n7);
+    const size_t w_refs = carve(off, Rmax * 64 * sizeof(uint16_t) * n7);
+    const size_t w_grp = carve(off, sizeof(uint32_t) * (Rmax + 1) * n7);
     std::vector<size_t> w_cmap(n6), w_smap(n6), w_centry(n6), w_sentry(n6);
     for (int k = 0; k < n6; k++) {
         const Plan6 &p = B.p6[k];
@@ -287,24 +287,10 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     uint8_t *dev = static_cast<uint8_t *>(s.arena.p);
     uint8_t *img = static_cast<uint8_t *>(s.pinned.p);
 
-    std::memcpy(img + L.status, status.data(), sizeof(int32_t) * n);
-    uint32_t *meta_base = reinterpret_cast<uint32_t *>(img + L.meta_base);
-    uint32_t *tile_base = reinterpret_cast<uint32_t *>(img + L.tile_base);
-    uint32_t nmeta = 0, ntile = 0;
-    for (int k = 0; k < n7; k++) {
-        Plan7 &p = B.p7[k];
-        p.rec_off = reinterpret_cast<uint32_t *>(dev + w_rec[k]);
-        p.bits = dev + w_bits[k];
-        p.refs = reinterpret_cast<uint16_t *>(dev + w_refs[k]);
-        p.grp_off = reinterpret_cast<uint32_t *>(dev + w_grp[k]);
-        p.status = reinterpret_cast<int32_t *>(dev + L.status) + B.idx7[k];
-        meta_base[k] = nmeta;
-        tile_base[k] = ntile;
-        nmeta += (2 * p.ngroups + 3) / 4; // 4 records per workgroup
-        ntile += p.ngroups;
-    }
-    meta_base[n7] = nmeta;
-    tile_base[n7] = ntile;
+    std::memset(img + L.status, 0, sizeof(int32_t) * (n7 + n6 + 1));
+    s.host_status = status;
+    s.order = B.idx7;
+    s.order.insert(s.order.end(), B.idx6.begin(), B.idx6.end());
     if (n7)
         std::memcpy(img + L.plans7, B.p7.data(), sizeof(Plan7) * n7);
 
@@ -318,7 +304,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         p.smap = reinterpret_cast<uint32_t *>(dev + w_smap[k]);
         p.centry = reinterpret_cast<uint32_t *>(dev + w_centry[k]);
         p.sentry = reinterpret_cast<uint32_t *>(dev + w_sentry[k]);
-        p.status = reinterpret_cast<int32_t *>(dev + L.status) + B.idx6[k];
+        p.status = reinterpret_cast<int32_t *>(dev + L.status) + n7 + k;
         map_base[k] = nmap;
         super_base[k] = nsup;
         row_base[k] = nrow;
@@ -336,22 +322,18 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
 
     // ---- launches -----------------------------------------------------------
     if (n7) {
-        const Plan7 *dp = reinterpret_cast<const Plan7 *>(dev + L.plans7);
-        {
-            KTimer t(c, MCRAW_K7_WALK, st);
-            launch_k7_walk(dp, n7, st);
-        }
-        {
-            KTimer t(c, MCRAW_K7_META, st);
-            launch_k7_meta(dp, reinterpret_cast<const uint32_t *>(dev + L.meta_base), n7, nmeta, st);
-        }
-        {
-            KTimer t(c, MCRAW_K7_SCAN, st);
-            launch_k7_scan(dp, n7, st);
-        }
-        {
-            KTimer t(c, MCRAW_K7_TILES, st);
-            launch_k7_tiles(dp, reinterpret_cast<const uint32_t *>(dev + L.tile_base), n7, ntile, st);
+        Work7 W{};
+        W.plans = reinterpret_cast<const Plan7 *>(dev + L.plans7);
+        W.status = reinterpret_cast<int32_t *>(dev + L.status);
+        W.rec_off = reinterpret_cast<uint32_t *>(dev + w_rec);
+        W.bits = dev + w_bits;
+        W.refs = reinterpret_cast<uint16_t *>(dev + w_refs);
+        W.grp_off = reinterpret_cast<uint32_t *>(dev + w_grp);
+        W.Rmax = static_cast<uint32_t>(Rmax);
+        W.n7 = n7;
+        for (uint32_t stage : {MCRAW_K7_WALK, MCRAW_K7_META, MCRAW_K7_SCAN, MCRAW_K7_TILES}) {
+            KTimer t(c, static_cast<int>(stage), st);
+            launch_k7(W, stage, st);
         }
     }
     if (n6) {
@@ -386,15 +368,22 @@ int acquire_slot(mcraw_ctx *c, Slot **out)
     return 0;
 }
 
-// Fetch statuses of a finished-or-running batch (synchronises on the slot).
+// Fetch statuses of a finished-or-running batch (synchronises on the stream).
 int fetch_status(mcraw_ctx *c, Slot &s, size_t status_off, int n, hipStream_t st, int32_t *status)
 {
-    if (int rc = ensure(s.status_host, sizeof(int32_t) * std::max(n, 1), true))
+    const int ndev = static_cast<int>(s.order.size());
+    if (int rc = ensure(s.status_host, sizeof(int32_t) * std::max(ndev, 1), true))
         return rc;
-    HIP_TRY(hipMemcpyAsync(s.status_host.p, static_cast<uint8_t *>(s.arena.p) + status_off, sizeof(int32_t) * n,
-                           hipMemcpyDeviceToHost, st));
+    if (ndev)
+        HIP_TRY(hipMemcpyAsync(s.status_host.p, static_cast<uint8_t *>(s.arena.p) + status_off, sizeof(int32_t) * ndev,
+                               hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    std::memcpy(status, s.status_host.p, sizeof(int32_t) * n);
+    const int32_t *dev = static_cast<const int32_t *>(s.status_host.p);
+    for (int i = 0; i < n && i < static_cast<int>(s.host_status.size()); i++)
+        status[i] = s.host_status[i];
+    for (int j = 0; j < ndev; j++)
+        if (s.order[j] < n)
+            status[s.order[j]] |= dev[j];
     (void)c;
     return 0;
 }

@@ -15,7 +15,7 @@ constexpr int GROUP_TILES = 16;    // 64x4 tiles per group
 constexpr int SPAN_MAX = 64 * 128; // largest payload span of one group (all raw-16)
 
 // Per-frame plan of the current ("type 7") encoding; lives in HBM for the
-// duration of one batch.  All workspace pointers are device pointers.
+// duration of one batch.
 struct Plan7 {
     const uint8_t *in;   // frame buffer (lib/RawData.cpp:528 `input`)
     uint16_t *out;       // width x rows mosaic
@@ -27,11 +27,21 @@ struct Plan7 {
     uint32_t nblk;       // N = 4 * tilesX * encH/4  (payload blocks = side-stream entries used)
     uint32_t ngroups;    // R = ceil(N / 64)
     uint32_t fast_store; // 1: out 16-B aligned and width % 8 == 0
-    uint32_t *rec_off;   // [2][R] byte offset of every side-stream record header
-    uint8_t *bits;       // [R*64] decoded `bits` stream  (:557)
-    uint16_t *refs;      // [R*64] decoded `refs` stream  (:560)
-    uint32_t *grp_off;   // [R+1]  payload byte offset of every 64-block group (:562 + prefix of LEN)
-    int32_t *status;     // this frame's status word
+};
+
+// Batch-wide view of the type-7 work, passed to the kernels BY VALUE (kernarg):
+// every workspace array has the same per-frame stride (sized for the largest
+// frame of the batch), so a workgroup finds its slice from (frame, group)
+// without any dependent pointer load.
+struct Work7 {
+    const Plan7 *plans;  // [n7]
+    int32_t *status;     // [n7] status word of every type-7 frame
+    uint32_t *rec_off;   // [n7][2][Rmax]  byte offset of every side-stream record header
+    uint8_t *bits;       // [n7][Rmax*64]  decoded `bits` stream  (:557)
+    uint16_t *refs;      // [n7][Rmax*64]  decoded `refs` stream  (:560)
+    uint32_t *grp_off;   // [n7][Rmax+1]   payload byte offset of every 64-block group (:562 + prefix of LEN)
+    uint32_t Rmax;       // largest ngroups in the batch
+    int32_t n7;
 };
 
 // Per-frame plan of the legacy ("type 6") encoding.

@@ -70,13 +70,14 @@ __device__ __forceinline__ uint32_t term_shl(uint32_t t) { return (t >> 24) & 31
 // the current one is walked) and chases the headers with scalar code.
 constexpr int PIECE = 4096;
 
-__global__ __launch_bounds__(64) void k7_walk(const Plan7 *__restrict__ plans)
+__global__ __launch_bounds__(64) void k7_walk(const Work7 W)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_piece[2][PIECE];
 
     const int f = blockIdx.x >> 1;
     const int s = blockIdx.x & 1;
-    const Plan7 *P = plans + f;
+    const Plan7 *P = W.plans + f;
+    int32_t *status = W.status + f;
     const uint32_t lane = threadIdx.x;
     const uint32_t len = P->len;
     const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
@@ -101,12 +102,12 @@ __global__ __launch_bounds__(64) void k7_walk(const Plan7 *__restrict__ plans)
     }
     if (err) {
         if (lane == 0)
-            atomicOr(P->status, err);
+            atomicOr(status, err);
         return;
     }
 
     const uint32_t R = P->ngroups;
-    uint32_t *__restrict__ rec_off = P->rec_off + static_cast<size_t>(s) * R;
+    uint32_t *__restrict__ rec_off = W.rec_off + (static_cast<size_t>(f) * 2u + s) * W.Rmax;
     uint32_t pos = __builtin_amdgcn_readfirstlane(so + 4u);
     uint32_t pb = pos & ~15u;
 
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(64) void k7_walk(const Plan7 *__restrict__ plans)
     }
     if (bad) {
         if (lane == 0)
-            atomicOr(P->status, MCRAW_E_TRUNCATED);
+            atomicOr(status, MCRAW_E_TRUNCATED);
         return;
     }
     const uint32_t tail = i & 63u;
@@ -163,22 +164,22 @@ __global__ __launch_bounds__(64) void k7_walk(const Plan7 *__restrict__ plans)
 // One wave per side-stream record, lane = entry.  Same unpack as a payload block
 // (DecodeBlock on the record, RawData.cpp:489) plus the record's reference
 // (:491-492).  Bits records also emit the byte length of their 64-block group.
-__global__ __launch_bounds__(256) void k7_meta(const Plan7 *__restrict__ plans, const uint32_t *__restrict__ item_base,
-                                               int nframes)
+__global__ __launch_bounds__(256) void k7_meta(const Work7 W)
 {
-    const int f = find_frame(blockIdx.x, item_base, nframes);
-    const Plan7 *P = plans + f;
-    if (*P->status != 0)
+    const uint32_t f = blockIdx.y;
+    const Plan7 *P = W.plans + f;
+    int32_t *status = W.status + f;
+    if (*status != 0)
         return;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t R = P->ngroups;
-    const uint32_t rec = (blockIdx.x - item_base[f]) * 4u + (threadIdx.x >> 6);
+    const uint32_t rec = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (rec >= 2u * R)
         return;
     const uint32_t s = rec >= R ? 1u : 0u;
     const uint32_t r = rec - s * R;
     const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, P->len);
-    const uint32_t off = __builtin_amdgcn_readfirstlane(P->rec_off[rec]);
+    const uint32_t off = __builtin_amdgcn_readfirstlane(W.rec_off[(static_cast<size_t>(f) * 2u + s) * W.Rmax + r]);
     const uint32_t b0 = ld_u8(rs, off), b1 = ld_u8(rs, off + 1u);
     const uint32_t hb = b0 >> 4;                   // RawData.cpp:106-110
     const uint32_t ref = ((b0 & 15u) << 8) | b1;
@@ -206,15 +207,15 @@ __global__ __launch_bounds__(256) void k7_meta(const Plan7 *__restrict__ plans, 
     if (s == 0u) {
         const bool used = idx < P->nblk;
         if (used && v > 16u) { // would index past ENCODING_BLOCK_LENGTH (RawData.cpp:419)
-            atomicOr(P->status, MCRAW_E_SIDESTREAM);
+            atomicOr(status, MCRAW_E_SIDESTREAM);
             v = 16u;
         }
-        P->bits[idx] = static_cast<uint8_t>(v);
+        W.bits[static_cast<size_t>(f) * W.Rmax * 64u + idx] = static_cast<uint8_t>(v);
         const uint32_t sum = wave_sum(used ? len7_of(v) : 0u);
         if (lane == 0)
-            P->grp_off[r] = sum; // lengths until k7_scan turns them into offsets
+            W.grp_off[static_cast<size_t>(f) * (W.Rmax + 1u) + r] = sum; // lengths until k7_scan
     } else {
-        P->refs[idx] = static_cast<uint16_t>(v);
+        W.refs[static_cast<size_t>(f) * W.Rmax * 64u + idx] = static_cast<uint16_t>(v);
     }
 }
 
@@ -222,14 +223,15 @@ __global__ __launch_bounds__(256) void k7_meta(const Plan7 *__restrict__ plans, 
 //
 // Payload offset of every group: 16 + sum of the lengths before it
 // (RawData.cpp:562 `offset = METADATA_OFFSET`, :576-579 `offset += ...`).
-__global__ __launch_bounds__(256) void k7_scan(const Plan7 *__restrict__ plans)
+__global__ __launch_bounds__(256) void k7_scan(const Work7 W)
 {
     __shared__ uint32_t s_w[4];
-    const Plan7 *P = plans + blockIdx.x;
-    if (*P->status != 0)
+    const Plan7 *P = W.plans + blockIdx.x;
+    int32_t *status = W.status + blockIdx.x;
+    if (*status != 0)
         return;
     const uint32_t R = P->ngroups, tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    uint32_t *__restrict__ g = P->grp_off;
+    uint32_t *__restrict__ g = W.grp_off + static_cast<size_t>(blockIdx.x) * (W.Rmax + 1u);
     uint32_t carry = 16u;
     for (uint32_t base = 0; base < R; base += 256u) {
         const uint32_t i = base + tid;
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(256) void k7_scan(const Plan7 *__restrict__ plans)
     if (tid == 0) {
         g[R] = carry;
         if (carry > P->len) // some block crosses `len` (RawData.cpp:419-420)
-            atomicOr(P->status, MCRAW_E_TRUNCATED);
+            atomicOr(status, MCRAW_E_TRUNCATED);
     }
 }
 
@@ -305,29 +307,30 @@ __device__ __forceinline__ Unpacked unpack8(const uint8_t *__restrict__ blk, uin
 
 constexpr int PAY_LDS = SPAN_MAX + 16 + 32; // span + 16-B alignment head + slack for zero-length tails
 
-__global__ __launch_bounds__(256) void k7_tiles(const Plan7 *__restrict__ plans, const uint32_t *__restrict__ item_base,
-                                                int nframes)
+__global__ __launch_bounds__(256) void k7_tiles(const Work7 W)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_pay[PAY_LDS];
     __shared__ uint4 s_tab[72];
     __shared__ uint32_t s_blk[GROUP_BLOCKS]; // byte offset in span | class << 16
     __shared__ uint16_t s_ref[GROUP_BLOCKS];
 
-    const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
-    const int f = find_frame(item, item_base, nframes);
-    const Plan7 *P = plans + f;
-    if (*P->status != 0)
+    // grid = (Rmax groups, n7 frames); consecutive items share an XCD (adjacent spans / rows)
+    const uint32_t item = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const uint32_t f = item / gridDim.x;
+    const uint32_t g = item - f * gridDim.x;
+    const Plan7 *P = W.plans + f;
+    if (g >= P->ngroups || W.status[f] != 0)
         return;
-    const uint32_t g = item - item_base[f];
     const uint32_t tid = threadIdx.x;
     const uint32_t nblk = P->nblk;
 
     // span of this group in the frame buffer
-    const uint32_t start = __builtin_amdgcn_readfirstlane(P->grp_off[g]);
-    const uint32_t end = __builtin_amdgcn_readfirstlane(P->grp_off[g + 1u]);
+    const uint32_t *grp = W.grp_off + static_cast<size_t>(f) * (W.Rmax + 1u) + g;
+    const uint32_t start = __builtin_amdgcn_readfirstlane(grp[0]);
+    const uint32_t end = __builtin_amdgcn_readfirstlane(grp[1]);
     const uint32_t base16 = start & ~15u;
     const uint32_t head = start - base16;
-    const uint32_t n16 = (end - base16 + 15u) >> 4; // <= 513
+    const uint32_t n16 = min((end - base16 + 15u) >> 4, 513u); // never more than SPAN_MAX + head
 
     const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, P->len);
     uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0;
@@ -344,8 +347,9 @@ __global__ __launch_bounds__(256) void k7_tiles(const Plan7 *__restrict__ plans,
     if (tid < 64u) { // wave 0: per-block class, reference and offset inside the span
         const uint32_t blk = g * 64u + tid;
         const bool used = blk < nblk;
-        const uint32_t b = used ? P->bits[blk] : 0u;
-        const uint32_t r = used ? P->refs[blk] : 0u;
+        const size_t mo = static_cast<size_t>(f) * W.Rmax * 64u + blk;
+        const uint32_t b = used ? W.bits[mo] : 0u;
+        const uint32_t r = used ? W.refs[mo] : 0u;
         uint32_t total;
         const uint32_t ex = wave_excl_scan(len7_of(b), tid, &total);
         s_blk[tid] = (head + ex) | (cls7_of(b) << 16);
@@ -407,21 +411,23 @@ __global__ __launch_bounds__(256) void k7_tiles(const Plan7 *__restrict__ plans,
 
 // ------------------------------------------------------------------ launchers
 
-void launch_k7_walk(const Plan7 *plans, int nframes, hipStream_t st)
+void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st)
 {
-    hipLaunchKernelGGL(k7_walk, dim3(2 * nframes), dim3(64), 0, st, plans);
-}
-void launch_k7_meta(const Plan7 *plans, const uint32_t *item_base, int nframes, uint32_t nitems, hipStream_t st)
-{
-    hipLaunchKernelGGL(k7_meta, dim3(nitems), dim3(256), 0, st, plans, item_base, nframes);
-}
-void launch_k7_scan(const Plan7 *plans, int nframes, hipStream_t st)
-{
-    hipLaunchKernelGGL(k7_scan, dim3(nframes), dim3(256), 0, st, plans);
-}
-void launch_k7_tiles(const Plan7 *plans, const uint32_t *item_base, int nframes, uint32_t nitems, hipStream_t st)
-{
-    hipLaunchKernelGGL(k7_tiles, dim3(nitems), dim3(256), 0, st, plans, item_base, nframes);
+    const uint32_t n7 = static_cast<uint32_t>(W.n7);
+    switch (stage) {
+    case MCRAW_K7_WALK:
+        hipLaunchKernelGGL(k7_walk, dim3(2 * n7), dim3(64), 0, st, W);
+        break;
+    case MCRAW_K7_META:
+        hipLaunchKernelGGL(k7_meta, dim3((2 * W.Rmax + 3) / 4, n7), dim3(256), 0, st, W);
+        break;
+    case MCRAW_K7_SCAN:
+        hipLaunchKernelGGL(k7_scan, dim3(n7), dim3(256), 0, st, W);
+        break;
+    case MCRAW_K7_TILES:
+        hipLaunchKernelGGL(k7_tiles, dim3(W.Rmax, n7), dim3(256), 0, st, W);
+        break;
+    }
 }
 
 } // namespace mcraw
