@@ -10,6 +10,9 @@
 // Integer bit-slicing on byte planes; no MFMA.  A "group" is the 64 payload
 // blocks (16 tiles of 64x4 px) described by one record of the bits stream; its
 // payload is one contiguous, 8-byte aligned span of <= 8 KiB.
+#include <algorithm>
+#include <cstdlib>
+
 #include "mcraw_dev.h"
 
 #include "../../include/mcraw_hip.h"
@@ -307,81 +310,137 @@ __device__ __forceinline__ Unpacked unpack8(const uint8_t *__restrict__ blk, uin
 
 constexpr int PAY_LDS = SPAN_MAX + 16 + 32; // span + 16-B alignment head + slack for zero-length tails
 
-__global__ __launch_bounds__(256) void k7_tiles(const Work7 W)
+// Wave-uniform description of one work item (frame f, group g).
+struct ItemS {
+    uint32_t valid;      // 0: nothing to do (group beyond the frame, or the frame already failed)
+    uint32_t g, nblk, tilesX;
+    uint32_t base16, n16, head; // 16-byte aligned span start, chunks to stage, start - base16
+    int32_t width, rows;
+    uint32_t fast;
+    const uint8_t *in;
+    uint32_t len;
+    uint16_t *out;
+    size_t meta;         // index of the group's first entry in W.bits / W.refs
+};
+
+// Per-lane loads in flight for one item.
+struct ItemV {
+    uint4 v0, v1, v2;    // 16-byte chunks tid, tid+256, tid+512 of the span
+    uint32_t b, r;       // wave 0: `bits` and `refs` entry of block tid
+};
+
+__device__ __forceinline__ ItemS item_scalars(const Work7 &W, uint32_t item)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_pay[PAY_LDS];
-    __shared__ uint4 s_tab[72];
-    __shared__ uint32_t s_blk[GROUP_BLOCKS]; // byte offset in span | class << 16
-    __shared__ uint16_t s_ref[GROUP_BLOCKS];
-
-    // grid = (Rmax groups, n7 frames); consecutive items share an XCD (adjacent spans / rows)
-    const uint32_t item = xcd_remap(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    const uint32_t f = item / gridDim.x;
-    const uint32_t g = item - f * gridDim.x;
+    ItemS I;
+    const uint32_t f = item / W.Rmax;
+    const uint32_t g = item - f * W.Rmax;
     const Plan7 *P = W.plans + f;
-    if (g >= P->ngroups || W.status[f] != 0)
-        return;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t nblk = P->nblk;
-
-    // span of this group in the frame buffer
     const uint32_t *grp = W.grp_off + static_cast<size_t>(f) * (W.Rmax + 1u) + g;
-    const uint32_t start = __builtin_amdgcn_readfirstlane(grp[0]);
-    const uint32_t end = __builtin_amdgcn_readfirstlane(grp[1]);
-    const uint32_t base16 = start & ~15u;
-    const uint32_t head = start - base16;
-    const uint32_t n16 = min((end - base16 + 15u) >> 4, 513u); // never more than SPAN_MAX + head
+    const uint32_t start = grp[0], end = grp[1];
+    I.valid = (g < P->ngroups && W.status[f] == 0) ? 1u : 0u;
+    I.g = g;
+    I.nblk = P->nblk;
+    I.tilesX = P->tilesX;
+    I.base16 = start & ~15u;
+    I.head = start - I.base16;
+    I.n16 = I.valid ? min((end - I.base16 + 15u) >> 4, 513u) : 0u; // never more than SPAN_MAX + head
+    I.width = P->width;
+    I.rows = P->rows;
+    I.fast = P->fast_store;
+    I.in = P->in;
+    I.len = P->len;
+    I.out = P->out;
+    I.meta = static_cast<size_t>(f) * W.Rmax * 64u + static_cast<size_t>(g) * 64u;
+    return I;
+}
 
-    const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, P->len);
-    uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0;
-    if (tid < n16)
-        v0 = ld_b128(rs, base16 + tid * 16u);
-    if (tid + 256u < n16)
-        v1 = ld_b128(rs, base16 + (tid + 256u) * 16u);
-    if (tid + 512u < n16)
-        v2 = ld_b128(rs, base16 + (tid + 512u) * 16u);
-
-    if (tid < 72u)
-        s_tab[tid] = reinterpret_cast<const uint4 *>(c_tab7)[tid];
-
-    if (tid < 64u) { // wave 0: per-block class, reference and offset inside the span
-        const uint32_t blk = g * 64u + tid;
-        const bool used = blk < nblk;
-        const size_t mo = static_cast<size_t>(f) * W.Rmax * 64u + blk;
-        const uint32_t b = used ? W.bits[mo] : 0u;
-        const uint32_t r = used ? W.refs[mo] : 0u;
-        uint32_t total;
-        const uint32_t ex = wave_excl_scan(len7_of(b), tid, &total);
-        s_blk[tid] = (head + ex) | (cls7_of(b) << 16);
-        s_ref[tid] = static_cast<uint16_t>(r);
+__device__ __forceinline__ ItemV item_loads(const Work7 &W, const ItemS &I, uint32_t tid)
+{
+    ItemV V;
+    V.v0 = V.v1 = V.v2 = make_uint4(0, 0, 0, 0);
+    V.b = V.r = 0;
+    const __amdgpu_buffer_rsrc_t rs = frame_rsrc(I.in, I.len);
+    if (tid < I.n16)
+        V.v0 = ld_b128(rs, I.base16 + tid * 16u);
+    if (tid + 256u < I.n16)
+        V.v1 = ld_b128(rs, I.base16 + (tid + 256u) * 16u);
+    if (tid + 512u < I.n16)
+        V.v2 = ld_b128(rs, I.base16 + (tid + 512u) * 16u);
+    if (tid < 64u && I.valid && I.g * 64u + tid < I.nblk) {
+        V.b = W.bits[I.meta + tid];
+        V.r = W.refs[I.meta + tid];
     }
+    return V;
+}
 
+// Stage one item in LDS: payload chunks, and (wave 0) per-block offset | class and reference.
+__device__ __forceinline__ void item_stage(const ItemS &I, const ItemV &V, uint32_t tid, uint8_t *s_pay,
+                                           uint32_t *s_blk, uint16_t *s_ref)
+{
     uint4 *pay4 = reinterpret_cast<uint4 *>(s_pay);
-    if (tid < n16)
-        pay4[tid] = v0;
-    if (tid + 256u < n16)
-        pay4[tid + 256u] = v1;
-    if (tid + 512u < n16)
-        pay4[tid + 512u] = v2;
-    __syncthreads();
+    if (tid < I.n16)
+        pay4[tid] = V.v0;
+    if (tid + 256u < I.n16)
+        pay4[tid + 256u] = V.v1;
+    if (tid + 512u < I.n16)
+        pay4[tid + 512u] = V.v2;
+    if (tid < 64u) {
+        uint32_t total;
+        const uint32_t ex = wave_excl_scan(len7_of(V.b), tid, &total);
+        s_blk[tid] = (I.head + ex) | (cls7_of(V.b) << 16);
+        s_ref[tid] = static_cast<uint16_t>(V.r);
+    }
+}
 
+// Store 8 consecutive pixels (16 B) of row y starting at column x, cropped to `width`
+// (RawData.cpp:598-608 copies `width` pixels of the coded row).
+__device__ __forceinline__ void store_px8(const ItemS &I, uint32_t y, uint32_t x, const uint32_t p[4])
+{
+    const uint32_t width = static_cast<uint32_t>(I.width);
+    if (y >= static_cast<uint32_t>(I.rows) || x >= width)
+        return;
+    uint16_t *dst = I.out + static_cast<size_t>(y) * static_cast<size_t>(width) + x;
+    if (I.fast && x + 8u <= width) {
+        *reinterpret_cast<uint4 *>(dst) = make_uint4(p[0], p[1], p[2], p[3]);
+    } else { // cropped or unaligned row: element stores
+        const uint32_t n = min(8u, width - x);
+#pragma unroll
+        for (uint32_t i = 0; i < 8u; i++)
+            if (i < n)
+                dst[i] = static_cast<uint16_t>(p[i >> 1] >> (16u * (i & 1u)));
+    }
+}
+
+// Decode the staged item: every lane owns 8 samples (8k..8k+7) of two sibling blocks
+// (2r, 2r+1) of one tile, i.e. 16 consecutive pixels of row 4ty + r + 2(k>>2).
+// Before storing, lanes k and k^4 trade one 16-byte half so that each lane ends up
+// with the SAME 16-byte column chunk of rows r and r+2: the 8 lanes of a (tile, r)
+// then write one full 128-byte line per store instruction instead of two half-filled
+// ones (partial-line writes were the bottleneck of the first version).
+//
+// ABL (diagnostic builds only, MCRAW_ABLATE): 0 = product; 1 = no global stores;
+// 2 = no unpack arithmetic; 3 (caller) = no payload loads.
+template <int ABL = 0>
+__device__ __forceinline__ void item_decode(const ItemS &I, uint32_t tid, const uint8_t *s_pay, const uint32_t *s_blk,
+                                            const uint16_t *s_ref, const uint4 *s_tab)
+{
     const uint32_t tt = tid >> 4, r = (tid >> 3) & 1u, k = tid & 7u;
-    const uint32_t tile = g * GROUP_TILES + tt;
-    if (tile * 4u >= nblk)
+    const uint32_t tile = I.g * GROUP_TILES + tt;
+    if (!I.valid || tile * 4u >= I.nblk) // uniform over the 16 lanes of a tile
         return;
-    const uint32_t tilesX = P->tilesX;
-    const uint32_t ty = tile / tilesX, tx = tile - ty * tilesX;
-    const uint32_t y = 4u * ty + r + 2u * (k >> 2);
-    const uint32_t x = 64u * tx + 16u * (k & 3u);
-    const int32_t width = P->width;
-    if (y >= static_cast<uint32_t>(P->rows) || x >= static_cast<uint32_t>(width))
-        return;
+    const uint32_t ty = tile / I.tilesX, tx = tile - ty * I.tilesX;
 
     const uint32_t bi = 4u * tt + 2u * r;
     const uint2 mb = *reinterpret_cast<const uint2 *>(&s_blk[bi]);
     const uint32_t refs2 = *reinterpret_cast<const uint32_t *>(&s_ref[bi]); // refA | refB << 16
-    const Unpacked A = unpack8(s_pay + (mb.x & 0xffffu), mb.x >> 16, k, s_tab);
-    const Unpacked B = unpack8(s_pay + (mb.y & 0xffffu), mb.y >> 16, k, s_tab);
+    Unpacked A, B;
+    if (ABL == 2) {
+        A.x[0] = A.x[1] = A.x[2] = A.x[3] = mb.x;
+        B.x[0] = B.x[1] = B.x[2] = B.x[3] = mb.y;
+    } else {
+        A = unpack8(s_pay + (mb.x & 0xffffu), mb.x >> 16, k, s_tab);
+        B = unpack8(s_pay + (mb.y & 0xffffu), mb.y >> 16, k, s_tab);
+    }
 
     // Bayer interleave (RawData.cpp:582-592): pixel 2i from block 2r, 2i+1 from 2r+1;
     // add both references with uint16 wrap-around in one packed add.
@@ -394,19 +453,107 @@ __global__ __launch_bounds__(256) void k7_tiles(const Work7 W)
         o[2 * m] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, e) + rr);
         o[2 * m + 1] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, d) + rr);
     }
-
-    uint16_t *dst = P->out + static_cast<size_t>(y) * static_cast<size_t>(width) + x;
-    if (P->fast_store && x + 16u <= static_cast<uint32_t>(width)) {
-        uint4 *d4 = reinterpret_cast<uint4 *>(dst);
-        d4[0] = make_uint4(o[0], o[1], o[2], o[3]);
-        d4[1] = make_uint4(o[4], o[5], o[6], o[7]);
-    } else { // cropped or unaligned row: element stores (RawData.cpp:598-608 copies `width` only)
-        const uint32_t n = min(16u, static_cast<uint32_t>(width) - x);
+    if (ABL == 1) { // keep the values alive without storing them
 #pragma unroll
-        for (uint32_t i = 0; i < 16u; i++)
-            if (i < n)
-                dst[i] = static_cast<uint16_t>(o[i >> 1] >> (16u * (i & 1u)));
+        for (int m = 0; m < 8; m++)
+            asm volatile("" ::"v"(o[m]));
+        return;
     }
+
+    // lane k < 4 holds chunks (2c, 2c+1) of row r, lane k+4 the same chunks of row r+2
+    // (c = k & 3).  Swap "my second chunk" against "partner's first chunk".
+    const bool lo = k < 4u;
+    uint32_t p0[4], p1[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t send = lo ? o[4 + i] : o[i];
+        // ds_swizzle bit-mask mode: lane' = ((lane & 0x1f) | 0) ^ 4  -> lane ^ 4, no LDS memory touched
+        const uint32_t recv = static_cast<uint32_t>(__builtin_amdgcn_ds_swizzle(static_cast<int>(send), 0x101F));
+        p0[i] = lo ? o[i] : recv;
+        p1[i] = lo ? recv : o[4 + i];
+    }
+    const uint32_t x = 64u * tx + 8u * (2u * (k & 3u) + (k >> 2));
+    const uint32_t y = 4u * ty + r;
+    store_px8(I, y, x, p0);
+    store_px8(I, y + 2u, x, p1);
+}
+
+// One workgroup per item (no pipelining): kept as the A/B baseline (MCRAW_TILES=1).
+__global__ __launch_bounds__(256) void k7_tiles_flat(const Work7 W)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_pay[PAY_LDS];
+    __shared__ uint4 s_tab[72];
+    __shared__ uint32_t s_blk[GROUP_BLOCKS]; // byte offset in span | class << 16
+    __shared__ uint16_t s_ref[GROUP_BLOCKS];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
+    const ItemS I = item_scalars(W, item);
+    if (!I.valid)
+        return;
+    const ItemV V = item_loads(W, I, tid);
+    if (tid < 72u)
+        s_tab[tid] = reinterpret_cast<const uint4 *>(c_tab7)[tid];
+    item_stage(I, V, tid, s_pay, s_blk, s_ref);
+    __syncthreads();
+    item_decode(I, tid, s_pay, s_blk, s_ref, s_tab);
+}
+
+// One WAVE per item, four independent waves per workgroup, no barrier on the data
+// path: lane = block for the metadata (bits -> LEN -> wave scan gives every block's
+// offset), the wave stages its own span in its own LDS slice, then decodes its 16
+// tiles in four rounds of 64 lanes.  The only workgroup-wide event is the barrier
+// that publishes the shared term table.
+template <int ABL>
+__global__ __launch_bounds__(256) void k7_tiles(const Work7 W, uint32_t total)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_pay[4][PAY_LDS];
+    __shared__ uint4 s_tab[72];
+    __shared__ uint32_t s_blk[4][GROUP_BLOCKS];
+    __shared__ uint16_t s_ref[4][GROUP_BLOCKS];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t item = xcd_remap(blockIdx.x, gridDim.x) * 4u + wave;
+    if (tid < 72u)
+        s_tab[tid] = reinterpret_cast<const uint4 *>(c_tab7)[tid];
+
+    ItemS I;
+    I.valid = 0;
+    I.n16 = 0;
+    if (item < total)
+        I = item_scalars(W, item);
+
+    // span -> registers: up to 9 chunks of 16 B per lane (8 KiB + alignment head)
+    const __amdgpu_buffer_rsrc_t rs = frame_rsrc(I.in, I.len);
+    uint4 v[9];
+#pragma unroll
+    for (uint32_t c = 0; c < 9u; c++) {
+        v[c] = make_uint4(0, 0, 0, 0);
+        if (ABL != 3 && lane + 64u * c < I.n16)
+            v[c] = ld_b128(rs, I.base16 + (lane + 64u * c) * 16u);
+    }
+    uint32_t b = 0, r = 0;
+    if (I.valid && I.g * 64u + lane < I.nblk) {
+        b = W.bits[I.meta + lane];
+        r = W.refs[I.meta + lane];
+    }
+
+    uint32_t tot;
+    const uint32_t ex = wave_excl_scan(len7_of(b), lane, &tot);
+    s_blk[wave][lane] = (I.head + ex) | (cls7_of(b) << 16);
+    s_ref[wave][lane] = static_cast<uint16_t>(r);
+    uint4 *pay4 = reinterpret_cast<uint4 *>(s_pay[wave]);
+#pragma unroll
+    for (uint32_t c = 0; c < 9u; c++)
+        if (lane + 64u * c < I.n16)
+            pay4[lane + 64u * c] = v[c];
+    __syncthreads();
+
+#pragma unroll
+    for (uint32_t q = 0; q < 4u; q++)
+        item_decode<ABL>(I, q * 64u + lane, s_pay[wave], s_blk[wave], s_ref[wave], s_tab);
 }
 
 // ------------------------------------------------------------------ launchers
@@ -424,9 +571,29 @@ void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st)
     case MCRAW_K7_SCAN:
         hipLaunchKernelGGL(k7_scan, dim3(n7), dim3(256), 0, st, W);
         break;
-    case MCRAW_K7_TILES:
-        hipLaunchKernelGGL(k7_tiles, dim3(W.Rmax, n7), dim3(256), 0, st, W);
+    case MCRAW_K7_TILES: {
+        const uint32_t total = W.Rmax * n7;
+        static const int mode = []() {
+            const char *e = std::getenv("MCRAW_TILES");
+            return e ? std::atoi(e) : 0;
+        }();
+        static const int abl = []() {
+            const char *e = std::getenv("MCRAW_ABLATE");
+            return e ? std::atoi(e) : 0;
+        }();
+        const dim3 grid((total + 3) / 4);
+        if (mode == 1)
+            hipLaunchKernelGGL(k7_tiles_flat, dim3(total), dim3(256), 0, st, W);
+        else if (abl == 1)
+            hipLaunchKernelGGL(k7_tiles<1>, grid, dim3(256), 0, st, W, total);
+        else if (abl == 2)
+            hipLaunchKernelGGL(k7_tiles<2>, grid, dim3(256), 0, st, W, total);
+        else if (abl == 3)
+            hipLaunchKernelGGL(k7_tiles<3>, grid, dim3(256), 0, st, W, total);
+        else
+            hipLaunchKernelGGL(k7_tiles<0>, grid, dim3(256), 0, st, W, total);
         break;
+    }
     }
 }
 
