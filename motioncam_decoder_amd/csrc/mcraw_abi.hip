@@ -266,7 +266,13 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     size_t Rmax = 0;
     for (const Plan7 &p : B.p7)
         Rmax = std::max<size_t>(Rmax, p.ngroups);
-    const size_t w_rec = carve(off, sizeof(uint32_t) * 2 * Rmax * n7);
+    // a stream of R records is at most R * 130 bytes long; never more chunks than the frame has bytes
+    size_t nch = 1;
+    for (const Plan7 &p : B.p7)
+        nch = std::max(nch, std::min<size_t>((static_cast<size_t>(p.ngroups) * 130 + CH7 - 1) / CH7 + 1,
+                                             (static_cast<size_t>(p.len) + CH7 - 1) / CH7));
+    const size_t w_cmap7 = carve(off, sizeof(uint32_t) * PH7 * nch * 2 * n7);
+    const size_t w_centry7 = carve(off, sizeof(uint32_t) * nch * 2 * n7);
     const size_t w_bits = carve(off, Rmax * 64 * n7);
     const size_t w_refs = carve(off, Rmax * 64 * sizeof(uint16_t) * n7);
     const size_t w_grp = carve(off, sizeof(uint32_t) * (Rmax + 1) * n7);
@@ -325,7 +331,9 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         Work7 W{};
         W.plans = reinterpret_cast<const Plan7 *>(dev + L.plans7);
         W.status = reinterpret_cast<int32_t *>(dev + L.status);
-        W.rec_off = reinterpret_cast<uint32_t *>(dev + w_rec);
+        W.cmap = reinterpret_cast<uint32_t *>(dev + w_cmap7);
+        W.centry = reinterpret_cast<uint32_t *>(dev + w_centry7);
+        W.nch = static_cast<uint32_t>(nch);
         W.bits = dev + w_bits;
         W.refs = reinterpret_cast<uint16_t *>(dev + w_refs);
         W.grp_off = reinterpret_cast<uint32_t *>(dev + w_grp);

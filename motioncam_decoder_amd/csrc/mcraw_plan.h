@@ -13,6 +13,8 @@ constexpr int32_t E_GEOMETRY = 0x1000;
 constexpr int GROUP_BLOCKS = 64;   // blocks per side-stream record = per decode group
 constexpr int GROUP_TILES = 16;    // 64x4 tiles per group
 constexpr int SPAN_MAX = 64 * 128; // largest payload span of one group (all raw-16)
+constexpr int CH7 = 1024;          // bytes of side stream per transition-map chunk
+constexpr int PH7 = 65;            // entry offsets 0,2,..,128 (record stride 2 + LEN <= 130, all even)
 
 // Per-frame plan of the current ("type 7") encoding; lives in HBM for the
 // duration of one batch.
@@ -36,11 +38,13 @@ struct Plan7 {
 struct Work7 {
     const Plan7 *plans;  // [n7]
     int32_t *status;     // [n7] status word of every type-7 frame
-    uint32_t *rec_off;   // [n7][2][Rmax]  byte offset of every side-stream record header
+    uint32_t *cmap;      // [n7][2][nch][PH7] transition map of every side-stream chunk (exit phase | count << 8)
+    uint32_t *centry;    // [n7][2][nch]      resolved entry of every chunk (phase | first record << 8)
     uint8_t *bits;       // [n7][Rmax*64]  decoded `bits` stream  (:557)
     uint16_t *refs;      // [n7][Rmax*64]  decoded `refs` stream  (:560)
     uint32_t *grp_off;   // [n7][Rmax+1]   payload byte offset of every 64-block group (:562 + prefix of LEN)
     uint32_t Rmax;       // largest ngroups in the batch
+    uint32_t nch;        // side-stream chunks planned per stream (covers Rmax records of 130 bytes)
     int32_t n7;
 };
 

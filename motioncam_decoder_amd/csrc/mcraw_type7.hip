@@ -1,8 +1,8 @@
 // mcraw_type7.hip -- gfx950 kernels for the current MCRAW frame encoding
 // (compressionType 7).  Replaces motioncam::raw::Decode, lib/RawData.cpp:528-612.
 //
-//   k7_walk   side-stream chain resolve   (RawData.cpp:463-498, the inline-header chain)
-//   k7_meta   side-stream record decode   (RawData.cpp:485-495) -> bits[], refs[], group lengths
+//   k7_maps + k7_follow   side-stream chain resolve (RawData.cpp:463-498, the inline-header chain)
+//   k7_records            side-stream record decode (RawData.cpp:485-495) -> bits[], refs[], group lengths
 //   k7_scan   payload offsets             (RawData.cpp:562, 576-579: offset += LEN[bits])
 //   k7_tiles  tile unpack + reference add + Bayer interleave + crop
 //             (RawData.cpp:410-461, 112-408, 581-593, 598-608)   <- the roofline kernel
@@ -64,24 +64,147 @@ __device__ __forceinline__ uint32_t term_shr(uint32_t t) { return (t >> 8) & 31u
 __device__ __forceinline__ uint32_t term_bits(uint32_t t) { return (t >> 16) & 31u; }
 __device__ __forceinline__ uint32_t term_shl(uint32_t t) { return (t >> 24) & 31u; }
 
-// ------------------------------------------------------------------ k7_walk
+// ------------------------------------------------------------------ block unpack
 //
-// One wave per (frame, side stream).  The stream is a chain of records
-// {hbits<<4 | ref>>8, ref & 255, LEN[hbits] payload bytes}: where record i+1
-// starts is only known from the header of record i (RawData.cpp:485-495).  The
-// wave pulls the stream through LDS in 4 KiB pieces (next piece in flight while
-// the current one is walked) and chases the headers with scalar code.
-constexpr int PIECE = 4096;
+// The reference's UInt16x8 vector (RawData.cpp:47-104): 8 samples 8k..8k+7 of one
+// 64-sample block as four dwords of packed u16 pairs.
+struct Unpacked { uint32_t x[4]; }; // samples (0,1)(2,3)(4,5)(6,7)
 
-__global__ __launch_bounds__(64) void k7_walk(const Work7 W)
+// 8 bytes of LDS at byte offset `off` of the array `base`.  Payload blocks are 8-byte
+// aligned (ALIGNED8); side-stream records only 2-byte aligned: three aligned dwords
+// and a funnel shift then stand in for the unaligned 64-bit read.
+template <bool ALIGNED8>
+__device__ __forceinline__ uint2 lds_read8(const uint8_t *__restrict__ base, uint32_t off)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_piece[2][PIECE];
+    if (ALIGNED8)
+        return *reinterpret_cast<const uint2 *>(base + off);
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(base) + (off >> 2);
+    const uint32_t sh = (off & 2u) * 8u;
+    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+    return make_uint2(__builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2, w1, sh));
+}
 
-    const int f = blockIdx.x >> 1;
-    const int s = blockIdx.x & 1;
+template <bool ALIGNED8>
+__device__ __forceinline__ Unpacked unpack8(const uint8_t *__restrict__ base, uint32_t blk, uint32_t cidx, uint32_t k,
+                                            const uint4 *__restrict__ s_tab)
+{
+    Unpacked u;
+    if (cidx >= 9u) { // raw 16: samples 8k..8k+7 are 16 bytes, already little-endian u16
+        const uint2 a = lds_read8<ALIGNED8>(base, blk + 16u * k);
+        const uint2 b = lds_read8<ALIGNED8>(base, blk + 16u * k + 8u);
+        u.x[0] = a.x; u.x[1] = a.y; u.x[2] = b.x; u.x[3] = b.y;
+        return u;
+    }
+    const uint4 row = s_tab[cidx * 8u + k];
+    uint32_t lo = 0, hi = 0; // byte-domain accumulators: samples j=0..3 and j=4..7
+    const uint32_t tms[3] = {row.x, row.y, row.z};
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        const uint32_t tm = tms[t];
+        const uint2 p = lds_read8<ALIGNED8>(base, blk + term_off(tm));
+        const uint32_t m = ((1u << term_bits(tm)) - 1u) * 0x01010101u;
+        lo |= ((p.x >> term_shr(tm)) & m) << term_shl(tm);
+        hi |= ((p.y >> term_shr(tm)) & m) << term_shl(tm);
+    }
+    const uint32_t th = row.w; // Decode10's bits 8..9
+    const uint2 ph = lds_read8<ALIGNED8>(base, blk + term_off(th));
+    const uint32_t mh = ((1u << term_bits(th)) - 1u) * 0x01010101u;
+    const uint32_t lo8 = (ph.x >> term_shr(th)) & mh, hi8 = (ph.y >> term_shr(th)) & mh;
+    // bytes -> packed u16 pairs: {lo.b0 | lo8.b0 << 8, lo.b1 | lo8.b1 << 8} ...
+    u.x[0] = __builtin_amdgcn_perm(lo8, lo, 0x05010400u);
+    u.x[1] = __builtin_amdgcn_perm(lo8, lo, 0x07030602u);
+    u.x[2] = __builtin_amdgcn_perm(hi8, hi, 0x05010400u);
+    u.x[3] = __builtin_amdgcn_perm(hi8, hi, 0x07030602u);
+    return u;
+}
+
+// ------------------------------------------------------------------ side-stream chain
+//
+// A side stream is a chain of records {hbits<<4 | ref>>8, ref & 255, LEN[hbits] payload
+// bytes}: where record i+1 starts is only known from the header of record i
+// (RawData.cpp:485-495).  A lone wave chasing ~2000 headers per stream costs ~0.3 ms,
+// so the chain is resolved in parallel with TRANSITION MAPS: record strides are even and
+// at most 130 bytes, hence a fixed 2 KiB chunk of the stream can only be entered at 65
+// offsets ("phases" 0,2,..,128 past the chunk start).
+//
+//   k7_maps     per chunk, per phase: walk the headers to the chunk end
+//               -> (exit phase into the next chunk, records started)
+//   k7_follow   per stream: validate the frame header, then follow the true phase
+//               through the chunk maps -> (entry phase, first record index) per chunk
+//   k7_records  per chunk: list its records from the true entry, unpack each one
+//               (lane = entry) -> bits[], refs[], byte length of every 64-block group
+constexpr uint32_t DEAD7 = 127u; // phase value: the chain has ended (record past `len`, or all records found)
+
+// Byte offset of the first record of side stream s (0 = bits, 1 = refs): the stream
+// begins with a u32 entry count (RawData.cpp:470-477).
+__device__ __forceinline__ uint32_t stream_first(const uint4 &hdr, uint32_t s) { return (s ? hdr.w : hdr.z) + 4u; }
+
+constexpr uint32_t MAPS_CH = 3; // chunks per 256-thread workgroup: 3 x 65 phases = 195 lanes
+constexpr uint32_t NODEAD = 0xFFFFu;
+
+// Where the record whose header sits at staged offset `rel` ends (= where the next one
+// starts), or NODEAD when it would cross `len` (RawData.cpp:419-420 skips such a block).
+__device__ __forceinline__ uint32_t next_of(const uint8_t *s_b, uint32_t head, uint32_t rel, uint32_t abs, uint32_t len)
+{
+    const uint32_t nx = rel + 2u + len7_of(static_cast<uint32_t>(s_b[head + rel]) >> 4);
+    return abs + nx > len ? NODEAD : nx;
+}
+
+__global__ __launch_bounds__(256) void k7_maps(const Work7 W)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_b[MAPS_CH * CH7 + 32];
+    __shared__ uint16_t s_nxt[MAPS_CH * CH7 / 2];
+
+    const uint32_t c0 = blockIdx.x * MAPS_CH, fs = blockIdx.y, f = fs >> 1, s = fs & 1u;
+    const uint32_t tid = threadIdx.x;
+    const Plan7 *P = W.plans + f;
+    const uint32_t len = P->len;
+    const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
+    const uint4 hdr = ld_b128(rs, 0);
+    const uint32_t s0 = __builtin_amdgcn_readfirstlane(stream_first(hdr, s));
+    const uint32_t abs0 = s0 + c0 * CH7;
+    const uint32_t sub = tid / PH7, ph = tid - sub * PH7;
+    const uint32_t c = c0 + sub;
+    const bool mine = sub < MAPS_CH && c < W.nch;
+    uint32_t *map = W.cmap + (static_cast<size_t>(fs) * W.nch + c) * PH7;
+    if (abs0 >= len || abs0 < s0) { // nothing of the frame here: every entry is a dead end
+        if (mine)
+            map[ph] = DEAD7;
+        return;
+    }
+    const uint32_t base16 = abs0 & ~15u, head = abs0 - base16;
+    const uint32_t n16 = (head + MAPS_CH * CH7 + 15u) >> 4; // <= 193
+    if (tid < n16)
+        reinterpret_cast<uint4 *>(s_b)[tid] = ld_b128(rs, base16 + tid * 16u);
+    __syncthreads();
+    // every even offset is a candidate header: tabulate its successor once, so the 65 walks
+    // of a chunk are chains of 2-byte LDS reads
+    for (uint32_t i = tid; i < MAPS_CH * CH7 / 2; i += 256u)
+        s_nxt[i] = static_cast<uint16_t>(next_of(s_b, head, 2u * i, abs0, len));
+    __syncthreads();
+    if (!mine)
+        return;
+    const uint32_t hi = (sub + 1u) * CH7; // end of this chunk inside the staged bytes
+    uint32_t rel = sub * CH7 + 2u * ph, count = 0;
+    while (rel < hi) { // NODEAD ends the loop too
+        rel = s_nxt[rel >> 1];
+        count += rel != NODEAD ? 1u : 0u;
+    }
+    map[ph] = (rel == NODEAD ? DEAD7 : (rel - hi) >> 1) | (count << 8);
+}
+
+constexpr uint32_t FOLLOW_PIECE = 192; // chunk maps staged per pass (192 * 65 * 4 B = 49 KB)
+
+__global__ __launch_bounds__(256) void k7_follow(const Work7 W)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_map[FOLLOW_PIECE * PH7];
+    __shared__ uint32_t s_entry[FOLLOW_PIECE];
+    __shared__ uint32_t s_state[2];
+
+    const uint32_t fs = blockIdx.x, f = fs >> 1, s = fs & 1u;
     const Plan7 *P = W.plans + f;
     int32_t *status = W.status + f;
-    const uint32_t lane = threadIdx.x;
+    const uint32_t tid = threadIdx.x;
     const uint32_t len = P->len;
     const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
 
@@ -97,128 +220,183 @@ __global__ __launch_bounds__(64) void k7_walk(const Work7 W)
         err = E_GEOMETRY;
     else if (so + 4u > len || so + 4u < so)
         err = MCRAW_E_TRUNCATED;
-    uint32_t count = 0;
     if (!err) {
-        count = ld_u8(rs, so) | (ld_u8(rs, so + 1) << 8) | (ld_u8(rs, so + 2) << 16) | (ld_u8(rs, so + 3) << 24);
+        const uint32_t count = ld_u8(rs, so) | (ld_u8(rs, so + 1) << 8) | (ld_u8(rs, so + 2) << 16) | (ld_u8(rs, so + 3) << 24);
         if (count < P->nblk) // the reference would index past the vector (RawData.cpp:573-574)
             err = MCRAW_E_SIDESTREAM;
     }
-    if (err) {
-        if (lane == 0)
+    if (err) { // uniform over the workgroup
+        if (tid == 0)
             atomicOr(status, err);
         return;
     }
 
-    const uint32_t R = P->ngroups;
-    uint32_t *__restrict__ rec_off = W.rec_off + (static_cast<size_t>(f) * 2u + s) * W.Rmax;
-    uint32_t pos = __builtin_amdgcn_readfirstlane(so + 4u);
-    uint32_t pb = pos & ~15u;
-
-    uint4 r0 = ld_b128(rs, pb + lane * 16u);
-    uint4 r1 = ld_b128(rs, pb + 1024u + lane * 16u);
-    uint4 r2 = ld_b128(rs, pb + 2048u + lane * 16u);
-    uint4 r3 = ld_b128(rs, pb + 3072u + lane * 16u);
-    int buf = 0;
-    uint32_t i = 0, mine = 0;
-    bool bad = false;
-    while (i < R && !bad) {
-        uint4 *dst = reinterpret_cast<uint4 *>(s_piece[buf]);
-        dst[lane] = r0;
-        dst[64 + lane] = r1;
-        dst[128 + lane] = r2;
-        dst[192 + lane] = r3;
-        __syncthreads();
-        // next piece goes in flight now, lands while this one is walked
-        const uint32_t nb = pb + PIECE;
-        r0 = ld_b128(rs, nb + lane * 16u);
-        r1 = ld_b128(rs, nb + 1024u + lane * 16u);
-        r2 = ld_b128(rs, nb + 2048u + lane * 16u);
-        r3 = ld_b128(rs, nb + 3072u + lane * 16u);
-        const uint8_t *piece = s_piece[buf];
-        while (i < R && pos < nb) {
-            const uint32_t hb = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(piece[pos - pb])) >> 4;
-            const uint32_t next = pos + 2u + len7_of(hb);
-            if (next > len) { // RawData.cpp:419-420 would skip the block and leave stale data
-                bad = true;
-                break;
+    const uint32_t R = P->ngroups, nch = W.nch;
+    const uint32_t *maps = W.cmap + static_cast<size_t>(fs) * nch * PH7;
+    uint32_t *centry = W.centry + static_cast<size_t>(fs) * nch;
+    uint32_t p = 0, n = 0; // the first record sits right behind the entry count
+    for (uint32_t base = 0; base < nch; base += FOLLOW_PIECE) {
+        const uint32_t cnt = min(FOLLOW_PIECE, nch - base);
+        if (p != DEAD7) { // (uniform) nothing left to follow once the chain is complete
+            const uint32_t words = cnt * PH7;
+            const uint32_t *src = maps + static_cast<size_t>(base) * PH7; // 16-byte aligned: base * 65 * 4, base % 4 == 0
+            for (uint32_t i = tid * 4u; i < words; i += 1024u) {
+                if (i + 4u <= words) {
+                    *reinterpret_cast<uint4 *>(&s_map[i]) = *reinterpret_cast<const uint4 *>(&src[i]);
+                } else {
+                    for (uint32_t t = i; t < words; t++)
+                        s_map[t] = src[t];
+                }
             }
-            if (lane == (i & 63u))
-                mine = pos;
-            if ((i & 63u) == 63u)
-                rec_off[i - 63u + lane] = mine;
-            pos = next;
-            ++i;
         }
-        pb = nb;
-        buf ^= 1;
+        __syncthreads();
+        if (tid == 0) {
+            for (uint32_t c = 0; c < cnt; c++) {
+                if (n >= R)
+                    p = DEAD7; // all records found: later chunks have nothing to do
+                s_entry[c] = p | (n << 8);
+                if (p != DEAD7) {
+                    const uint32_t m = s_map[c * PH7 + p];
+                    n += m >> 8;
+                    p = m & 255u;
+                }
+            }
+            s_state[0] = p;
+            s_state[1] = n;
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < cnt; i += 256u)
+            centry[base + i] = s_entry[i];
+        p = s_state[0];
+        n = s_state[1];
+        __syncthreads();
     }
-    if (bad) {
-        if (lane == 0)
-            atomicOr(status, MCRAW_E_TRUNCATED);
-        return;
-    }
-    const uint32_t tail = i & 63u;
-    if (lane < tail)
-        rec_off[i - tail + lane] = mine;
+    if (tid == 0 && n < R) // the chain ended before R records: a record crosses `len`
+        atomicOr(status, MCRAW_E_TRUNCATED);
 }
 
-// ------------------------------------------------------------------ k7_meta
-//
-// One wave per side-stream record, lane = entry.  Same unpack as a payload block
-// (DecodeBlock on the record, RawData.cpp:489) plus the record's reference
-// (:491-492).  Bits records also emit the byte length of their 64-block group.
-__global__ __launch_bounds__(256) void k7_meta(const Work7 W)
+constexpr int REC_STAGE = CH7 + 130 + 8 + 16; // records starting in the chunk may run 130 bytes past it (+ read slack)
+constexpr int REC_BYTES = (REC_STAGE + 15) / 16 * 16 + 16;
+constexpr int REC_MAX = CH7 / 2;
+
+template <int PATTERN>
+__device__ __forceinline__ uint32_t swz_xor(uint32_t v)
 {
-    const uint32_t f = blockIdx.y;
-    const Plan7 *P = W.plans + f;
+    return static_cast<uint32_t>(__builtin_amdgcn_ds_swizzle(static_cast<int>(v), PATTERN));
+}
+
+// One wave per chunk.  The wave lists the records that start in its chunk (a chain of
+// 2-byte LDS reads through the successor table), parses their headers in parallel, then
+// unpacks EIGHT records per pass: lane = (record, k) owns samples 8k..8k+7 exactly like a
+// payload lane (DecodeBlock on the record, RawData.cpp:489; + reference, :491-492).
+__global__ __launch_bounds__(64) void k7_records(const Work7 W)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_b[REC_BYTES];
+    __shared__ uint16_t s_nxt[REC_MAX];
+    __shared__ uint16_t s_rec[REC_MAX];
+    __shared__ uint32_t s_hdr[REC_MAX + 8]; // per record: payload offset | hbits << 12 | reference << 16
+    __shared__ uint4 s_tab[72];
+
+    const uint32_t c = blockIdx.x, fs = blockIdx.y, f = fs >> 1, s = fs & 1u;
     int32_t *status = W.status + f;
     if (*status != 0)
         return;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t R = P->ngroups;
-    const uint32_t rec = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (rec >= 2u * R)
+    const uint32_t entry = __builtin_amdgcn_readfirstlane(W.centry[static_cast<size_t>(fs) * W.nch + c]);
+    const uint32_t ph = entry & 255u, i0 = entry >> 8;
+    const Plan7 *P = W.plans + f;
+    const uint32_t R = P->ngroups, nblk = P->nblk;
+    if (ph == DEAD7 || i0 >= R)
         return;
-    const uint32_t s = rec >= R ? 1u : 0u;
-    const uint32_t r = rec - s * R;
-    const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, P->len);
-    const uint32_t off = __builtin_amdgcn_readfirstlane(W.rec_off[(static_cast<size_t>(f) * 2u + s) * W.Rmax + r]);
-    const uint32_t b0 = ld_u8(rs, off), b1 = ld_u8(rs, off + 1u);
-    const uint32_t hb = b0 >> 4;                   // RawData.cpp:106-110
-    const uint32_t ref = ((b0 & 15u) << 8) | b1;
-    const uint32_t pay = off + 2u;
-    const uint32_t k = lane >> 3, j = lane & 7u;
-
-    uint32_t v = 0;
-    if (hb >= 11u) { // raw 16, little endian (RawData.cpp:376-408)
-        v = ld_u8(rs, pay + 2u * lane) | (ld_u8(rs, pay + 2u * lane + 1u) << 8);
-    } else if (hb != 0u) {
-        const uint32_t *row = c_tab7[cls7_of(hb) * 8u + k];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t len = P->len;
+    const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
+    const uint4 hdr = ld_b128(rs, 0);
+    const uint32_t abs = __builtin_amdgcn_readfirstlane(stream_first(hdr, s)) + c * CH7;
+    const uint32_t base16 = abs & ~15u, head = abs - base16;
 #pragma unroll
-        for (int t = 0; t < 3; t++) {
-            const uint32_t tm = row[t];
-            if (term_bits(tm) != 0u)
-                v |= ((ld_u8(rs, pay + term_off(tm) + j) >> term_shr(tm)) & ((1u << term_bits(tm)) - 1u)) << term_shl(tm);
-        }
-        const uint32_t th = row[3];
-        if (term_bits(th) != 0u)
-            v |= ((ld_u8(rs, pay + term_off(th) + j) >> term_shr(th)) & 3u) << 8;
-    }
-    v = (v + ref) & 0xffffu; // uint16 wrap (RawData.cpp:492)
+    for (uint32_t q = 0; q < (REC_BYTES / 16 + 63) / 64; q++)
+        if (lane + 64u * q < REC_BYTES / 16)
+            reinterpret_cast<uint4 *>(s_b)[lane + 64u * q] = ld_b128(rs, base16 + (lane + 64u * q) * 16u);
+    s_tab[lane] = reinterpret_cast<const uint4 *>(c_tab7)[lane];
+    if (lane < 8u)
+        s_tab[64u + lane] = reinterpret_cast<const uint4 *>(c_tab7)[64u + lane];
+    __syncthreads();
+    for (uint32_t i = lane; i < REC_MAX; i += 64u)
+        s_nxt[i] = static_cast<uint16_t>(next_of(s_b, head, 2u * i, abs, len));
+    __syncthreads();
 
-    const uint32_t idx = r * 64u + lane;
-    if (s == 0u) {
-        const bool used = idx < P->nblk;
-        if (used && v > 16u) { // would index past ENCODING_BLOCK_LENGTH (RawData.cpp:419)
-            atomicOr(status, MCRAW_E_SIDESTREAM);
-            v = 16u;
-        }
-        W.bits[static_cast<size_t>(f) * W.Rmax * 64u + idx] = static_cast<uint8_t>(v);
-        const uint32_t sum = wave_sum(used ? len7_of(v) : 0u);
+    // list the records that start in this chunk (every lane runs the same chain)
+    uint32_t rel = 2u * ph, n = 0;
+    while (rel < CH7 && i0 + n < R) {
+        const uint32_t nx = s_nxt[rel >> 1];
+        if (nx == NODEAD)
+            break; // k7_follow has failed the frame already
         if (lane == 0)
-            W.grp_off[static_cast<size_t>(f) * (W.Rmax + 1u) + r] = sum; // lengths until k7_scan
-    } else {
-        W.refs[static_cast<size_t>(f) * W.Rmax * 64u + idx] = static_cast<uint16_t>(v);
+            s_rec[n] = static_cast<uint16_t>(rel);
+        rel = nx;
+        n++;
+    }
+    __syncthreads();
+    // headers of all records in parallel (RawData.cpp:106-110)
+    for (uint32_t q = lane; q < n + 8u; q += 64u) {
+        uint32_t hv = 0;
+        if (q < n) {
+            const uint32_t ro = head + s_rec[q];
+            const uint32_t b0 = s_b[ro], b1 = s_b[ro + 1u];
+            hv = (ro + 2u) | ((b0 >> 4) << 12) | ((((b0 & 15u) << 8) | b1) << 16);
+        }
+        s_hdr[q] = hv; // 8 zero entries of padding: idle lanes of the last pass unpack "class 0"
+    }
+    __syncthreads();
+
+    const uint32_t k = lane & 7u, sub = lane >> 3;
+    uint8_t *bits = W.bits + static_cast<size_t>(f) * W.Rmax * 64u;
+    uint16_t *refs = W.refs + static_cast<size_t>(f) * W.Rmax * 64u;
+    uint32_t *glen = W.grp_off + static_cast<size_t>(f) * (W.Rmax + 1u);
+    for (uint32_t qb = 0; qb < n; qb += 8u) {
+        const uint32_t q = qb + sub;
+        const bool live = q < n;
+        const uint32_t h = s_hdr[q];
+        const uint32_t hb = (h >> 12) & 15u, ref = h >> 16;
+        Unpacked U = unpack8<false>(s_b, h & 0xfffu, cls7_of(hb), k, s_tab);
+        const u16x2 rr = __builtin_bit_cast(u16x2, ref | (ref << 16));
+#pragma unroll
+        for (int i = 0; i < 4; i++) // uint16 wrap (RawData.cpp:492)
+            U.x[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, U.x[i]) + rr);
+        const uint32_t r = i0 + q;
+        const uint32_t idx = r * 64u + 8u * k;
+        if (s == 1u) {
+            if (live)
+                *reinterpret_cast<uint4 *>(refs + idx) = make_uint4(U.x[0], U.x[1], U.x[2], U.x[3]);
+            continue;
+        }
+        // bits stream: validate, narrow to bytes, and add up the byte length of the group
+        uint32_t l8 = 0, bytes_lo = 0, bytes_hi = 0;
+        bool over = false;
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) {
+            uint32_t v = (U.x[j >> 1] >> (16u * (j & 1u))) & 0xffffu;
+            const bool used = live && idx + j < nblk;
+            if (used && v > 16u) { // would index past ENCODING_BLOCK_LENGTH (RawData.cpp:419)
+                over = true;
+                v = 16u;
+            }
+            l8 += used ? len7_of(v) >> 3 : 0u;
+            if (j < 4u)
+                bytes_lo |= (v & 0xffu) << (8u * j);
+            else
+                bytes_hi |= (v & 0xffu) << (8u * (j - 4u));
+        }
+        if (over)
+            atomicOr(status, MCRAW_E_SIDESTREAM);
+        if (live)
+            *reinterpret_cast<uint2 *>(bits + idx) = make_uint2(bytes_lo, bytes_hi);
+        // sum over the 8 lanes of the record (ds_swizzle bit-mask mode: lane ^ 1, ^ 2, ^ 4)
+        l8 += swz_xor<0x041F>(l8);
+        l8 += swz_xor<0x081F>(l8);
+        l8 += swz_xor<0x101F>(l8);
+        if (live && k == 0u)
+            glen[r] = l8 << 3; // lengths until k7_scan turns them into offsets
     }
 }
 
@@ -273,41 +451,6 @@ __global__ __launch_bounds__(256) void k7_scan(const Work7 W)
 //
 //   lane -> tile tt = tid>>4, row pair r = (tid>>3)&1, k = tid&7
 //   pixel row = 4*ty + r + 2*(k>>2), first column = 64*tx + 16*(k&3)   (RawData.cpp:581-593)
-struct Unpacked { uint32_t x[4]; }; // samples (0,1)(2,3)(4,5)(6,7) as packed u16 pairs
-
-__device__ __forceinline__ Unpacked unpack8(const uint8_t *__restrict__ blk, uint32_t cidx, uint32_t k,
-                                            const uint4 *__restrict__ s_tab)
-{
-    Unpacked u;
-    if (cidx >= 9u) { // raw 16: samples 8k..8k+7 are 16 bytes, already little-endian u16
-        const uint2 a = *reinterpret_cast<const uint2 *>(blk + 16u * k);
-        const uint2 b = *reinterpret_cast<const uint2 *>(blk + 16u * k + 8u);
-        u.x[0] = a.x; u.x[1] = a.y; u.x[2] = b.x; u.x[3] = b.y;
-        return u;
-    }
-    const uint4 row = s_tab[cidx * 8u + k];
-    uint32_t lo = 0, hi = 0; // byte-domain accumulators: samples j=0..3 and j=4..7
-    const uint32_t tms[3] = {row.x, row.y, row.z};
-#pragma unroll
-    for (int t = 0; t < 3; t++) {
-        const uint32_t tm = tms[t];
-        const uint2 p = *reinterpret_cast<const uint2 *>(blk + term_off(tm));
-        const uint32_t m = ((1u << term_bits(tm)) - 1u) * 0x01010101u;
-        lo |= ((p.x >> term_shr(tm)) & m) << term_shl(tm);
-        hi |= ((p.y >> term_shr(tm)) & m) << term_shl(tm);
-    }
-    const uint32_t th = row.w; // Decode10's bits 8..9
-    const uint2 ph = *reinterpret_cast<const uint2 *>(blk + term_off(th));
-    const uint32_t mh = ((1u << term_bits(th)) - 1u) * 0x01010101u;
-    const uint32_t lo8 = (ph.x >> term_shr(th)) & mh, hi8 = (ph.y >> term_shr(th)) & mh;
-    // bytes -> packed u16 pairs: {lo.b0 | lo8.b0 << 8, lo.b1 | lo8.b1 << 8} ...
-    u.x[0] = __builtin_amdgcn_perm(lo8, lo, 0x05010400u);
-    u.x[1] = __builtin_amdgcn_perm(lo8, lo, 0x07030602u);
-    u.x[2] = __builtin_amdgcn_perm(hi8, hi, 0x05010400u);
-    u.x[3] = __builtin_amdgcn_perm(hi8, hi, 0x07030602u);
-    return u;
-}
-
 constexpr int PAY_LDS = SPAN_MAX + 16 + 32; // span + 16-B alignment head + slack for zero-length tails
 
 // Wave-uniform description of one work item (frame f, group g).
@@ -438,8 +581,8 @@ __device__ __forceinline__ void item_decode(const ItemS &I, uint32_t tid, const 
         A.x[0] = A.x[1] = A.x[2] = A.x[3] = mb.x;
         B.x[0] = B.x[1] = B.x[2] = B.x[3] = mb.y;
     } else {
-        A = unpack8(s_pay + (mb.x & 0xffffu), mb.x >> 16, k, s_tab);
-        B = unpack8(s_pay + (mb.y & 0xffffu), mb.y >> 16, k, s_tab);
+        A = unpack8<true>(s_pay, mb.x & 0xffffu, mb.x >> 16, k, s_tab);
+        B = unpack8<true>(s_pay, mb.y & 0xffffu, mb.y >> 16, k, s_tab);
     }
 
     // Bayer interleave (RawData.cpp:582-592): pixel 2i from block 2r, 2i+1 from 2r+1;
@@ -563,10 +706,11 @@ void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st)
     const uint32_t n7 = static_cast<uint32_t>(W.n7);
     switch (stage) {
     case MCRAW_K7_WALK:
-        hipLaunchKernelGGL(k7_walk, dim3(2 * n7), dim3(64), 0, st, W);
+        hipLaunchKernelGGL(k7_maps, dim3((W.nch + MAPS_CH - 1) / MAPS_CH, 2 * n7), dim3(256), 0, st, W);
+        hipLaunchKernelGGL(k7_follow, dim3(2 * n7), dim3(256), 0, st, W);
         break;
     case MCRAW_K7_META:
-        hipLaunchKernelGGL(k7_meta, dim3((2 * W.Rmax + 3) / 4, n7), dim3(256), 0, st, W);
+        hipLaunchKernelGGL(k7_records, dim3(W.nch, 2 * n7), dim3(64), 0, st, W);
         break;
     case MCRAW_K7_SCAN:
         hipLaunchKernelGGL(k7_scan, dim3(n7), dim3(256), 0, st, W);
