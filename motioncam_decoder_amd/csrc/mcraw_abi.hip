@@ -275,7 +275,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     const size_t w_centry7 = carve(off, sizeof(uint32_t) * nch * 2 * n7);
     const size_t w_bits = carve(off, Rmax * 64 * n7);
     const size_t w_refs = carve(off, Rmax * 64 * sizeof(uint16_t) * n7);
-    const size_t w_grp = carve(off, sizeof(uint32_t) * (Rmax + 1) * n7);
+    const size_t w_grp = carve(off, sizeof(uint32_t) * (Rmax * ITEM_SPLIT + 1) * n7);
     std::vector<size_t> w_cmap(n6), w_smap(n6), w_centry(n6), w_sentry(n6);
     for (int k = 0; k < n6; k++) {
         const Plan6 &p = B.p6[k];

@@ -12,6 +12,13 @@ constexpr int32_t E_GEOMETRY = 0x1000;
 
 constexpr int GROUP_BLOCKS = 64;   // blocks per side-stream record = per decode group
 constexpr int GROUP_TILES = 16;    // 64x4 tiles per group
+// A decode ITEM is the unit one wave of k7_tiles handles: 1/ITEM_SPLIT of a group.  Halving the
+// item halves the LDS a wave needs for its payload span (4 KiB instead of 8) and so doubles the
+// waves a CU can keep in flight; the payload offset table has one entry per item.
+constexpr int ITEM_SPLIT = 2;
+constexpr int ITEM_BLOCKS = GROUP_BLOCKS / ITEM_SPLIT;
+constexpr int ITEM_TILES = GROUP_TILES / ITEM_SPLIT;
+constexpr int ITEM_SPAN = ITEM_BLOCKS * 128; // largest payload span of one item (all raw-16)
 constexpr int SPAN_MAX = 64 * 128; // largest payload span of one group (all raw-16)
 constexpr int CH7 = 1024;          // bytes of side stream per transition-map chunk
 constexpr int PH7 = 65;            // entry offsets 0,2,..,128 (record stride 2 + LEN <= 130, all even)
@@ -42,7 +49,7 @@ struct Work7 {
     uint32_t *centry;    // [n7][2][nch]      resolved entry of every chunk (phase | first record << 8)
     uint8_t *bits;       // [n7][Rmax*64]  decoded `bits` stream  (:557)
     uint16_t *refs;      // [n7][Rmax*64]  decoded `refs` stream  (:560)
-    uint32_t *grp_off;   // [n7][Rmax+1]   payload byte offset of every 64-block group (:562 + prefix of LEN)
+    uint32_t *grp_off;   // [n7][Rmax*ITEM_SPLIT+1] payload byte offset of every decode item (:562 + prefix of LEN)
     uint32_t Rmax;       // largest ngroups in the batch
     uint32_t nch;        // side-stream chunks planned per stream (covers Rmax records of 130 bytes)
     int32_t n7;

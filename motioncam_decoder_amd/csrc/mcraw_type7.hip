@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64) void k7_records(const Work7 W)
     const uint32_t k = lane & 7u, sub = lane >> 3;
     uint8_t *bits = W.bits + static_cast<size_t>(f) * W.Rmax * 64u;
     uint16_t *refs = W.refs + static_cast<size_t>(f) * W.Rmax * 64u;
-    uint32_t *glen = W.grp_off + static_cast<size_t>(f) * (W.Rmax + 1u);
+    uint32_t *glen = W.grp_off + static_cast<size_t>(f) * (W.Rmax * ITEM_SPLIT + 1u);
     for (uint32_t qb = 0; qb < n; qb += 8u) {
         const uint32_t q = qb + sub;
         const bool live = q < n;
@@ -391,12 +391,13 @@ __global__ __launch_bounds__(64) void k7_records(const Work7 W)
             atomicOr(status, MCRAW_E_SIDESTREAM);
         if (live)
             *reinterpret_cast<uint2 *>(bits + idx) = make_uint2(bytes_lo, bytes_hi);
-        // sum over the 8 lanes of the record (ds_swizzle bit-mask mode: lane ^ 1, ^ 2, ^ 4)
+        // sum over the lanes of one decode item (ds_swizzle bit-mask mode: lane ^ 1, ^ 2, ^ 4)
         l8 += swz_xor<0x041F>(l8);
         l8 += swz_xor<0x081F>(l8);
-        l8 += swz_xor<0x101F>(l8);
-        if (live && k == 0u)
-            glen[r] = l8 << 3; // lengths until k7_scan turns them into offsets
+        if (ITEM_SPLIT == 1)
+            l8 += swz_xor<0x101F>(l8);
+        if (live && (k & (8u / ITEM_SPLIT - 1u)) == 0u)
+            glen[r * ITEM_SPLIT + k / (8u / ITEM_SPLIT)] = l8 << 3; // lengths until k7_scan turns them into offsets
     }
 }
 
@@ -411,8 +412,8 @@ __global__ __launch_bounds__(256) void k7_scan(const Work7 W)
     int32_t *status = W.status + blockIdx.x;
     if (*status != 0)
         return;
-    const uint32_t R = P->ngroups, tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    uint32_t *__restrict__ g = W.grp_off + static_cast<size_t>(blockIdx.x) * (W.Rmax + 1u);
+    const uint32_t R = P->ngroups * ITEM_SPLIT, tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    uint32_t *__restrict__ g = W.grp_off + static_cast<size_t>(blockIdx.x) * (W.Rmax * ITEM_SPLIT + 1u);
     uint32_t carry = 16u;
     for (uint32_t base = 0; base < R; base += 256u) {
         const uint32_t i = base + tid;
@@ -451,7 +452,8 @@ __global__ __launch_bounds__(256) void k7_scan(const Work7 W)
 //
 //   lane -> tile tt = tid>>4, row pair r = (tid>>3)&1, k = tid&7
 //   pixel row = 4*ty + r + 2*(k>>2), first column = 64*tx + 16*(k&3)   (RawData.cpp:581-593)
-constexpr int PAY_LDS = SPAN_MAX + 16 + 32; // span + 16-B alignment head + slack for zero-length tails
+constexpr int PAY_LDS = ITEM_SPAN + 16 + 32; // span + 16-B alignment head + slack for zero-length tails
+constexpr uint32_t PAY_CHUNKS = ITEM_SPAN / 16 + 1; // 16-byte chunks of a staged span
 
 // Wave-uniform description of one work item (frame f, group g).
 struct ItemS {
@@ -466,77 +468,35 @@ struct ItemS {
     size_t meta;         // index of the group's first entry in W.bits / W.refs
 };
 
-// Per-lane loads in flight for one item.
-struct ItemV {
-    uint4 v0, v1, v2;    // 16-byte chunks tid, tid+256, tid+512 of the span
-    uint32_t b, r;       // wave 0: `bits` and `refs` entry of block tid
-};
-
 __device__ __forceinline__ ItemS item_scalars(const Work7 &W, uint32_t item)
 {
     ItemS I;
-    const uint32_t f = item / W.Rmax;
-    const uint32_t g = item - f * W.Rmax;
+    const uint32_t per = W.Rmax * ITEM_SPLIT; // items planned per frame
+    const uint32_t f = item / per;
+    const uint32_t g = item - f * per;
     const Plan7 *P = W.plans + f;
-    const uint32_t *grp = W.grp_off + static_cast<size_t>(f) * (W.Rmax + 1u) + g;
+    const uint32_t *grp = W.grp_off + static_cast<size_t>(f) * (per + 1u) + g;
     const uint32_t start = grp[0], end = grp[1];
-    I.valid = (g < P->ngroups && W.status[f] == 0) ? 1u : 0u;
+    I.valid = (g * ITEM_BLOCKS < P->nblk && W.status[f] == 0) ? 1u : 0u;
     I.g = g;
     I.nblk = P->nblk;
     I.tilesX = P->tilesX;
     I.base16 = start & ~15u;
     I.head = start - I.base16;
-    I.n16 = I.valid ? min((end - I.base16 + 15u) >> 4, 513u) : 0u; // never more than SPAN_MAX + head
+    I.n16 = I.valid ? min((end - I.base16 + 15u) >> 4, PAY_CHUNKS) : 0u; // never more than ITEM_SPAN + head
     I.width = P->width;
     I.rows = P->rows;
     I.fast = P->fast_store;
     I.in = P->in;
     I.len = P->len;
     I.out = P->out;
-    I.meta = static_cast<size_t>(f) * W.Rmax * 64u + static_cast<size_t>(g) * 64u;
+    I.meta = static_cast<size_t>(f) * W.Rmax * 64u + static_cast<size_t>(g) * ITEM_BLOCKS;
     return I;
-}
-
-__device__ __forceinline__ ItemV item_loads(const Work7 &W, const ItemS &I, uint32_t tid)
-{
-    ItemV V;
-    V.v0 = V.v1 = V.v2 = make_uint4(0, 0, 0, 0);
-    V.b = V.r = 0;
-    const __amdgpu_buffer_rsrc_t rs = frame_rsrc(I.in, I.len);
-    if (tid < I.n16)
-        V.v0 = ld_b128(rs, I.base16 + tid * 16u);
-    if (tid + 256u < I.n16)
-        V.v1 = ld_b128(rs, I.base16 + (tid + 256u) * 16u);
-    if (tid + 512u < I.n16)
-        V.v2 = ld_b128(rs, I.base16 + (tid + 512u) * 16u);
-    if (tid < 64u && I.valid && I.g * 64u + tid < I.nblk) {
-        V.b = W.bits[I.meta + tid];
-        V.r = W.refs[I.meta + tid];
-    }
-    return V;
-}
-
-// Stage one item in LDS: payload chunks, and (wave 0) per-block offset | class and reference.
-__device__ __forceinline__ void item_stage(const ItemS &I, const ItemV &V, uint32_t tid, uint8_t *s_pay,
-                                           uint32_t *s_blk, uint16_t *s_ref)
-{
-    uint4 *pay4 = reinterpret_cast<uint4 *>(s_pay);
-    if (tid < I.n16)
-        pay4[tid] = V.v0;
-    if (tid + 256u < I.n16)
-        pay4[tid + 256u] = V.v1;
-    if (tid + 512u < I.n16)
-        pay4[tid + 512u] = V.v2;
-    if (tid < 64u) {
-        uint32_t total;
-        const uint32_t ex = wave_excl_scan(len7_of(V.b), tid, &total);
-        s_blk[tid] = (I.head + ex) | (cls7_of(V.b) << 16);
-        s_ref[tid] = static_cast<uint16_t>(V.r);
-    }
 }
 
 // Store 8 consecutive pixels (16 B) of row y starting at column x, cropped to `width`
 // (RawData.cpp:598-608 copies `width` pixels of the coded row).
+template <bool NT = false>
 __device__ __forceinline__ void store_px8(const ItemS &I, uint32_t y, uint32_t x, const uint32_t p[4])
 {
     const uint32_t width = static_cast<uint32_t>(I.width);
@@ -544,7 +504,12 @@ __device__ __forceinline__ void store_px8(const ItemS &I, uint32_t y, uint32_t x
         return;
     uint16_t *dst = I.out + static_cast<size_t>(y) * static_cast<size_t>(width) + x;
     if (I.fast && x + 8u <= width) {
-        *reinterpret_cast<uint4 *>(dst) = make_uint4(p[0], p[1], p[2], p[3]);
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = {p[0], p[1], p[2], p[3]};
+        if (NT)
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst));
+        else
+            *reinterpret_cast<u32x4 *>(dst) = v;
     } else { // cropped or unaligned row: element stores
         const uint32_t n = min(8u, width - x);
 #pragma unroll
@@ -563,12 +528,11 @@ __device__ __forceinline__ void store_px8(const ItemS &I, uint32_t y, uint32_t x
 //
 // ABL (diagnostic builds only, MCRAW_ABLATE): 0 = product; 1 = no global stores;
 // 2 = no unpack arithmetic; 3 (caller) = no payload loads.
-template <int ABL = 0>
-__device__ __forceinline__ void item_decode(const ItemS &I, uint32_t tid, const uint8_t *s_pay, const uint32_t *s_blk,
-                                            const uint16_t *s_ref, const uint4 *s_tab)
+template <int ABL = 0, bool NT = false>
+__device__ __forceinline__ void item_decode(const ItemS &I, uint32_t tt, uint32_t r, uint32_t k, const uint8_t *s_pay,
+                                            const uint32_t *s_blk, const uint16_t *s_ref, const uint4 *s_tab)
 {
-    const uint32_t tt = tid >> 4, r = (tid >> 3) & 1u, k = tid & 7u;
-    const uint32_t tile = I.g * GROUP_TILES + tt;
+    const uint32_t tile = I.g * ITEM_TILES + tt;
     if (!I.valid || tile * 4u >= I.nblk) // uniform over the 16 lanes of a tile
         return;
     const uint32_t ty = tile / I.tilesX, tx = tile - ty * I.tilesX;
@@ -617,29 +581,8 @@ __device__ __forceinline__ void item_decode(const ItemS &I, uint32_t tid, const 
     }
     const uint32_t x = 64u * tx + 8u * (2u * (k & 3u) + (k >> 2));
     const uint32_t y = 4u * ty + r;
-    store_px8(I, y, x, p0);
-    store_px8(I, y + 2u, x, p1);
-}
-
-// One workgroup per item (no pipelining): kept as the A/B baseline (MCRAW_TILES=1).
-__global__ __launch_bounds__(256) void k7_tiles_flat(const Work7 W)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t s_pay[PAY_LDS];
-    __shared__ uint4 s_tab[72];
-    __shared__ uint32_t s_blk[GROUP_BLOCKS]; // byte offset in span | class << 16
-    __shared__ uint16_t s_ref[GROUP_BLOCKS];
-
-    const uint32_t tid = threadIdx.x;
-    const uint32_t item = xcd_remap(blockIdx.x, gridDim.x);
-    const ItemS I = item_scalars(W, item);
-    if (!I.valid)
-        return;
-    const ItemV V = item_loads(W, I, tid);
-    if (tid < 72u)
-        s_tab[tid] = reinterpret_cast<const uint4 *>(c_tab7)[tid];
-    item_stage(I, V, tid, s_pay, s_blk, s_ref);
-    __syncthreads();
-    item_decode(I, tid, s_pay, s_blk, s_ref, s_tab);
+    store_px8<NT>(I, y, x, p0);
+    store_px8<NT>(I, y + 2u, x, p1);
 }
 
 // One WAVE per item, four independent waves per workgroup, no barrier on the data
@@ -647,13 +590,13 @@ __global__ __launch_bounds__(256) void k7_tiles_flat(const Work7 W)
 // offset), the wave stages its own span in its own LDS slice, then decodes its 16
 // tiles in four rounds of 64 lanes.  The only workgroup-wide event is the barrier
 // that publishes the shared term table.
-template <int ABL>
+template <int ABL, bool NT>
 __global__ __launch_bounds__(256) void k7_tiles(const Work7 W, uint32_t total)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_pay[4][PAY_LDS];
     __shared__ uint4 s_tab[72];
-    __shared__ uint32_t s_blk[4][GROUP_BLOCKS];
-    __shared__ uint16_t s_ref[4][GROUP_BLOCKS];
+    __shared__ uint32_t s_blk[4][ITEM_BLOCKS];
+    __shared__ uint16_t s_ref[4][ITEM_BLOCKS];
 
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
@@ -668,35 +611,39 @@ __global__ __launch_bounds__(256) void k7_tiles(const Work7 W, uint32_t total)
     if (item < total)
         I = item_scalars(W, item);
 
-    // span -> registers: up to 9 chunks of 16 B per lane (8 KiB + alignment head)
+    // span -> registers: 16-byte chunks lane, lane+64, ... (ITEM_SPAN + alignment head)
+    constexpr uint32_t NV = (PAY_CHUNKS + 63u) / 64u;
     const __amdgpu_buffer_rsrc_t rs = frame_rsrc(I.in, I.len);
-    uint4 v[9];
+    uint4 v[NV];
 #pragma unroll
-    for (uint32_t c = 0; c < 9u; c++) {
+    for (uint32_t c = 0; c < NV; c++) {
         v[c] = make_uint4(0, 0, 0, 0);
         if (ABL != 3 && lane + 64u * c < I.n16)
             v[c] = ld_b128(rs, I.base16 + (lane + 64u * c) * 16u);
     }
     uint32_t b = 0, r = 0;
-    if (I.valid && I.g * 64u + lane < I.nblk) {
+    if (I.valid && lane < ITEM_BLOCKS && I.g * ITEM_BLOCKS + lane < I.nblk) {
         b = W.bits[I.meta + lane];
         r = W.refs[I.meta + lane];
     }
 
     uint32_t tot;
-    const uint32_t ex = wave_excl_scan(len7_of(b), lane, &tot);
-    s_blk[wave][lane] = (I.head + ex) | (cls7_of(b) << 16);
-    s_ref[wave][lane] = static_cast<uint16_t>(r);
+    const uint32_t ex = wave_excl_scan(lane < ITEM_BLOCKS ? len7_of(b) : 0u, lane, &tot);
+    if (lane < ITEM_BLOCKS) {
+        s_blk[wave][lane] = (I.head + ex) | (cls7_of(b) << 16);
+        s_ref[wave][lane] = static_cast<uint16_t>(r);
+    }
     uint4 *pay4 = reinterpret_cast<uint4 *>(s_pay[wave]);
 #pragma unroll
-    for (uint32_t c = 0; c < 9u; c++)
+    for (uint32_t c = 0; c < NV; c++)
         if (lane + 64u * c < I.n16)
             pay4[lane + 64u * c] = v[c];
     __syncthreads();
 
 #pragma unroll
-    for (uint32_t q = 0; q < 4u; q++)
-        item_decode<ABL>(I, q * 64u + lane, s_pay[wave], s_blk[wave], s_ref[wave], s_tab);
+    for (uint32_t q = 0; q < ITEM_TILES / 4u; q++)
+        item_decode<ABL, NT>(I, q * 4u + (lane >> 4), (lane >> 3) & 1u, lane & 7u, s_pay[wave], s_blk[wave], s_ref[wave],
+                             s_tab);
 }
 
 // ------------------------------------------------------------------ launchers
@@ -716,26 +663,22 @@ void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st)
         hipLaunchKernelGGL(k7_scan, dim3(n7), dim3(256), 0, st, W);
         break;
     case MCRAW_K7_TILES: {
-        const uint32_t total = W.Rmax * n7;
-        static const int mode = []() {
-            const char *e = std::getenv("MCRAW_TILES");
-            return e ? std::atoi(e) : 0;
-        }();
-        static const int abl = []() {
+        const uint32_t total = W.Rmax * ITEM_SPLIT * n7;
+        static const int abl = []() { // diagnostic builds of the same kernel (see item_decode)
             const char *e = std::getenv("MCRAW_ABLATE");
             return e ? std::atoi(e) : 0;
         }();
         const dim3 grid((total + 3) / 4);
-        if (mode == 1)
-            hipLaunchKernelGGL(k7_tiles_flat, dim3(total), dim3(256), 0, st, W);
-        else if (abl == 1)
-            hipLaunchKernelGGL(k7_tiles<1>, grid, dim3(256), 0, st, W, total);
+        if (abl == 1)
+            hipLaunchKernelGGL((k7_tiles<1, true>), grid, dim3(256), 0, st, W, total);
         else if (abl == 2)
-            hipLaunchKernelGGL(k7_tiles<2>, grid, dim3(256), 0, st, W, total);
+            hipLaunchKernelGGL((k7_tiles<2, true>), grid, dim3(256), 0, st, W, total);
         else if (abl == 3)
-            hipLaunchKernelGGL(k7_tiles<3>, grid, dim3(256), 0, st, W, total);
+            hipLaunchKernelGGL((k7_tiles<3, true>), grid, dim3(256), 0, st, W, total);
+        else if (abl == 4)
+            hipLaunchKernelGGL((k7_tiles<0, false>), grid, dim3(256), 0, st, W, total);
         else
-            hipLaunchKernelGGL(k7_tiles<0>, grid, dim3(256), 0, st, W, total);
+            hipLaunchKernelGGL((k7_tiles<0, true>), grid, dim3(256), 0, st, W, total);
         break;
     }
     }
