@@ -190,7 +190,7 @@ def traffic_from_profile(workload_key):
         with open(p) as f:
             t = json.load(f)
         e = t.get(workload_key)
-        return e.get("hbm_bytes_per_launch") if e else None
+        return e.get("hbm_bytes_per_launch") if e else None  # per k7_tiles launch, like `achieved`
     except Exception:
         return None
 
@@ -240,18 +240,20 @@ def main():
 
         def summarize(r):
             wl = r["wl"]
-            tile_ms, tile_n = r["kms"]["k7_tiles"]
-            per_launch_ms = tile_ms / max(tile_n, 1)
-            bytes_launch = wl.in_bytes + wl.out_bytes
-            ach = bytes_launch / (per_launch_ms * 1e-3) / 1e9 if per_launch_ms > 0 else 0.0
+            tile_ms, tile_n = r["kms"]["k7_tiles"]          # summed over the timed region
+            launches_per_step = max(tile_n, 1) / args.steps  # a batch may be unpacked in sub-batches
+            step_tiles_ms = tile_ms / args.steps
+            bytes_step = wl.in_bytes + wl.out_bytes
+            ach = bytes_step / (step_tiles_ms * 1e-3) / 1e9 if step_tiles_ms > 0 else 0.0
             return {
                 "mpix_s": world * wl.pixels * args.steps / r["elapsed"] / 1e6,
                 "ms_per_step": 1e3 * r["elapsed"] / args.steps,
-                "tiles_ms_per_launch": per_launch_ms,
+                "tiles_ms_per_launch": tile_ms / max(tile_n, 1),
+                "launches_per_step": launches_per_step,
                 "achieved_gbs": ach,
-                "bytes_per_launch": bytes_launch,
+                "bytes_per_launch": bytes_step / launches_per_step,
                 "bpp": wl.bpp,
-                "kernels_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in r["kms"].items()},
+                "kernels_ms_per_step": {k: v[0] / args.steps for k, v in r["kms"].items()},
             }
 
         s = summarize(r)
@@ -279,8 +281,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k7_tiles", "achieved": round(s["achieved_gbs"], 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(s["achieved_gbs"] / HBM_PEAK_GBS, 4),
                          "traffic": traffic_from_profile(key),
-                         "algorithmic_bytes_per_launch": s["bytes_per_launch"],
-                         "avg_launch_ms": round(s["tiles_ms_per_launch"], 4)},
+                         "algorithmic_bytes_per_launch": round(s["bytes_per_launch"]),
+                         "avg_launch_ms": round(s["tiles_ms_per_launch"], 4),
+                         "launches_per_step": s["launches_per_step"]},
             "kernels_ms_per_step": {k: round(v, 4) for k, v in s["kernels_ms_per_step"].items()},
         }
         for d in dists[1:]:

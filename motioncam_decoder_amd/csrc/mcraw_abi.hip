@@ -157,6 +157,7 @@ struct KTimer { // brackets one launch with events on the launch stream
 // Geometry the host plans a type-7 frame with unless the header says otherwise.
 struct Geom7 {
     uint32_t encW, encH;
+    uint32_t full_extent;
 };
 
 struct Batch {
@@ -176,6 +177,7 @@ inline size_t carve(size_t &off, size_t bytes)
 
 struct Layout { // byte offsets inside the slot arena / upload image
     size_t status = 0;                                   // int32[n]
+    size_t counters = 0;                                 // u32[4] work-list lengths, start at 0
     size_t plans7 = 0;                                   // Plan7[n7]
     size_t plans6 = 0, map_base = 0, super_base = 0, row_base = 0;
     size_t upload_bytes = 0;                             // tables end here, workspace follows
@@ -194,6 +196,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         uint16_t *out = dev_out ? dev_out[i] : f.out;
         if (!in || !out || f.width <= 0 || f.height <= 0 || f.len == 0 || f.len >= (1ull << 32) ||
             (f.type != MCRAW_TYPE_BLOCK && f.type != MCRAW_TYPE_LEGACY) ||
+            reinterpret_cast<uintptr_t>(in) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 2 != 0 ||
             static_cast<uint64_t>(f.width) * static_cast<uint64_t>(f.height) >= (1ull << 31)) {
             status[i] = MCRAW_E_ARGS;
             continue;
@@ -208,6 +211,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
             if (geom_override) {
                 p.encW = (*geom_override)[i].encW;
                 p.encH = (*geom_override)[i].encH;
+                p.full_extent = (*geom_override)[i].full_extent;
             } else {
                 p.encW = static_cast<uint32_t>(up(f.width, 64));
                 p.encH = static_cast<uint32_t>(up(f.height, 4));
@@ -254,6 +258,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     Layout L;
     size_t off = 0;
     L.status = carve(off, sizeof(int32_t) * (n7 + n6 + 1));
+    L.counters = carve(off, sizeof(uint32_t) * 4);
     L.plans7 = carve(off, sizeof(Plan7) * n7);
     L.plans6 = carve(off, sizeof(Plan6) * n6);
     L.map_base = carve(off, sizeof(uint32_t) * (n6 + 1));
@@ -273,6 +278,9 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
                                              (static_cast<size_t>(p.len) + CH7 - 1) / CH7));
     const size_t w_cmap7 = carve(off, sizeof(uint32_t) * PH7 * nch * 2 * n7);
     const size_t w_centry7 = carve(off, sizeof(uint32_t) * nch * 2 * n7);
+    const size_t w_sinfo = carve(off, sizeof(uint4) * 2 * n7);
+    const size_t w_lmaps = carve(off, sizeof(uint4) * 2 * n7 * ((nch + 2) / 3));
+    const size_t w_lrecs = carve(off, sizeof(uint4) * 2 * n7 * nch);
     const size_t w_bits = carve(off, Rmax * 64 * n7);
     const size_t w_refs = carve(off, Rmax * 64 * sizeof(uint16_t) * n7);
     const size_t w_grp = carve(off, sizeof(uint32_t) * (Rmax * ITEM_SPLIT + 1) * n7);
@@ -294,6 +302,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     uint8_t *img = static_cast<uint8_t *>(s.pinned.p);
 
     std::memset(img + L.status, 0, sizeof(int32_t) * (n7 + n6 + 1));
+    std::memset(img + L.counters, 0, sizeof(uint32_t) * 4);
     s.host_status = status;
     s.order = B.idx7;
     s.order.insert(s.order.end(), B.idx6.begin(), B.idx6.end());
@@ -334,6 +343,10 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         W.cmap = reinterpret_cast<uint32_t *>(dev + w_cmap7);
         W.centry = reinterpret_cast<uint32_t *>(dev + w_centry7);
         W.nch = static_cast<uint32_t>(nch);
+        W.sinfo = reinterpret_cast<uint4 *>(dev + w_sinfo);
+        W.list_maps = reinterpret_cast<uint4 *>(dev + w_lmaps);
+        W.list_recs = reinterpret_cast<uint4 *>(dev + w_lrecs);
+        W.counters = reinterpret_cast<uint32_t *>(dev + L.counters);
         W.bits = dev + w_bits;
         W.refs = reinterpret_cast<uint16_t *>(dev + w_refs);
         W.grp_off = reinterpret_cast<uint32_t *>(dev + w_grp);
@@ -436,7 +449,7 @@ int decode_device(mcraw_ctx *c, const mcraw_frame *frames, int n, hipStream_t st
     // real header and run them again with it
     std::vector<int> redo;
     for (int i = 0; i < n; i++)
-        if (status[i] == E_GEOMETRY)
+        if (status[i] == E_GEOMETRY || status[i] == E_LAYOUT)
             redo.push_back(i);
     if (!redo.empty()) {
         std::vector<mcraw_frame> rf(redo.size());
@@ -446,7 +459,7 @@ int decode_device(mcraw_ctx *c, const mcraw_frame *frames, int n, hipStream_t st
             uint32_t hdr[4] = {0, 0, 0, 0};
             HIP_TRY(hipMemcpyAsync(hdr, rf[k].in, 16, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            rg[k] = {hdr[0], hdr[1]};
+            rg[k] = {hdr[0], hdr[1], 1u};
         }
         Slot *s2 = nullptr;
         if (int rc = acquire_slot(c, &s2))
@@ -460,7 +473,7 @@ int decode_device(mcraw_ctx *c, const mcraw_frame *frames, int n, hipStream_t st
         if (int rc = fetch_status(c, *s2, off2, static_cast<int>(rf.size()), st, st2.data()))
             return rc;
         for (size_t k = 0; k < redo.size(); k++) {
-            status[redo[k]] = st2[k] == E_GEOMETRY ? MCRAW_E_HEADER : st2[k];
+            status[redo[k]] = (st2[k] & (E_GEOMETRY | E_LAYOUT)) ? MCRAW_E_HEADER : st2[k];
             encH[redo[k]] = rg[k].encH;
         }
     }
@@ -560,11 +573,11 @@ int decode_host(mcraw_ctx *c, const mcraw_frame *frames, int n, size_t *written,
     // geometry mismatches: the header is readable on the host here
     for (int i = 0; i < n; i++) {
         uint32_t encH = static_cast<uint32_t>(up(std::max(frames[i].height, 1), 4));
-        if (status[i] == E_GEOMETRY) {
+        if (status[i] == E_GEOMETRY || status[i] == E_LAYOUT) {
             const mcraw_frame &f = frames[i];
             uint32_t hdr[4];
             std::memcpy(hdr, f.in, 16);
-            std::vector<Geom7> g{{hdr[0], hdr[1]}};
+            std::vector<Geom7> g{{hdr[0], hdr[1], 1u}};
             Slot *sp = nullptr;
             if (int rc = acquire_slot(c, &sp))
                 return rc;
@@ -587,7 +600,7 @@ int decode_host(mcraw_ctx *c, const mcraw_frame *frames, int n, size_t *written,
             int32_t st2 = 0;
             if (int rc = fetch_status(c, s, so, 1, st, &st2))
                 return rc;
-            status[i] = st2 == E_GEOMETRY ? MCRAW_E_HEADER : st2;
+            status[i] = (st2 & (E_GEOMETRY | E_LAYOUT)) ? MCRAW_E_HEADER : st2;
             encH = hdr[1];
         }
         if (status_out)
@@ -738,7 +751,7 @@ int mcraw_ctx_synchronize(mcraw_ctx *c, int32_t *status, int nframes)
         if (int rc = fetch_status(c, s, c->last_status_off, n, c->stream, status))
             return rc;
         for (int i = 0; i < n; i++)
-            if (status[i] == E_GEOMETRY)
+            if (status[i] & (E_GEOMETRY | E_LAYOUT))
                 status[i] = MCRAW_E_HEADER; // asynchronous submits are not re-planned
     }
     return 0;

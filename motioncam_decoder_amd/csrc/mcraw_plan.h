@@ -1,6 +1,7 @@
 // mcraw_plan.h -- structures shared by the host side of the C ABI (mcraw_abi.hip)
 // and the gfx950 kernels (mcraw_type7.hip, mcraw_type6.hip).
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace mcraw {
@@ -9,6 +10,9 @@ namespace mcraw {
 // frame header differs from the one the host planned with (ceil64(width) x
 // ceil4(height)); the host re-plans that frame from the real header.
 constexpr int32_t E_GEOMETRY = 0x1000;
+// ... or: the bits side stream does not end before the refs side stream begins; the host
+// re-plans the frame without the extent hint (Plan7::full_extent).
+constexpr int32_t E_LAYOUT = 0x2000;
 
 constexpr int GROUP_BLOCKS = 64;   // blocks per side-stream record = per decode group
 constexpr int GROUP_TILES = 16;    // 64x4 tiles per group
@@ -36,6 +40,7 @@ struct Plan7 {
     uint32_t nblk;       // N = 4 * tilesX * encH/4  (payload blocks = side-stream entries used)
     uint32_t ngroups;    // R = ceil(N / 64)
     uint32_t fast_store; // 1: out 16-B aligned and width % 8 == 0
+    uint32_t full_extent; // 1: do not assume the bits stream ends where the refs stream starts
 };
 
 // Batch-wide view of the type-7 work, passed to the kernels BY VALUE (kernarg):
@@ -47,6 +52,10 @@ struct Work7 {
     int32_t *status;     // [n7] status word of every type-7 frame
     uint32_t *cmap;      // [n7][2][nch][PH7] transition map of every side-stream chunk (exit phase | count << 8)
     uint32_t *centry;    // [n7][2][nch]      resolved entry of every chunk (phase | first record << 8)
+    uint4 *sinfo;        // [n7][2]           per stream: first record offset, chunks to map, extent hinted, -
+    uint4 *list_maps;    // work list of k7_maps:    (stream, first of 3 chunks, its byte offset, chunks of the stream)
+    uint4 *list_recs;    // work list of k7_records: (stream, chunk, its byte offset, entry phase | first record << 8)
+    uint32_t *counters;  // [2] lengths of the two lists (zeroed by the table upload)
     uint8_t *bits;       // [n7][Rmax*64]  decoded `bits` stream  (:557)
     uint16_t *refs;      // [n7][Rmax*64]  decoded `refs` stream  (:560)
     uint32_t *grp_off;   // [n7][Rmax*ITEM_SPLIT+1] payload byte offset of every decode item (:562 + prefix of LEN)

@@ -127,17 +127,18 @@ __device__ __forceinline__ Unpacked unpack8(const uint8_t *__restrict__ base, ui
 // at most 130 bytes, hence a fixed 2 KiB chunk of the stream can only be entered at 65
 // offsets ("phases" 0,2,..,128 past the chunk start).
 //
+//   k7_hdr      per stream: validate the frame header (RawData.cpp:547-554), find where the
+//               stream starts and how many chunks it can span; build the work list of k7_maps
 //   k7_maps     per chunk, per phase: walk the headers to the chunk end
 //               -> (exit phase into the next chunk, records started)
-//   k7_follow   per stream: validate the frame header, then follow the true phase
-//               through the chunk maps -> (entry phase, first record index) per chunk
+//   k7_follow   per stream: follow the true phase through the chunk maps
+//               -> (entry phase, first record index) per chunk; work list of k7_records
 //   k7_records  per chunk: list its records from the true entry, unpack each one
-//               (lane = entry) -> bits[], refs[], byte length of every 64-block group
+//               -> bits[], refs[], byte length of every decode item
+//
+// k7_maps and k7_records are persistent grids looping over device-built work lists, so no
+// workgroup is spent on chunks that lie beyond a stream.
 constexpr uint32_t DEAD7 = 127u; // phase value: the chain has ended (record past `len`, or all records found)
-
-// Byte offset of the first record of side stream s (0 = bits, 1 = refs): the stream
-// begins with a u32 entry count (RawData.cpp:470-477).
-__device__ __forceinline__ uint32_t stream_first(const uint4 &hdr, uint32_t s) { return (s ? hdr.w : hdr.z) + 4u; }
 
 constexpr uint32_t MAPS_CH = 3; // chunks per 256-thread workgroup: 3 x 65 phases = 195 lanes
 constexpr uint32_t NODEAD = 0xFFFFu;
@@ -150,47 +151,132 @@ __device__ __forceinline__ uint32_t next_of(const uint8_t *s_b, uint32_t head, u
     return abs + nx > len ? NODEAD : nx;
 }
 
+// One thread per side stream (index fs = 2 * frame + s; s = 0 bits, 1 refs).
+__global__ __launch_bounds__(256) void k7_hdr(const Work7 W)
+{
+    __shared__ uint32_t s_w[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const uint32_t nstreams = 2u * static_cast<uint32_t>(W.n7);
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nstreams; base += 256u) {
+        const uint32_t fs = base + tid;
+        uint32_t nwg = 0;
+        if (fs < nstreams) {
+            const uint32_t f = fs >> 1, s = fs & 1u;
+            const Plan7 *P = W.plans + f;
+            const uint32_t len = P->len;
+            const uint8_t *in = P->in;
+            uint32_t h[4] = {0, 0, 0, 0};
+            if (len >= 16u) { // frame header: 4 x u32 LE (RawData.cpp:500-524)
+                const uint4 hv = *reinterpret_cast<const uint4 *>(in); // frame buffers are 16-byte aligned
+                h[0] = hv.x; h[1] = hv.y; h[2] = hv.z; h[3] = hv.w;
+            }
+            const uint32_t encW = h[0], encH = h[1], so = h[2 + s];
+            int32_t err = 0;
+            bool frame_ok = false;
+            if (len < 16u || h[2] > len || h[3] > len || (encW & 63u) != 0u ||
+                encW < static_cast<uint32_t>(P->width) || encW == 0u || encH == 0u || (encH & 3u) != 0u)
+                err = MCRAW_E_HEADER; // RawData.cpp:547-554 returns 0
+            else if (encW != P->encW || encH != P->encH)
+                err = E_GEOMETRY;
+            else {
+                frame_ok = true;
+                if (so + 4u > len || so + 4u < so)
+                    err = MCRAW_E_TRUNCATED;
+                else {
+                    const uint32_t count = static_cast<uint32_t>(in[so]) | (static_cast<uint32_t>(in[so + 1u]) << 8) |
+                                           (static_cast<uint32_t>(in[so + 2u]) << 16) |
+                                           (static_cast<uint32_t>(in[so + 3u]) << 24);
+                    if (count < P->nblk) // the reference would index past the vector (RawData.cpp:573-574)
+                        err = MCRAW_E_SIDESTREAM;
+                }
+            }
+            if (err)
+                atomicOr(W.status + f, err);
+            // Extent: the bits stream of a canonically laid out frame ends where the refs
+            // stream begins; k7_follow reports E_LAYOUT if its chain is still alive there and
+            // the host re-plans that frame with the hint off (Plan7::full_extent).
+            uint32_t s0 = so + 4u, nchunk = 0, hinted = 0;
+            if (frame_ok && !err) {
+                uint32_t end = len;
+                if (s == 0u && !P->full_extent && h[3] > h[2]) {
+                    end = h[3];
+                    hinted = 1u;
+                }
+                if (end > s0)
+                    nchunk = min(W.nch, (end - s0 + CH7 - 1u) / CH7);
+            }
+            nwg = (nchunk + MAPS_CH - 1u) / MAPS_CH;
+            W.sinfo[fs] = make_uint4(s0, nchunk, hinted, 0u);
+        }
+        // block-wide exclusive scan of nwg -> position of this stream's entries in the list
+        uint32_t wtot;
+        const uint32_t ex = wave_excl_scan(nwg, lane, &wtot);
+        if (lane == 63u)
+            s_w[w] = wtot;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; q++) {
+            before += q < w ? s_w[q] : 0u;
+            total += s_w[q];
+        }
+        uint4 *dst = W.list_maps + carry + before + ex;
+        if (nwg) { // everything k7_maps needs to start loading: stream, first chunk, its byte offset, chunk count
+            const uint4 si = W.sinfo[fs];
+            for (uint32_t i = 0; i < nwg; i++)
+                dst[i] = make_uint4(fs, i * MAPS_CH, si.x + i * MAPS_CH * CH7, si.y);
+        }
+        carry += total;
+        __syncthreads();
+    }
+    if (tid == 0)
+        W.counters[0] = carry;
+}
+
 __global__ __launch_bounds__(256) void k7_maps(const Work7 W)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_b[MAPS_CH * CH7 + 32];
     __shared__ uint16_t s_nxt[MAPS_CH * CH7 / 2];
 
-    const uint32_t c0 = blockIdx.x * MAPS_CH, fs = blockIdx.y, f = fs >> 1, s = fs & 1u;
     const uint32_t tid = threadIdx.x;
-    const Plan7 *P = W.plans + f;
-    const uint32_t len = P->len;
-    const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
-    const uint4 hdr = ld_b128(rs, 0);
-    const uint32_t s0 = __builtin_amdgcn_readfirstlane(stream_first(hdr, s));
-    const uint32_t abs0 = s0 + c0 * CH7;
     const uint32_t sub = tid / PH7, ph = tid - sub * PH7;
-    const uint32_t c = c0 + sub;
-    const bool mine = sub < MAPS_CH && c < W.nch;
-    uint32_t *map = W.cmap + (static_cast<size_t>(fs) * W.nch + c) * PH7;
-    if (abs0 >= len || abs0 < s0) { // nothing of the frame here: every entry is a dead end
-        if (mine)
-            map[ph] = DEAD7;
-        return;
+    const uint32_t nwork = W.counters[0];
+    uint4 nextw = make_uint4(0, 0, 0, 0);
+    if (blockIdx.x < nwork)
+        nextw = W.list_maps[blockIdx.x];
+    for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+        const uint4 e = nextw;
+        if (wi + gridDim.x < nwork) // descriptor of the next work item rides behind this one
+            nextw = W.list_maps[wi + gridDim.x];
+        const uint32_t fs = __builtin_amdgcn_readfirstlane(e.x), c0 = __builtin_amdgcn_readfirstlane(e.y);
+        const uint32_t abs0 = __builtin_amdgcn_readfirstlane(e.z), nchunk = __builtin_amdgcn_readfirstlane(e.w);
+        const Plan7 *P = W.plans + (fs >> 1);
+        const uint32_t len = P->len;
+        const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
+        const uint32_t base16 = abs0 & ~15u, head = abs0 - base16;
+        const uint32_t n16 = (head + MAPS_CH * CH7 + 15u) >> 4;
+        for (uint32_t q = tid; q < n16; q += 256u)
+            reinterpret_cast<uint4 *>(s_b)[q] = ld_b128(rs, base16 + q * 16u);
+        __syncthreads();
+        // every even offset is a candidate header: tabulate its successor once, so the 65
+        // walks of a chunk are chains of 2-byte LDS reads
+        for (uint32_t i = tid; i < MAPS_CH * CH7 / 2; i += 256u)
+            s_nxt[i] = static_cast<uint16_t>(next_of(s_b, head, 2u * i, abs0, len));
+        __syncthreads();
+        const uint32_t c = c0 + sub;
+        if (sub < MAPS_CH && c < nchunk) {
+            const uint32_t hi = (sub + 1u) * CH7; // end of this chunk inside the staged bytes
+            uint32_t rel = sub * CH7 + 2u * ph, count = 0;
+            while (rel < hi) { // NODEAD ends the loop too
+                rel = s_nxt[rel >> 1];
+                count += rel != NODEAD ? 1u : 0u;
+            }
+            W.cmap[(static_cast<size_t>(fs) * W.nch + c) * PH7 + ph] =
+                (rel == NODEAD ? DEAD7 : (rel - hi) >> 1) | (count << 8);
+        }
+        __syncthreads(); // the staging buffers are reused by the next work item
     }
-    const uint32_t base16 = abs0 & ~15u, head = abs0 - base16;
-    const uint32_t n16 = (head + MAPS_CH * CH7 + 15u) >> 4; // <= 193
-    if (tid < n16)
-        reinterpret_cast<uint4 *>(s_b)[tid] = ld_b128(rs, base16 + tid * 16u);
-    __syncthreads();
-    // every even offset is a candidate header: tabulate its successor once, so the 65 walks
-    // of a chunk are chains of 2-byte LDS reads
-    for (uint32_t i = tid; i < MAPS_CH * CH7 / 2; i += 256u)
-        s_nxt[i] = static_cast<uint16_t>(next_of(s_b, head, 2u * i, abs0, len));
-    __syncthreads();
-    if (!mine)
-        return;
-    const uint32_t hi = (sub + 1u) * CH7; // end of this chunk inside the staged bytes
-    uint32_t rel = sub * CH7 + 2u * ph, count = 0;
-    while (rel < hi) { // NODEAD ends the loop too
-        rel = s_nxt[rel >> 1];
-        count += rel != NODEAD ? 1u : 0u;
-    }
-    map[ph] = (rel == NODEAD ? DEAD7 : (rel - hi) >> 1) | (count << 8);
 }
 
 constexpr uint32_t FOLLOW_PIECE = 192; // chunk maps staged per pass (192 * 65 * 4 B = 49 KB)
@@ -199,80 +285,68 @@ __global__ __launch_bounds__(256) void k7_follow(const Work7 W)
 {
     __shared__ __attribute__((aligned(16))) uint32_t s_map[FOLLOW_PIECE * PH7];
     __shared__ uint32_t s_entry[FOLLOW_PIECE];
-    __shared__ uint32_t s_state[2];
+    __shared__ uint32_t s_state[4];
 
-    const uint32_t fs = blockIdx.x, f = fs >> 1, s = fs & 1u;
-    const Plan7 *P = W.plans + f;
+    const uint32_t fs = blockIdx.x, f = fs >> 1;
     int32_t *status = W.status + f;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t len = P->len;
-    const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
-
-    // frame header: 4 x u32 LE (RawData.cpp:500-524) and its checks (:547-554)
-    const uint4 h = ld_b128(rs, 0);
-    const uint32_t encW = h.x, encH = h.y;
-    const uint32_t so = s ? h.w : h.z; // refsOffset : bitsOffset
-    int32_t err = 0;
-    if (len < 16u || h.z > len || h.w > len || (encW & 63u) != 0u || encW < static_cast<uint32_t>(P->width) ||
-        encW == 0u || encH == 0u || (encH & 3u) != 0u)
-        err = MCRAW_E_HEADER;
-    else if (encW != P->encW || encH != P->encH)
-        err = E_GEOMETRY;
-    else if (so + 4u > len || so + 4u < so)
-        err = MCRAW_E_TRUNCATED;
-    if (!err) {
-        const uint32_t count = ld_u8(rs, so) | (ld_u8(rs, so + 1) << 8) | (ld_u8(rs, so + 2) << 16) | (ld_u8(rs, so + 3) << 24);
-        if (count < P->nblk) // the reference would index past the vector (RawData.cpp:573-574)
-            err = MCRAW_E_SIDESTREAM;
-    }
-    if (err) { // uniform over the workgroup
-        if (tid == 0)
-            atomicOr(status, err);
+    if (*status != 0)
         return;
-    }
-
+    const Plan7 *P = W.plans + f;
+    const uint32_t tid = threadIdx.x;
+    const uint4 si = W.sinfo[fs];
+    const uint32_t nchunk = si.y, hinted = si.z;
     const uint32_t R = P->ngroups, nch = W.nch;
     const uint32_t *maps = W.cmap + static_cast<size_t>(fs) * nch * PH7;
     uint32_t *centry = W.centry + static_cast<size_t>(fs) * nch;
-    uint32_t p = 0, n = 0; // the first record sits right behind the entry count
-    for (uint32_t base = 0; base < nch; base += FOLLOW_PIECE) {
-        const uint32_t cnt = min(FOLLOW_PIECE, nch - base);
-        if (p != DEAD7) { // (uniform) nothing left to follow once the chain is complete
-            const uint32_t words = cnt * PH7;
-            const uint32_t *src = maps + static_cast<size_t>(base) * PH7; // 16-byte aligned: base * 65 * 4, base % 4 == 0
-            for (uint32_t i = tid * 4u; i < words; i += 1024u) {
-                if (i + 4u <= words) {
-                    *reinterpret_cast<uint4 *>(&s_map[i]) = *reinterpret_cast<const uint4 *>(&src[i]);
-                } else {
-                    for (uint32_t t = i; t < words; t++)
-                        s_map[t] = src[t];
-                }
+    uint32_t p = 0, n = 0, creal = 0; // the first record sits right behind the entry count
+    for (uint32_t base = 0; base < nchunk && p != DEAD7; base += FOLLOW_PIECE) {
+        const uint32_t cnt = min(FOLLOW_PIECE, nchunk - base);
+        const uint32_t words = cnt * PH7;
+        const uint32_t *src = maps + static_cast<size_t>(base) * PH7; // 16-byte aligned (base % 4 == 0)
+        for (uint32_t i = tid * 4u; i < words; i += 1024u) {
+            if (i + 4u <= words) {
+                *reinterpret_cast<uint4 *>(&s_map[i]) = *reinterpret_cast<const uint4 *>(&src[i]);
+            } else {
+                for (uint32_t t = i; t < words; t++)
+                    s_map[t] = src[t];
             }
         }
         __syncthreads();
         if (tid == 0) {
-            for (uint32_t c = 0; c < cnt; c++) {
-                if (n >= R)
-                    p = DEAD7; // all records found: later chunks have nothing to do
+            uint32_t c = 0;
+            for (; c < cnt && p != DEAD7; c++) {
                 s_entry[c] = p | (n << 8);
-                if (p != DEAD7) {
-                    const uint32_t m = s_map[c * PH7 + p];
-                    n += m >> 8;
-                    p = m & 255u;
-                }
+                const uint32_t m = s_map[c * PH7 + p];
+                n += m >> 8;
+                p = n >= R ? DEAD7 : (m & 255u); // all records found: nothing beyond this chunk
             }
             s_state[0] = p;
             s_state[1] = n;
+            s_state[2] = c; // chunks of this piece that hold records
         }
         __syncthreads();
-        for (uint32_t i = tid; i < cnt; i += 256u)
+        const uint32_t live = s_state[2];
+        for (uint32_t i = tid; i < live; i += 256u)
             centry[base + i] = s_entry[i];
         p = s_state[0];
         n = s_state[1];
+        creal = base + live;
         __syncthreads();
     }
-    if (tid == 0 && n < R) // the chain ended before R records: a record crosses `len`
-        atomicOr(status, MCRAW_E_TRUNCATED);
+    if (n < R) {
+        // the chain stopped short of R records: a record crosses `len` -- or the bits stream
+        // runs past the start of the refs stream (non-canonical layout: host re-plans)
+        if (tid == 0)
+            atomicOr(status, (p != DEAD7 && hinted) ? E_LAYOUT : MCRAW_E_TRUNCATED);
+        return;
+    }
+    // work list of k7_records: the chunks [0, creal) of this stream
+    if (tid == 0)
+        s_state[3] = atomicAdd(W.counters + 1, creal);
+    __syncthreads();
+    uint4 *dst = W.list_recs + s_state[3];
+    for (uint32_t i = tid; i < creal; i += 256u) // stream, chunk, its byte offset, its entry (phase | first record << 8)
+        dst[i] = make_uint4(fs, i, si.x + i * CH7, centry[i]);
 }
 
 constexpr int REC_STAGE = CH7 + 130 + 8 + 16; // records starting in the chunk may run 130 bytes past it (+ read slack)
@@ -289,6 +363,7 @@ __device__ __forceinline__ uint32_t swz_xor(uint32_t v)
 // 2-byte LDS reads through the successor table), parses their headers in parallel, then
 // unpacks EIGHT records per pass: lane = (record, k) owns samples 8k..8k+7 exactly like a
 // payload lane (DecodeBlock on the record, RawData.cpp:489; + reference, :491-492).
+template <int ABL>
 __global__ __launch_bounds__(64) void k7_records(const Work7 W)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_b[REC_BYTES];
@@ -297,29 +372,34 @@ __global__ __launch_bounds__(64) void k7_records(const Work7 W)
     __shared__ uint32_t s_hdr[REC_MAX + 8]; // per record: payload offset | hbits << 12 | reference << 16
     __shared__ uint4 s_tab[72];
 
-    const uint32_t c = blockIdx.x, fs = blockIdx.y, f = fs >> 1, s = fs & 1u;
+    const uint32_t lane = threadIdx.x;
+    s_tab[lane] = reinterpret_cast<const uint4 *>(c_tab7)[lane];
+    if (lane < 8u)
+        s_tab[64u + lane] = reinterpret_cast<const uint4 *>(c_tab7)[64u + lane];
+    const uint32_t nwork = W.counters[1];
+    uint4 nextw = make_uint4(0, 0, 0, 0);
+    if (blockIdx.x < nwork)
+        nextw = W.list_recs[blockIdx.x];
+    for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+    const uint4 we = nextw;
+    if (wi + gridDim.x < nwork) // descriptor of the next work item rides behind this one
+        nextw = W.list_recs[wi + gridDim.x];
+    const uint32_t fs = __builtin_amdgcn_readfirstlane(we.x);
+    const uint32_t f = fs >> 1, s = fs & 1u;
     int32_t *status = W.status + f;
-    if (*status != 0)
-        return;
-    const uint32_t entry = __builtin_amdgcn_readfirstlane(W.centry[static_cast<size_t>(fs) * W.nch + c]);
+    const uint32_t entry = __builtin_amdgcn_readfirstlane(we.w);
     const uint32_t ph = entry & 255u, i0 = entry >> 8;
     const Plan7 *P = W.plans + f;
     const uint32_t R = P->ngroups, nblk = P->nblk;
-    if (ph == DEAD7 || i0 >= R)
-        return;
-    const uint32_t lane = threadIdx.x;
     const uint32_t len = P->len;
     const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
-    const uint4 hdr = ld_b128(rs, 0);
-    const uint32_t abs = __builtin_amdgcn_readfirstlane(stream_first(hdr, s)) + c * CH7;
+    const uint32_t abs = __builtin_amdgcn_readfirstlane(we.z);
     const uint32_t base16 = abs & ~15u, head = abs - base16;
+    __syncthreads(); // previous work item is done with the staging buffers
 #pragma unroll
     for (uint32_t q = 0; q < (REC_BYTES / 16 + 63) / 64; q++)
         if (lane + 64u * q < REC_BYTES / 16)
             reinterpret_cast<uint4 *>(s_b)[lane + 64u * q] = ld_b128(rs, base16 + (lane + 64u * q) * 16u);
-    s_tab[lane] = reinterpret_cast<const uint4 *>(c_tab7)[lane];
-    if (lane < 8u)
-        s_tab[64u + lane] = reinterpret_cast<const uint4 *>(c_tab7)[64u + lane];
     __syncthreads();
     for (uint32_t i = lane; i < REC_MAX; i += 64u)
         s_nxt[i] = static_cast<uint16_t>(next_of(s_b, head, 2u * i, abs, len));
@@ -330,13 +410,15 @@ __global__ __launch_bounds__(64) void k7_records(const Work7 W)
     while (rel < CH7 && i0 + n < R) {
         const uint32_t nx = s_nxt[rel >> 1];
         if (nx == NODEAD)
-            break; // k7_follow has failed the frame already
+            break; // cannot happen for a chunk k7_follow listed
         if (lane == 0)
             s_rec[n] = static_cast<uint16_t>(rel);
         rel = nx;
         n++;
     }
     __syncthreads();
+    if (ABL == 2)
+        n = 0;
     // headers of all records in parallel (RawData.cpp:106-110)
     for (uint32_t q = lane; q < n + 8u; q += 64u) {
         uint32_t hv = 0;
@@ -353,7 +435,7 @@ __global__ __launch_bounds__(64) void k7_records(const Work7 W)
     uint8_t *bits = W.bits + static_cast<size_t>(f) * W.Rmax * 64u;
     uint16_t *refs = W.refs + static_cast<size_t>(f) * W.Rmax * 64u;
     uint32_t *glen = W.grp_off + static_cast<size_t>(f) * (W.Rmax * ITEM_SPLIT + 1u);
-    for (uint32_t qb = 0; qb < n; qb += 8u) {
+    for (uint32_t qb = 0; qb < (ABL == 1 ? 0u : n); qb += 8u) {
         const uint32_t q = qb + sub;
         const bool live = q < n;
         const uint32_t h = s_hdr[q];
@@ -399,6 +481,7 @@ __global__ __launch_bounds__(64) void k7_records(const Work7 W)
         if (live && (k & (8u / ITEM_SPLIT - 1u)) == 0u)
             glen[r * ITEM_SPLIT + k / (8u / ITEM_SPLIT)] = l8 << 3; // lengths until k7_scan turns them into offsets
     }
+    } // work items
 }
 
 // ------------------------------------------------------------------ k7_scan
@@ -648,16 +731,46 @@ __global__ __launch_bounds__(256) void k7_tiles(const Work7 W, uint32_t total)
 
 // ------------------------------------------------------------------ launchers
 
+// Grid of a persistent kernel: as many workgroups as the device keeps resident.
+static uint32_t persistent_grid(int which)
+{
+    static uint32_t g[2] = {0, 0};
+    if (!g[which]) {
+        int dev = 0, cus = 256, per_cu = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
+            cus = p.multiProcessorCount;
+        hipError_t e = which == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k7_maps, 256, 0)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k7_records<0>, 64, 0);
+        if (e != hipSuccess || per_cu <= 0)
+            per_cu = which == 0 ? 8 : 16;
+        g[which] = static_cast<uint32_t>(cus * per_cu);
+    }
+    return g[which];
+}
+
 void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st)
 {
     const uint32_t n7 = static_cast<uint32_t>(W.n7);
     switch (stage) {
     case MCRAW_K7_WALK:
-        hipLaunchKernelGGL(k7_maps, dim3((W.nch + MAPS_CH - 1) / MAPS_CH, 2 * n7), dim3(256), 0, st, W);
+        hipLaunchKernelGGL(k7_hdr, dim3(1), dim3(256), 0, st, W);
+        hipLaunchKernelGGL(k7_maps, dim3(persistent_grid(0)), dim3(256), 0, st, W);
         hipLaunchKernelGGL(k7_follow, dim3(2 * n7), dim3(256), 0, st, W);
         break;
     case MCRAW_K7_META:
-        hipLaunchKernelGGL(k7_records, dim3(W.nch, 2 * n7), dim3(64), 0, st, W);
+        {
+            static const int abl = []() {
+                const char *e = std::getenv("MCRAW_ABLATE_REC");
+                return e ? std::atoi(e) : 0;
+            }();
+            if (abl == 1)
+                hipLaunchKernelGGL(k7_records<1>, dim3(persistent_grid(1)), dim3(64), 0, st, W);
+            else if (abl == 2)
+                hipLaunchKernelGGL(k7_records<2>, dim3(persistent_grid(1)), dim3(64), 0, st, W);
+            else
+                hipLaunchKernelGGL(k7_records<0>, dim3(persistent_grid(1)), dim3(64), 0, st, W);
+        }
         break;
     case MCRAW_K7_SCAN:
         hipLaunchKernelGGL(k7_scan, dim3(n7), dim3(256), 0, st, W);

@@ -74,3 +74,28 @@ def test_header_geometry_differs_from_rounded_size(gpu_ctx):
     written, status, outs = decode_batch_device(gpu_ctx, [(7, 200, 16, buf)])
     assert status == [0] and written == [200 * 16]
     assert np.array_equal(outs[0], want) and np.array_equal(want, big[:16, :200])
+
+
+def test_aliased_side_streams_are_replanned(gpu_ctx):
+    # A frame whose bits stream runs past the start of its refs stream (the two chains share
+    # bytes).  The reference follows each chain wherever it goes; the build's extent hint
+    # (bits stream ends at refsOffset) is wrong here, so the frame must be re-planned, not failed.
+    from _gpu import decode_batch_device
+    w, h, val = 256, 16, 5
+    img = np.full((h, w), val, np.uint16)
+    nblk = (w // 64) * (h // 4) * 4          # 64 blocks -> one side-stream record per stream
+    enc = L.encode7(img, np.full(nblk, 5, np.uint8))
+    bits_off = int(np.frombuffer(enc[8:12].tobytes(), np.uint32)[0])
+    nrec, m = (nblk + 63) // 64, 3
+    # rebuild the tail: one long run of {hbits 0, ref 5} records read by BOTH chains
+    tail = np.concatenate([_u32(nrec * 64), np.tile(np.array([0, 5], np.uint8), nrec + m + 4)])
+    buf = np.concatenate([enc[:bits_off], tail]).copy()
+    buf[12:16] = _u32(bits_off + 4 + 2 * m)   # refsOffset inside the bits stream
+    ret, want = L.oracle_decode7(buf, w, h)
+    assert ret == w * h and np.array_equal(want, img)
+    if L.ref() is not None:
+        rr, orr = L.ref_decode7(buf, w, h)
+        assert rr == w * h and np.array_equal(orr[:h], img)
+    written, status, outs = decode_batch_device(gpu_ctx, [(7, w, h, buf), (7, w, h, enc)])
+    assert status == [0, 0] and written == [w * h, w * h]
+    assert np.array_equal(outs[0], img) and np.array_equal(outs[1], img)
