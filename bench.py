@@ -6,7 +6,7 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the decode path (mcraw_decode_batch through the C ABI,
-kernels k7_walk -> k7_meta -> k7_scan -> k7_tiles) over one batch of synthetic
+kernels k7_hdr/maps/follow -> k7_records -> k7_scan -> k7_tiles) over one batch of synthetic
 frames that are already resident in HBM.  Workload = BASELINE.json config 3:
 240 frames of 3840x2160 12-bit, current (type 7) encoding, per GPU.  Frames
 shard by index, no collective on the data path (weak scaling: every rank decodes
@@ -57,22 +57,25 @@ def synth_lib():
     return L
 
 
-def make_frames(L, n, w, h, nbits, dist, sigma, seed0):
-    """n distinct (image, encoded buffer) pairs, generated and encoded in parallel on the host."""
-    def one(i):
-        img = L.synth_image(w, h, nbits, 1 if dist == "nat" else 0, sigma, seed0 + i)
+def make_frames(L, seeds, w, h, nbits, dist, sigma):
+    """One (image, encoded buffer) pair per seed, generated and encoded in parallel on the host."""
+    def one(seed):
+        img = L.synth_image(w, h, nbits, 1 if dist == "nat" else 0, sigma, seed)
         return img, L.encode7(img)
     with ThreadPoolExecutor(max_workers=max(1, min(os.cpu_count() or 1, 32))) as ex:
-        return list(ex.map(one, range(n)))
+        return list(ex.map(one, seeds))
 
 
 class Workload:
     """A batch of `frames` type-7 frames resident in HBM (inputs at distinct addresses)."""
 
-    def __init__(self, torch, M, L, dev, args, dist, seed0):
+    def __init__(self, torch, M, L, dev, args, dist, gidx):
+        """gidx: global frame indices of this rank (frame i of the job lives on rank i % world);
+        frame g is generated from seed 1000 * 3 + g (config 3 of SURVEY 8d)."""
         self.w, self.h = args.width, args.height
         self.frames = args.frames
-        self.pairs = make_frames(L, min(args.distinct, args.frames), self.w, self.h, args.nbits, dist, args.sigma, seed0)
+        seeds = [1000 * 3 + g for g in gidx[: min(args.distinct, args.frames)]]
+        self.pairs = make_frames(L, seeds, self.w, self.h, args.nbits, dist, args.sigma)
         lens = [p[1].size for p in self.pairs]
         d = len(self.pairs)
         stride = [(x + 255) // 256 * 256 for x in lens]
@@ -211,6 +214,7 @@ def main():
 
     import motioncam_decoder_amd as M
     from motioncam_decoder_amd import build as B
+    from motioncam_decoder_amd import shard
     if rank == 0 or world == 1:
         if not os.path.exists(M.lib_path()):
             B.build_hip()
@@ -224,15 +228,11 @@ def main():
     dists = [args.dist] + ([] if (args.no_also or world > 1) else [("u" if args.dist == "nat" else "nat")])
     results = {}
     for d in dists:
-        wl = Workload(torch, M, L, dev, args, d, 1000 * 3 + rank * args.frames)
+        # weak scaling: the job is world * frames frames, frame i decoded by rank i % world
+        wl = Workload(torch, M, L, dev, args, d, shard.shard_frames(world * args.frames, rank, world))
         el, kms, ok = run_timed(torch, dist_mod, ctx, M, wl, args.steps, args.warmup, world)
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
-        okt = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
-        if world > 1:
-            dist_mod.all_reduce(okt, op=dist_mod.ReduceOp.MIN)
-        results[d] = dict(wl=wl, elapsed=float(t.item()), kms=kms, ok=bool(okt.item()))
+        results[d] = dict(wl=wl, elapsed=shard.reduce_max(dist_mod, el, dev), kms=kms,
+                          ok=shard.reduce_min_flag(dist_mod, ok, dev))
 
     if rank == 0:
         r = results[args.dist]
