@@ -1,0 +1,385 @@
+// Decoder.cpp -- container side of motioncam::Decoder (host only) and the hand-off of
+// compressed frames to the MI355X decode path.  Written from the container layout
+// (Container.hpp); behaviour and error texts follow the reference's public contract
+// (lib/Decoder.cpp:97-319) so callers cannot tell the difference, the mechanics do not:
+// positional reads, one index built up front, batched GPU decode.
+#include <motioncam/Decoder.hpp>
+#include <motioncam/RawData.hpp>
+
+#include "mcraw_hip.h"
+
+#include <algorithm>
+#include <cerrno>
+#include <cstring>
+#include <unistd.h>
+
+namespace motioncam {
+
+namespace {
+
+constexpr int kTypeLegacy = MCRAW_TYPE_LEGACY; // frame JSON "compressionType" (lib/Decoder.cpp:20-21)
+constexpr int kTypeBlock = MCRAW_TYPE_BLOCK;
+
+// Positional reader over the container file: no shared file position, so frame
+// payloads can be fetched in any order (and, later, from several threads).
+class FileReader {
+public:
+    explicit FileReader(FILE *f) : mFile(f), mFd(f ? fileno(f) : -1) {}
+    ~FileReader()
+    {
+        if (mFile)
+            std::fclose(mFile);
+    }
+    bool ok() const { return mFd >= 0; }
+
+    // Reads exactly `size` bytes at `offset` or throws.
+    void readAt(int64_t offset, void *dst, size_t size) const
+    {
+        if (!tryReadAt(offset, dst, size))
+            throw IOException("Failed to read data");
+    }
+    bool tryReadAt(int64_t offset, void *dst, size_t size) const
+    {
+        if (offset < 0)
+            return false;
+        uint8_t *p = static_cast<uint8_t *>(dst);
+        while (size > 0) {
+            ssize_t n = ::pread(mFd, p, size, static_cast<off_t>(offset));
+            if (n < 0 && errno == EINTR)
+                continue;
+            if (n <= 0)
+                return false;
+            p += n;
+            offset += n;
+            size -= static_cast<size_t>(n);
+        }
+        return true;
+    }
+    int64_t size() const
+    {
+        off_t end = ::lseek(mFd, 0, SEEK_END);
+        return static_cast<int64_t>(end);
+    }
+
+private:
+    FILE *mFile;
+    int mFd;
+};
+
+template <typename T> T readPod(const FileReader &r, int64_t offset)
+{
+    T v{};
+    r.readAt(offset, &v, sizeof(T));
+    return v;
+}
+
+nlohmann::json readJson(const FileReader &r, int64_t offset, uint32_t size)
+{
+    std::string text(size, '\0');
+    if (size)
+        r.readAt(offset, &text[0], size);
+    return nlohmann::json::parse(text);
+}
+
+// Where the pieces of one frame live in the file.
+struct FrameSpan {
+    int64_t payload = 0;
+    uint32_t payloadSize = 0;
+    int64_t json = 0;
+    uint32_t jsonSize = 0;
+};
+
+bool loadAudioChunkAt(const FileReader &r, const BufferOffset &o, AudioChunk &out)
+{
+    Item item{};
+    if (!r.tryReadAt(o.offset, &item, sizeof(item)))
+        return false;
+    if (item.type != Type::AUDIO_DATA)
+        throw IOException("Invalid audio data");
+    std::vector<int16_t> samples((static_cast<size_t>(item.size) + 1) / 2);
+    r.readAt(o.offset + static_cast<int64_t>(sizeof(Item)), samples.data(), item.size);
+    // newer files follow the samples with their capture time; older ones do not
+    Timestamp ts = -1;
+    const int64_t next = o.offset + static_cast<int64_t>(sizeof(Item)) + item.size;
+    Item meta{};
+    r.readAt(next, &meta, sizeof(meta));
+    if (meta.type == Type::AUDIO_DATA_METADATA)
+        ts = readPod<AudioMetadata>(r, next + static_cast<int64_t>(sizeof(Item))).timestampNs;
+    out = std::make_pair(ts, std::move(samples));
+    return true;
+}
+
+} // namespace
+
+struct Decoder::Impl {
+    explicit Impl(FILE *f) : reader(f) {}
+
+    FileReader reader;
+    nlohmann::json metadata;
+    std::vector<Timestamp> frames;               // ascending
+    std::map<Timestamp, int64_t> frameOffsets;   // timestamp -> offset of its BUFFER item
+    std::vector<BufferOffset> audioOffsets;
+
+    struct Loader : AudioChunkLoader {
+        Loader(const FileReader &r, const std::vector<BufferOffset> &o) : reader(r), offsets(o) {}
+        bool next(AudioChunk &output) override
+        {
+            if (index >= offsets.size() || !loadAudioChunkAt(reader, offsets[index], output))
+                return false;
+            ++index;
+            return true;
+        }
+        const FileReader &reader;
+        const std::vector<BufferOffset> &offsets;
+        size_t index = 0;
+    };
+    std::unique_ptr<Loader> loader;
+
+    // pinned staging reused across loadFrames() calls
+    uint8_t *pinIn = nullptr, *pinOut = nullptr;
+    size_t pinInCap = 0, pinOutCap = 0;
+    mcraw_ctx *ctx = nullptr;
+
+    ~Impl()
+    {
+        mcraw_host_free(pinIn);
+        mcraw_host_free(pinOut);
+        if (ctx)
+            mcraw_ctx_destroy(ctx);
+    }
+
+    void open();
+    FrameSpan locate(Timestamp ts) const;
+};
+
+void Decoder::Impl::open()
+{
+    if (!reader.ok())
+        throw IOException("Invalid file");
+
+    const Header header = readPod<Header>(reader, 0);
+    if (header.version != CONTAINER_VERSION)
+        throw IOException("Invalid container version");
+    if (std::memcmp(header.ident, CONTAINER_ID, sizeof(CONTAINER_ID)) != 0)
+        throw IOException("Invalid header id");
+
+    // camera metadata follows the header
+    const Item camera = readPod<Item>(reader, sizeof(Header));
+    if (camera.type != Type::METADATA)
+        throw IOException("Invalid camera metadata");
+    metadata = readJson(reader, sizeof(Header) + sizeof(Item), camera.size);
+
+    // the frame index hangs off the last 24 bytes of the file
+    const int64_t fileSize = reader.size();
+    const int64_t tail = fileSize - static_cast<int64_t>(sizeof(Item) + sizeof(BufferIndex));
+    Item indexItem{};
+    if (tail < 0 || !reader.tryReadAt(tail, &indexItem, sizeof(indexItem)))
+        throw IOException("Failed to get end chunk");
+    if (indexItem.type != Type::BUFFER_INDEX)
+        throw IOException("Invalid file");
+    const BufferIndex index = readPod<BufferIndex>(reader, tail + static_cast<int64_t>(sizeof(Item)));
+    if (static_cast<uint32_t>(index.magicNumber) != INDEX_MAGIC_NUMBER)
+        throw IOException("Corrupted file");
+    if (index.numOffsets < 0)
+        throw IOException("Invalid index");
+
+    std::vector<BufferOffset> offsets(static_cast<size_t>(index.numOffsets));
+    if (!offsets.empty())
+        reader.readAt(index.indexDataOffset, offsets.data(), offsets.size() * sizeof(BufferOffset));
+    std::stable_sort(offsets.begin(), offsets.end(),
+                     [](const BufferOffset &a, const BufferOffset &b) { return a.timestamp < b.timestamp; });
+    for (const BufferOffset &o : offsets) {
+        frames.push_back(o.timestamp);
+        frameOffsets.insert({o.timestamp, o.offset});
+    }
+
+    // The audio index, when present, is found by hopping over the items that follow the
+    // last (by timestamp) frame.
+    if (!offsets.empty()) {
+        int64_t pos = offsets.back().offset;
+        for (;;) {
+            Item item{};
+            if (!reader.tryReadAt(pos, &item, sizeof(item)))
+                break;
+            pos += static_cast<int64_t>(sizeof(Item));
+            if (item.type == Type::BUFFER || item.type == Type::METADATA || item.type == Type::AUDIO_DATA ||
+                item.type == Type::AUDIO_DATA_METADATA) {
+                pos += item.size;
+            } else if (item.type == Type::AUDIO_INDEX) {
+                const AudioIndex ai = readPod<AudioIndex>(reader, pos);
+                pos += static_cast<int64_t>(sizeof(AudioIndex));
+                if (ai.numOffsets < 0)
+                    break;
+                audioOffsets.resize(static_cast<size_t>(ai.numOffsets));
+                if (!audioOffsets.empty())
+                    reader.readAt(pos, audioOffsets.data(), audioOffsets.size() * sizeof(BufferOffset));
+                pos += static_cast<int64_t>(audioOffsets.size() * sizeof(BufferOffset));
+            } else {
+                break;
+            }
+        }
+    }
+    loader.reset(new Loader(reader, audioOffsets));
+}
+
+FrameSpan Decoder::Impl::locate(Timestamp ts) const
+{
+    auto it = frameOffsets.find(ts);
+    if (it == frameOffsets.end())
+        throw IOException("Frame not found (timestamp: " + std::to_string(ts) + ")");
+    FrameSpan s;
+    Item buffer{};
+    if (!reader.tryReadAt(it->second, &buffer, sizeof(buffer)))
+        throw IOException("Invalid offset");
+    if (buffer.type != Type::BUFFER)
+        throw IOException("Invalid buffer type");
+    s.payload = it->second + static_cast<int64_t>(sizeof(Item));
+    s.payloadSize = buffer.size;
+    const int64_t metaPos = s.payload + buffer.size;
+    const Item meta = readPod<Item>(reader, metaPos);
+    if (meta.type != Type::METADATA)
+        throw IOException("Invalid metadata");
+    s.json = metaPos + static_cast<int64_t>(sizeof(Item));
+    s.jsonSize = meta.size;
+    return s;
+}
+
+Decoder::Decoder(FILE *file) : mImpl(new Impl(file))
+{
+    if (!file)
+        throw IOException("Invalid file");
+    mImpl->open();
+}
+
+Decoder::Decoder(const std::string &path) : mImpl(new Impl(std::fopen(path.c_str(), "rb")))
+{
+    if (!mImpl->reader.ok())
+        throw IOException("Failed to open " + path);
+    mImpl->open();
+}
+
+Decoder::~Decoder() = default;
+
+const std::vector<Timestamp> &Decoder::getFrames() const { return mImpl->frames; }
+
+const nlohmann::json &Decoder::getContainerMetadata() const { return mImpl->metadata; }
+
+int Decoder::audioSampleRateHz() const { return mImpl->metadata["extraData"]["audioSampleRate"]; }
+
+int Decoder::numAudioChannels() const { return mImpl->metadata["extraData"]["audioChannels"]; }
+
+void Decoder::loadAudio(std::vector<AudioChunk> &outAudioChunks)
+{
+    for (const BufferOffset &o : mImpl->audioOffsets) {
+        AudioChunk chunk;
+        if (loadAudioChunkAt(mImpl->reader, o, chunk))
+            outAudioChunks.emplace_back(std::move(chunk));
+    }
+}
+
+AudioChunkLoader &Decoder::loadAudio() const { return *mImpl->loader; }
+
+void Decoder::loadFrame(const Timestamp timestamp, std::vector<uint8_t> &outData, nlohmann::json &outMetadata)
+{
+    const FrameSpan span = mImpl->locate(timestamp);
+    std::vector<uint8_t> compressed(span.payloadSize);
+    if (span.payloadSize)
+        mImpl->reader.readAt(span.payload, compressed.data(), compressed.size());
+    outMetadata = readJson(mImpl->reader, span.json, span.jsonSize);
+
+    const int width = outMetadata["width"];
+    const int height = outMetadata["height"];
+    const int compressionType = outMetadata["compressionType"];
+    if (width <= 0 || height <= 0)
+        throw IOException("Failed to uncompress frame");
+    outData.resize(sizeof(uint16_t) * static_cast<size_t>(width) * static_cast<size_t>(height));
+    uint16_t *out = reinterpret_cast<uint16_t *>(outData.data());
+
+    if (compressionType == kTypeBlock) {
+        if (raw::Decode(out, width, height, compressed.data(), compressed.size()) <= 0)
+            throw IOException("Failed to uncompress frame");
+    } else if (compressionType == kTypeLegacy) {
+        if (raw::DecodeLegacy(out, width, height, compressed.data(), compressed.size()) <= 0)
+            throw IOException("Failed to uncompress legacy frame");
+    } else {
+        throw IOException("Invalid compression type");
+    }
+}
+
+void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<std::vector<uint8_t>> &outData,
+                         std::vector<nlohmann::json> &outMetadata)
+{
+    Impl &I = *mImpl;
+    const size_t n = timestamps.size();
+    outData.assign(n, {});
+    outMetadata.assign(n, nlohmann::json());
+    if (n == 0)
+        return;
+    if (!I.ctx && mcraw_ctx_create(-1, &I.ctx) != 0)
+        throw IOException(std::string("GPU decode unavailable: ") + mcraw_last_error());
+
+    // pass 1: locate, parse the per-frame JSON, size the pinned staging
+    std::vector<FrameSpan> spans(n);
+    std::vector<mcraw_frame> frames(n);
+    size_t inBytes = 0, outBytes = 0;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    for (size_t i = 0; i < n; i++) {
+        spans[i] = I.locate(timestamps[i]);
+        outMetadata[i] = readJson(I.reader, spans[i].json, spans[i].jsonSize);
+        const int width = outMetadata[i]["width"];
+        const int height = outMetadata[i]["height"];
+        const int type = outMetadata[i]["compressionType"];
+        if (type != kTypeBlock && type != kTypeLegacy)
+            throw IOException("Invalid compression type");
+        if (width <= 0 || height <= 0)
+            throw IOException("Failed to uncompress frame");
+        mcraw_frame &f = frames[i];
+        f.len = spans[i].payloadSize;
+        f.width = width;
+        f.height = height;
+        f.type = type;
+        f.reserved = 0;
+        f.out_capacity = static_cast<size_t>(width) * static_cast<size_t>(height);
+        inBytes += up(f.len);
+        outBytes += up(f.out_capacity * 2);
+    }
+    auto grow = [](uint8_t *&p, size_t &cap, size_t want) {
+        if (want <= cap)
+            return;
+        mcraw_host_free(p);
+        p = static_cast<uint8_t *>(mcraw_host_alloc(want));
+        cap = p ? want : 0;
+        if (!p)
+            throw IOException("Failed to allocate pinned staging");
+    };
+    grow(I.pinIn, I.pinInCap, inBytes);
+    grow(I.pinOut, I.pinOutCap, outBytes);
+
+    // pass 2: compressed payloads straight into pinned memory
+    size_t io = 0, oo = 0;
+    for (size_t i = 0; i < n; i++) {
+        mcraw_frame &f = frames[i];
+        if (f.len)
+            I.reader.readAt(spans[i].payload, I.pinIn + io, f.len);
+        f.in = I.pinIn + io;
+        f.out = reinterpret_cast<uint16_t *>(I.pinOut + oo);
+        io += up(f.len);
+        oo += up(f.out_capacity * 2);
+    }
+
+    // one batch: copies and decode pipelined on the context's streams
+    std::vector<size_t> written(n);
+    std::vector<int32_t> status(n);
+    if (mcraw_decode_batch(I.ctx, frames.data(), static_cast<int>(n), MCRAW_MEM_HOST, nullptr, written.data(),
+                           status.data()) != 0)
+        throw IOException(std::string("GPU decode failed: ") + mcraw_last_error());
+    for (size_t i = 0; i < n; i++) {
+        if (status[i] != 0 || written[i] == 0)
+            throw IOException(frames[i].type == kTypeBlock ? "Failed to uncompress frame"
+                                                           : "Failed to uncompress legacy frame");
+        const uint8_t *src = reinterpret_cast<const uint8_t *>(frames[i].out);
+        outData[i].assign(src, src + frames[i].out_capacity * 2);
+    }
+}
+
+} // namespace motioncam

@@ -1,0 +1,82 @@
+// Decoder.hpp -- motioncam::Decoder with the public interface of the reference
+// (lib/include/motioncam/Decoder.hpp:28-74), so that example.cpp and other callers build
+// unchanged, implemented from scratch on top of the MI355X decode path:
+//
+//   * the container is indexed once at construction and read with positional reads (pread),
+//     not with the reference's seek+read on a shared FILE position;
+//   * loadFrame() decodes on the GPU through mcraw_decode7 / mcraw_decode6;
+//   * loadFrames() (an addition) reads a whole set of frames into pinned memory and decodes
+//     them as ONE batch (mcraw_decode_batch, host-memory mode: H2D copies of a sub-batch overlap
+//     the decode of the previous one) -- the replacement for the per-frame loop of
+//     example.cpp:187-195.
+#ifndef MCRAW_HOST_DECODER_HPP
+#define MCRAW_HOST_DECODER_HPP
+
+#include <motioncam/Container.hpp>
+#include <nlohmann/json.hpp>
+
+#include <cstdio>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace motioncam {
+
+typedef int64_t Timestamp;
+typedef std::pair<Timestamp, std::vector<int16_t>> AudioChunk;
+
+class MotionCamException : public std::runtime_error {
+public:
+    MotionCamException(const std::string &error) : runtime_error(error) {}
+};
+
+class IOException : public MotionCamException {
+public:
+    IOException(const std::string &error) : MotionCamException(error) {}
+};
+
+class AudioChunkLoader {
+public:
+    virtual bool next(AudioChunk &output) = 0;
+    virtual ~AudioChunkLoader() = default;
+};
+
+class Decoder {
+public:
+    Decoder(const std::string &path);
+    Decoder(FILE *file); // takes ownership, like the reference (closed by the destructor)
+    ~Decoder();
+
+    Decoder(const Decoder &) = delete;
+    Decoder &operator=(const Decoder &) = delete;
+
+    // Container (camera) metadata.
+    const nlohmann::json &getContainerMetadata() const;
+
+    // Timestamps of all frames, ascending.
+    const std::vector<Timestamp> &getFrames() const;
+
+    // Decode one frame: outData becomes width*height uint16 LE (row-major Bayer mosaic).
+    void loadFrame(const Timestamp timestamp, std::vector<uint8_t> &outData, nlohmann::json &outMetadata);
+
+    // Decode many frames as one GPU batch (addition to the reference API).
+    void loadFrames(const std::vector<Timestamp> &timestamps, std::vector<std::vector<uint8_t>> &outData,
+                    std::vector<nlohmann::json> &outMetadata);
+
+    int audioSampleRateHz() const;
+    int numAudioChannels() const;
+
+    // All audio chunks at once / one at a time.
+    void loadAudio(std::vector<AudioChunk> &outAudioChunks);
+    AudioChunkLoader &loadAudio() const;
+
+private:
+    struct Impl;
+    std::unique_ptr<Impl> mImpl;
+};
+
+} // namespace motioncam
+
+#endif

@@ -1,0 +1,106 @@
+// mcraw_export -- decode a .mcraw file on the GPU and dump what it holds.
+//
+//   mcraw_export <file.mcraw> [-n frames] [-o outdir] [--single]
+//
+// Writes outdir/frame_%06d.u16 (width*height uint16 LE, row-major Bayer mosaic) for the
+// first N frames (by timestamp) and outdir/audio.s16 (interleaved PCM), and prints one line
+// per frame with its geometry and a CRC-32 of the pixels.  Frames are decoded as one GPU
+// batch (Decoder::loadFrames); --single uses the per-frame loadFrame() path instead.
+#include <motioncam/Decoder.hpp>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+static uint32_t crc32(const uint8_t *p, size_t n)
+{
+    static uint32_t table[256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++)
+                c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            table[i] = c;
+        }
+        init = true;
+    }
+    uint32_t c = 0xFFFFFFFFu;
+    for (size_t i = 0; i < n; i++)
+        c = table[(c ^ p[i]) & 0xFF] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
+}
+
+static bool writeFile(const std::string &path, const void *data, size_t size)
+{
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f)
+        return false;
+    const bool ok = size == 0 || std::fwrite(data, 1, size, f) == size;
+    std::fclose(f);
+    return ok;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) {
+        std::cerr << "Usage: mcraw_export <input file> [-n frames] [-o outdir] [--single]" << std::endl;
+        return 2;
+    }
+    std::string input = argv[1], outdir = ".";
+    long limit = -1;
+    bool single = false;
+    for (int i = 2; i < argc; i++) {
+        if (!std::strcmp(argv[i], "-n") && i + 1 < argc)
+            limit = std::atol(argv[++i]);
+        else if (!std::strcmp(argv[i], "-o") && i + 1 < argc)
+            outdir = argv[++i];
+        else if (!std::strcmp(argv[i], "--single"))
+            single = true;
+    }
+    try {
+        motioncam::Decoder decoder(input);
+        std::vector<motioncam::Timestamp> frames = decoder.getFrames();
+        std::cout << "Found " << frames.size() << " frames" << std::endl;
+        if (limit >= 0 && static_cast<size_t>(limit) < frames.size())
+            frames.resize(static_cast<size_t>(limit));
+
+        std::vector<motioncam::AudioChunk> audio;
+        decoder.loadAudio(audio);
+        std::vector<int16_t> pcm;
+        for (const auto &chunk : audio)
+            pcm.insert(pcm.end(), chunk.second.begin(), chunk.second.end());
+        if (!audio.empty()) {
+            writeFile(outdir + "/audio.s16", pcm.data(), pcm.size() * sizeof(int16_t));
+            std::cout << "audio: " << audio.size() << " chunks, " << pcm.size() << " samples, "
+                      << decoder.audioSampleRateHz() << " Hz x " << decoder.numAudioChannels() << std::endl;
+        }
+
+        std::vector<std::vector<uint8_t>> data;
+        std::vector<nlohmann::json> meta;
+        if (single) {
+            data.resize(frames.size());
+            meta.resize(frames.size());
+            for (size_t i = 0; i < frames.size(); i++)
+                decoder.loadFrame(frames[i], data[i], meta[i]);
+        } else {
+            decoder.loadFrames(frames, data, meta);
+        }
+        for (size_t i = 0; i < frames.size(); i++) {
+            char name[64];
+            std::snprintf(name, sizeof(name), "/frame_%06zu.u16", i);
+            if (!writeFile(outdir + name, data[i].data(), data[i].size()))
+                throw motioncam::IOException("Failed to write " + outdir + name);
+            const int w = meta[i]["width"], h = meta[i]["height"], t = meta[i]["compressionType"];
+            std::printf("frame %zu ts %lld %dx%d type %d crc32 %08x\n", i, static_cast<long long>(frames[i]), w, h, t,
+                        crc32(data[i].data(), data[i].size()));
+        }
+    } catch (const motioncam::MotionCamException &e) {
+        std::cerr << "Error: " << e.what() << std::endl;
+        return 1;
+    }
+    return 0;
+}

@@ -195,3 +195,56 @@ def natural_image_np(w, h, nbits, sigma, seed):
 def uniform_image_np(w, h, nbits, seed):
     rng = np.random.default_rng(seed)
     return rng.integers(0, 1 << nbits, size=(h, w), dtype=np.uint16)
+
+
+# ---------------------------------------------------------------- .mcraw container writer
+
+def write_mcraw(path, frames, audio_chunks=(), camera_extra=None, audio_rate=48000, audio_channels=2):
+    """Write a synthetic .mcraw container (layout: SURVEY Appendix A.5).
+
+    frames: list of (timestamp, type, width, height, encoded bytes), written in the given order
+    (the reader sorts by timestamp).  audio_chunks: list of (timestamp_ns or None, int16 array).
+    """
+    import json
+    import struct
+    camera = {"blackLevel": [64, 64, 64, 64], "whiteLevel": 1023.0, "sensorArrangment": "rggb",
+              "colorMatrix1": [1, 0, 0, 0, 1, 0, 0, 0, 1], "colorMatrix2": [1, 0, 0, 0, 1, 0, 0, 0, 1],
+              "forwardMatrix1": [1, 0, 0, 0, 1, 0, 0, 0, 1], "forwardMatrix2": [1, 0, 0, 0, 1, 0, 0, 0, 1],
+              "extraData": {"audioSampleRate": audio_rate, "audioChannels": audio_channels}}
+    if camera_extra:
+        camera.update(camera_extra)
+    BUFFER_INDEX, BUFFER_INDEX_DATA, BUFFER, METADATA, AUDIO_INDEX, AUDIO_DATA, AUDIO_DATA_METADATA = range(7)
+
+    def item(t, size):
+        return struct.pack("<II", t, size)
+
+    out = bytearray(b"MOTION " + bytes([3]))
+    cj = json.dumps(camera).encode()
+    out += item(METADATA, len(cj)) + cj
+    offsets = []
+    for ts, typ, w, h, buf in frames:
+        offsets.append((len(out), ts))
+        b = bytes(np.ascontiguousarray(buf, dtype=np.uint8))
+        out += item(BUFFER, len(b)) + b
+        fj = json.dumps({"width": w, "height": h, "compressionType": typ, "asShotNeutral": [1.0, 1.0, 1.0],
+                         "timestamp": str(ts)}).encode()
+        out += item(METADATA, len(fj)) + fj
+    audio_offsets = []
+    for ts, samples in audio_chunks:
+        audio_offsets.append((len(out), ts if ts is not None else -1))
+        b = np.ascontiguousarray(samples, dtype=np.int16).tobytes()
+        out += item(AUDIO_DATA, len(b)) + b
+        if ts is not None:
+            out += item(AUDIO_DATA_METADATA, 8) + struct.pack("<q", ts)
+    if audio_offsets:
+        out += item(AUDIO_INDEX, 16 + 16 * len(audio_offsets)) + struct.pack("<qq", len(audio_offsets), 0)
+        for off, ts in audio_offsets:
+            out += struct.pack("<qq", off, ts)
+    out += item(BUFFER_INDEX_DATA, 16 * len(offsets))
+    index_data_offset = len(out)
+    for off, ts in offsets:
+        out += struct.pack("<qq", off, ts)
+    out += item(BUFFER_INDEX, 16) + struct.pack("<iiq", np.int32(np.uint32(0x8A905612)), len(offsets), index_data_offset)
+    with open(path, "wb") as f:
+        f.write(out)
+    return path

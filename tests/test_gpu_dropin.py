@@ -1,0 +1,84 @@
+"""GPU (-m gpu): end-to-end drop-in.  A synthetic .mcraw (current + legacy frames written out of
+timestamp order, audio chunks with and without timestamps) goes through
+  * mcraw_export (own CLI over motioncam::Decoder::loadFrames -> one GPU batch, and --single),
+  * example_dropin: the reference's example.cpp, compiled unchanged against this repository,
+  * example_ref:    the reference built from its own sources (CPU codec),
+and the DNG / WAV files of the last two must be byte-identical."""
+import os
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+import _libs as L
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXPORT = os.path.join(ROOT, "motioncam_decoder_amd", "lib", "mcraw_export")
+DROPIN = os.path.join(ROOT, "oracle", "_ref", "example_dropin")
+REFEX = os.path.join(ROOT, "oracle", "_ref", "example_ref")
+
+
+@pytest.fixture(scope="module")
+def container(tmp_path_factory):
+    d = tmp_path_factory.mktemp("mcraw")
+    specs = [(3000, 7, 1920, 1080, 12, 12.0), (1000, 7, 640, 480, 10, 4.0), (2000, 6, 800, 600, 12, 12.0),
+             (4000, 6, 1000, 30, 14, 40.0), (5000, 7, 200, 12, 12, 12.0)]
+    frames, images = [], {}
+    for ts, typ, w, h, nb, sig in specs:
+        img = L.natural_image_np(w, h, nb, sig, ts)
+        frames.append((ts, typ, w, h, L.encode7(img) if typ == 7 else L.encode6(img)))
+        images[ts] = img
+    audio = [(111, np.arange(1920, dtype=np.int16)), (None, (np.arange(1920, dtype=np.int16) * 3).astype(np.int16))]
+    path = L.write_mcraw(str(d / "clip.mcraw"), frames, audio)
+    return d, path, images, audio
+
+
+def _run(cmd, cwd):
+    env = dict(os.environ)
+    return subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, timeout=300, env=env)
+
+
+@pytest.mark.parametrize("mode", ["batch", "single"])
+def test_export_tool(container, mode, tmp_path):
+    d, path, images, audio = container
+    if not os.path.exists(EXPORT):
+        from motioncam_decoder_amd import build
+        build.build_host()
+    cmd = [EXPORT, path, "-o", str(tmp_path)] + (["--single"] if mode == "single" else [])
+    r = _run(cmd, str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    assert "Found 5 frames" in r.stdout
+    order = sorted(images)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("frame ")]
+    assert len(lines) == 5
+    for i, ts in enumerate(order):
+        got = np.fromfile(str(tmp_path / ("frame_%06d.u16" % i)), dtype=np.uint16)
+        assert np.array_equal(got.reshape(images[ts].shape), images[ts]), (i, ts)
+        assert ("crc32 %08x" % (zlib.crc32(images[ts].tobytes()) & 0xFFFFFFFF)) in lines[i]
+    pcm = np.fromfile(str(tmp_path / "audio.s16"), dtype=np.int16)
+    assert np.array_equal(pcm, np.concatenate([a[1] for a in audio]))
+
+
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/example_dropin not built (needs /root/reference)")
+def test_reference_example_over_gpu_decode(container, tmp_path):
+    d, path, images, audio = container
+    a = tmp_path / "dropin"
+    a.mkdir()
+    r = _run([DROPIN, path], str(a))
+    assert r.returncode == 0, r.stderr + r.stdout
+    order = sorted(images)
+    for i, ts in enumerate(order):
+        dng = (a / ("frame_%06d.dng" % i)).read_bytes()
+        assert images[ts].tobytes() in dng, (i, ts)  # one uncompressed strip (example.cpp:80-92)
+    assert (a / "audio.wav").stat().st_size == 44 + 2 * 2 * 1920
+    if os.path.exists(REFEX):
+        b = tmp_path / "ref"
+        b.mkdir()
+        r2 = _run([REFEX, path], str(b))
+        assert r2.returncode == 0, r2.stderr
+        assert r.stdout == r2.stdout
+        for name in sorted(os.listdir(str(b))):
+            assert (a / name).read_bytes() == (b / name).read_bytes(), name
