@@ -186,6 +186,41 @@ def cpu_baseline(L, wl, seconds):
                       "%.1f s on %d threads + %.1f s on 1 thread" % (n, wl.w, wl.h, 12, res["all_s"], cores, res["one_s"])}
 
 
+def pcie_inclusive(M, ctx, wl, nframes=48, reps=3):
+    """End-to-end rate when the boundary hands over HOST buffers (never `value`): frames in pinned
+    memory -> H2D -> decode -> D2H into pinned memory, sub-batches pipelined on the context's
+    streams (mcraw_decode_batch, MCRAW_MEM_HOST)."""
+    lib = M.load()
+    d = len(wl.pairs)
+    n = min(nframes, wl.frames)
+    ins, outs, descs = [], [], []
+    try:
+        for i in range(n):
+            buf = wl.pairs[i % d][1]
+            pi = lib.mcraw_host_alloc(buf.size)
+            po = lib.mcraw_host_alloc(wl.out_stride)
+            ins.append(pi)
+            outs.append(po)
+            C.memmove(pi, buf.ctypes.data, buf.size)
+            descs.append((pi, buf.size, wl.w, wl.h, M.TYPE_BLOCK, po, wl.w * wl.h))
+        frames = M.Context.make_frames(descs)
+        ctx.decode_batch(frames, mem=M.MEM_HOST)  # warm-up: staging buffers get allocated
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            written, status = ctx.decode_batch(frames, mem=M.MEM_HOST)
+        t = (time.perf_counter() - t0) / reps
+        ok = all(s == 0 for s in status)
+        got = np.ctypeslib.as_array(C.cast(outs[0], C.POINTER(C.c_uint16)), shape=(wl.h, wl.w))
+        ok = ok and np.array_equal(got, wl.pairs[0][0])
+        in_b = sum(wl.pairs[i % d][1].size for i in range(n))
+        return {"frames": n, "mpix_s": round(n * wl.w * wl.h / t / 1e6, 1), "frames_per_s": round(n / t, 1),
+                "h2d_GBs": round(in_b / t / 1e9, 2), "d2h_GBs": round(n * wl.out_stride / t / 1e9, 2), "bit_exact": bool(ok),
+                "note": "pinned host buffers in and out, sub-batches pipelined on 4 streams; PCIe-bound"}
+    finally:
+        for p in ins + outs:
+            lib.mcraw_host_free(p)
+
+
 def traffic_from_profile(workload_key):
     """HBM bytes per k7_tiles launch from the committed rocprofv3 --pmc summary, if present."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
@@ -292,6 +327,10 @@ def main():
                                 "input_bpp": round(s2["bpp"], 2), "achieved_gbs": round(s2["achieved_gbs"], 1),
                                 "frac": round(s2["achieved_gbs"] / HBM_PEAK_GBS, 4), "bit_exact": results[d]["ok"]}
         if world == 1 and not args.no_cpu:
+            try:
+                out["pcie_inclusive"] = pcie_inclusive(M, ctx, wl)
+            except Exception as e:
+                out["pcie_inclusive"] = {"error": repr(e)}
             try:
                 out["cpu_baseline"] = cpu_baseline(L, wl, args.cpu_seconds)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU line
