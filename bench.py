@@ -122,14 +122,14 @@ def run_timed(torch, dist_mod, ctx, M, wl, steps, warmup, world):
     torch.cuda.synchronize()
     for k in M.KERNELS:
         ctx.kernel_ms(k, reset=True)
-    if world > 1:
+    if dist_mod.is_initialized():
         dist_mod.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         ctx.decode_batch(wl.descs, mem=M.MEM_DEVICE, stream=stream, want_status=False)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_mod.is_initialized():
         dist_mod.barrier()
     t1 = time.perf_counter()
     st = ctx.synchronize(wl.frames)
@@ -244,17 +244,18 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        dist_mod.init_process_group("nccl", device_id=dev)
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched by torch.distributed.run
+    if use_dist:
+        dist_mod.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
     import motioncam_decoder_amd as M
     from motioncam_decoder_amd import build as B
     from motioncam_decoder_amd import shard
-    if rank == 0 or world == 1:
+    if local == 0:
         if not os.path.exists(M.lib_path()):
             B.build_hip()
         B.build_synth()
-    if world > 1:
+    if use_dist:
         dist_mod.barrier()
     L = synth_lib()
     ctx = M.Context(local)
@@ -337,7 +338,7 @@ def main():
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist_mod.barrier()
         dist_mod.destroy_process_group()
 

@@ -24,7 +24,7 @@ def reduce_max(dist, value, device="cpu"):
     """Max over ranks of a python float (the job takes as long as its slowest rank)."""
     import torch
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -32,7 +32,7 @@ def reduce_max(dist, value, device="cpu"):
 def reduce_min_flag(dist, ok, device="cpu"):
     import torch
     t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return bool(t.item())
 
@@ -44,6 +44,6 @@ def gather_checksums(dist, n_total, local, device="cpu"):
     t = torch.zeros(n_total, dtype=torch.int64, device=device)
     for i, c in local.items():
         t[i] = int(c)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return [int(x) for x in t.tolist()]
