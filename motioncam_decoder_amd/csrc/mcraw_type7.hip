@@ -151,87 +151,63 @@ __device__ __forceinline__ uint32_t next_of(const uint8_t *s_b, uint32_t head, u
     return abs + nx > len ? NODEAD : nx;
 }
 
-// One thread per side stream (index fs = 2 * frame + s; s = 0 bits, 1 refs).
-__global__ __launch_bounds__(256) void k7_hdr(const Work7 W)
+// One wave per side stream (index fs = 2 * frame + s; s = 0 bits, 1 refs).
+__global__ __launch_bounds__(64) void k7_hdr(const Work7 W)
 {
-    __shared__ uint32_t s_w[4];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    const uint32_t nstreams = 2u * static_cast<uint32_t>(W.n7);
-    uint32_t carry = 0;
-    for (uint32_t base = 0; base < nstreams; base += 256u) {
-        const uint32_t fs = base + tid;
-        uint32_t nwg = 0;
-        if (fs < nstreams) {
-            const uint32_t f = fs >> 1, s = fs & 1u;
-            const Plan7 *P = W.plans + f;
-            const uint32_t len = P->len;
-            const uint8_t *in = P->in;
-            uint32_t h[4] = {0, 0, 0, 0};
-            if (len >= 16u) { // frame header: 4 x u32 LE (RawData.cpp:500-524)
-                const uint4 hv = *reinterpret_cast<const uint4 *>(in); // frame buffers are 16-byte aligned
-                h[0] = hv.x; h[1] = hv.y; h[2] = hv.z; h[3] = hv.w;
-            }
-            const uint32_t encW = h[0], encH = h[1], so = h[2 + s];
-            int32_t err = 0;
-            bool frame_ok = false;
-            if (len < 16u || h[2] > len || h[3] > len || (encW & 63u) != 0u ||
-                encW < static_cast<uint32_t>(P->width) || encW == 0u || encH == 0u || (encH & 3u) != 0u)
-                err = MCRAW_E_HEADER; // RawData.cpp:547-554 returns 0
-            else if (encW != P->encW || encH != P->encH)
-                err = E_GEOMETRY;
-            else {
-                frame_ok = true;
-                if (so + 4u > len || so + 4u < so)
-                    err = MCRAW_E_TRUNCATED;
-                else {
-                    const uint32_t count = static_cast<uint32_t>(in[so]) | (static_cast<uint32_t>(in[so + 1u]) << 8) |
-                                           (static_cast<uint32_t>(in[so + 2u]) << 16) |
-                                           (static_cast<uint32_t>(in[so + 3u]) << 24);
-                    if (count < P->nblk) // the reference would index past the vector (RawData.cpp:573-574)
-                        err = MCRAW_E_SIDESTREAM;
-                }
-            }
-            if (err)
-                atomicOr(W.status + f, err);
-            // Extent: the bits stream of a canonically laid out frame ends where the refs
-            // stream begins; k7_follow reports E_LAYOUT if its chain is still alive there and
-            // the host re-plans that frame with the hint off (Plan7::full_extent).
-            uint32_t s0 = so + 4u, nchunk = 0, hinted = 0;
-            if (frame_ok && !err) {
-                uint32_t end = len;
-                if (s == 0u && !P->full_extent && h[3] > h[2]) {
-                    end = h[3];
-                    hinted = 1u;
-                }
-                if (end > s0)
-                    nchunk = min(W.nch, (end - s0 + CH7 - 1u) / CH7);
-            }
-            nwg = (nchunk + MAPS_CH - 1u) / MAPS_CH;
-            W.sinfo[fs] = make_uint4(s0, nchunk, hinted, 0u);
+    const uint32_t fs = blockIdx.x, lane = threadIdx.x;
+    const uint32_t f = fs >> 1, s = fs & 1u;
+    const Plan7 *P = W.plans + f;
+    const uint32_t len = P->len;
+    const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
+    const uint4 hv = ld_b128(rs, 0); // frame header: 4 x u32 LE (RawData.cpp:500-524); zeros when len < 16
+    const uint32_t encW = __builtin_amdgcn_readfirstlane(hv.x), encH = __builtin_amdgcn_readfirstlane(hv.y);
+    const uint32_t bitsOff = __builtin_amdgcn_readfirstlane(hv.z), refsOff = __builtin_amdgcn_readfirstlane(hv.w);
+    const uint32_t so = s ? refsOff : bitsOff;
+    int32_t err = 0;
+    bool frame_ok = false;
+    if (len < 16u || bitsOff > len || refsOff > len || (encW & 63u) != 0u || encW < static_cast<uint32_t>(P->width) ||
+        encW == 0u || encH == 0u || (encH & 3u) != 0u)
+        err = MCRAW_E_HEADER; // RawData.cpp:547-554 returns 0
+    else if (encW != P->encW || encH != P->encH)
+        err = E_GEOMETRY;
+    else {
+        frame_ok = true;
+        if (so + 4u > len || so + 4u < so)
+            err = MCRAW_E_TRUNCATED;
+        else {
+            const uint32_t count = ld_u8(rs, so) | (ld_u8(rs, so + 1u) << 8) | (ld_u8(rs, so + 2u) << 16) |
+                                   (ld_u8(rs, so + 3u) << 24);
+            if (__builtin_amdgcn_readfirstlane(count) < P->nblk) // the reference would index past the vector (:573-574)
+                err = MCRAW_E_SIDESTREAM;
         }
-        // block-wide exclusive scan of nwg -> position of this stream's entries in the list
-        uint32_t wtot;
-        const uint32_t ex = wave_excl_scan(nwg, lane, &wtot);
-        if (lane == 63u)
-            s_w[w] = wtot;
-        __syncthreads();
-        uint32_t before = 0, total = 0;
-#pragma unroll
-        for (uint32_t q = 0; q < 4u; q++) {
-            before += q < w ? s_w[q] : 0u;
-            total += s_w[q];
-        }
-        uint4 *dst = W.list_maps + carry + before + ex;
-        if (nwg) { // everything k7_maps needs to start loading: stream, first chunk, its byte offset, chunk count
-            const uint4 si = W.sinfo[fs];
-            for (uint32_t i = 0; i < nwg; i++)
-                dst[i] = make_uint4(fs, i * MAPS_CH, si.x + i * MAPS_CH * CH7, si.y);
-        }
-        carry += total;
-        __syncthreads();
     }
-    if (tid == 0)
-        W.counters[0] = carry;
+    if (err && lane == 0)
+        atomicOr(W.status + f, err);
+    // Extent: the bits stream of a canonically laid out frame ends where the refs stream
+    // begins; k7_follow reports E_LAYOUT if its chain is still alive there and the host
+    // re-plans that frame with the hint off (Plan7::full_extent).
+    const uint32_t s0 = so + 4u;
+    uint32_t nchunk = 0, hinted = 0;
+    if (frame_ok && !err) {
+        uint32_t end = len;
+        if (s == 0u && !P->full_extent && refsOff > bitsOff) {
+            end = refsOff;
+            hinted = 1u;
+        }
+        if (end > s0)
+            nchunk = min(W.nch, (end - s0 + CH7 - 1u) / CH7);
+    }
+    const uint32_t nwg = (nchunk + MAPS_CH - 1u) / MAPS_CH;
+    uint32_t base = 0;
+    if (lane == 0) {
+        W.sinfo[fs] = make_uint4(s0, nchunk, hinted, 0u);
+        if (nwg)
+            base = atomicAdd(W.counters, nwg); // the order of the work list does not matter
+    }
+    base = __builtin_amdgcn_readfirstlane(base);
+    // everything k7_maps needs to start loading: stream, first chunk, its byte offset, chunk count
+    for (uint32_t i = lane; i < nwg; i += 64u)
+        W.list_maps[base + i] = make_uint4(fs, i * MAPS_CH, s0 + i * MAPS_CH * CH7, nchunk);
 }
 
 __global__ __launch_bounds__(256) void k7_maps(const Work7 W)
@@ -367,8 +343,6 @@ template <int ABL>
 __global__ __launch_bounds__(64) void k7_records(const Work7 W)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_b[REC_BYTES];
-    __shared__ uint16_t s_nxt[REC_MAX];
-    __shared__ uint16_t s_rec[REC_MAX];
     __shared__ uint32_t s_hdr[REC_MAX + 8]; // per record: payload offset | hbits << 12 | reference << 16
     __shared__ uint4 s_tab[72];
 
@@ -401,34 +375,26 @@ __global__ __launch_bounds__(64) void k7_records(const Work7 W)
         if (lane + 64u * q < REC_BYTES / 16)
             reinterpret_cast<uint4 *>(s_b)[lane + 64u * q] = ld_b128(rs, base16 + (lane + 64u * q) * 16u);
     __syncthreads();
-    for (uint32_t i = lane; i < REC_MAX; i += 64u)
-        s_nxt[i] = static_cast<uint16_t>(next_of(s_b, head, 2u * i, abs, len));
-    __syncthreads();
 
-    // list the records that start in this chunk (every lane runs the same chain)
+    // Walk the records that start in this chunk (every lane runs the same chain) and note
+    // payload offset, class and reference of each (RawData.cpp:106-110).  One walk only, so the
+    // headers are read straight from the staged bytes (no successor table as in k7_maps).
     uint32_t rel = 2u * ph, n = 0;
     while (rel < CH7 && i0 + n < R) {
-        const uint32_t nx = s_nxt[rel >> 1];
-        if (nx == NODEAD)
+        const uint32_t ro = head + rel;
+        const uint32_t b0 = s_b[ro], b1 = s_b[ro + 1u];
+        const uint32_t nx = rel + 2u + len7_of(b0 >> 4);
+        if (abs + nx > len)
             break; // cannot happen for a chunk k7_follow listed
         if (lane == 0)
-            s_rec[n] = static_cast<uint16_t>(rel);
+            s_hdr[n] = (ro + 2u) | ((b0 >> 4) << 12) | ((((b0 & 15u) << 8) | b1) << 16);
         rel = nx;
         n++;
     }
-    __syncthreads();
     if (ABL == 2)
         n = 0;
-    // headers of all records in parallel (RawData.cpp:106-110)
-    for (uint32_t q = lane; q < n + 8u; q += 64u) {
-        uint32_t hv = 0;
-        if (q < n) {
-            const uint32_t ro = head + s_rec[q];
-            const uint32_t b0 = s_b[ro], b1 = s_b[ro + 1u];
-            hv = (ro + 2u) | ((b0 >> 4) << 12) | ((((b0 & 15u) << 8) | b1) << 16);
-        }
-        s_hdr[q] = hv; // 8 zero entries of padding: idle lanes of the last pass unpack "class 0"
-    }
+    if (lane < 8u)
+        s_hdr[n + lane] = 0u; // padding: idle lanes of the last pass unpack "class 0"
     __syncthreads();
 
     const uint32_t k = lane & 7u, sub = lane >> 3;
@@ -488,9 +454,9 @@ __global__ __launch_bounds__(64) void k7_records(const Work7 W)
 //
 // Payload offset of every group: 16 + sum of the lengths before it
 // (RawData.cpp:562 `offset = METADATA_OFFSET`, :576-579 `offset += ...`).
-__global__ __launch_bounds__(256) void k7_scan(const Work7 W)
+__global__ __launch_bounds__(1024) void k7_scan(const Work7 W)
 {
-    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_w[16];
     const Plan7 *P = W.plans + blockIdx.x;
     int32_t *status = W.status + blockIdx.x;
     if (*status != 0)
@@ -498,7 +464,7 @@ __global__ __launch_bounds__(256) void k7_scan(const Work7 W)
     const uint32_t R = P->ngroups * ITEM_SPLIT, tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     uint32_t *__restrict__ g = W.grp_off + static_cast<size_t>(blockIdx.x) * (W.Rmax * ITEM_SPLIT + 1u);
     uint32_t carry = 16u;
-    for (uint32_t base = 0; base < R; base += 256u) {
+    for (uint32_t base = 0; base < R; base += 1024u) {
         const uint32_t i = base + tid;
         const uint32_t v = i < R ? g[i] : 0u;
         uint32_t wtot;
@@ -508,7 +474,7 @@ __global__ __launch_bounds__(256) void k7_scan(const Work7 W)
         __syncthreads();
         uint32_t before = 0, total = 0;
 #pragma unroll
-        for (uint32_t q = 0; q < 4u; q++) {
+        for (uint32_t q = 0; q < 16u; q++) {
             const uint32_t x = s_w[q];
             before += q < w ? x : 0u;
             total += x;
@@ -754,7 +720,7 @@ void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st)
     const uint32_t n7 = static_cast<uint32_t>(W.n7);
     switch (stage) {
     case MCRAW_K7_WALK:
-        hipLaunchKernelGGL(k7_hdr, dim3(1), dim3(256), 0, st, W);
+        hipLaunchKernelGGL(k7_hdr, dim3(2 * n7), dim3(64), 0, st, W);
         hipLaunchKernelGGL(k7_maps, dim3(persistent_grid(0)), dim3(256), 0, st, W);
         hipLaunchKernelGGL(k7_follow, dim3(2 * n7), dim3(256), 0, st, W);
         break;
@@ -773,7 +739,7 @@ void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st)
         }
         break;
     case MCRAW_K7_SCAN:
-        hipLaunchKernelGGL(k7_scan, dim3(n7), dim3(256), 0, st, W);
+        hipLaunchKernelGGL(k7_scan, dim3(n7), dim3(1024), 0, st, W);
         break;
     case MCRAW_K7_TILES: {
         const uint32_t total = W.Rmax * ITEM_SPLIT * n7;
