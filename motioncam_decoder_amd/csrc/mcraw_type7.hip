@@ -71,7 +71,7 @@ __device__ __forceinline__ uint32_t term_shl(uint32_t t) { return (t >> 24) & 31
 struct Unpacked { uint32_t x[4]; }; // samples (0,1)(2,3)(4,5)(6,7)
 
 // 8 bytes of LDS at byte offset `off` of the array `base`.  Payload blocks are 8-byte
-// aligned (ALIGNED8); side-stream records only 2-byte aligned: three aligned dwords
+// aligned (ALIGNED8); side-stream records sit at arbitrary byte offsets: three aligned dwords
 // and a funnel shift then stand in for the unaligned 64-bit read.
 template <bool ALIGNED8>
 __device__ __forceinline__ uint2 lds_read8(const uint8_t *__restrict__ base, uint32_t off)
@@ -79,7 +79,7 @@ __device__ __forceinline__ uint2 lds_read8(const uint8_t *__restrict__ base, uin
     if (ALIGNED8)
         return *reinterpret_cast<const uint2 *>(base + off);
     const uint32_t *w = reinterpret_cast<const uint32_t *>(base) + (off >> 2);
-    const uint32_t sh = (off & 2u) * 8u;
+    const uint32_t sh = (off & 3u) * 8u; // any byte alignment: a side stream may start at an odd offset
     const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
     return make_uint2(__builtin_amdgcn_alignbit(w1, w0, sh), __builtin_amdgcn_alignbit(w2, w1, sh));
 }

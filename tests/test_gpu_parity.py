@@ -129,3 +129,31 @@ def test_roundtrip_property_8k(gpu_ctx):
         img = L.synth_image(w, h, 12, dist, 12.0, seed)
         buf = L.encode7(img)
         _check(gpu_ctx, [(7, w, h, buf)], [(w * h, img)])
+
+
+def _shift_streams(buf, pad_bits, pad_refs):
+    """Re-lay a type-7 frame with `pad_*` junk bytes in front of each side stream (the header
+    offsets are free-form: lib/RawData.cpp:513-523 just reads them)."""
+    bo = int(np.frombuffer(buf[8:12].tobytes(), np.uint32)[0])
+    ro = int(np.frombuffer(buf[12:16].tobytes(), np.uint32)[0])
+    out = np.concatenate([buf[:bo], np.full(pad_bits, 0xEE, np.uint8), buf[bo:ro], np.full(pad_refs, 0x77, np.uint8), buf[ro:]])
+    out = out.copy()
+    out[8:12] = np.frombuffer(np.uint32(bo + pad_bits).tobytes(), np.uint8)
+    out[12:16] = np.frombuffer(np.uint32(ro + pad_bits + pad_refs).tobytes(), np.uint8)
+    return out
+
+
+@pytest.mark.parametrize("pads", [(1, 0), (0, 1), (3, 2), (5, 7), (2, 2), (1030, 515)])
+def test_side_streams_at_odd_offsets(gpu_ctx, pads):
+    items, expect = [], []
+    for (w, h, nb, sig, seed) in ((256, 32, 12, 12.0, 1), (1000, 20, 14, 40.0, 2), (640, 480, 10, 4.0, 3)):
+        img = L.natural_image_np(w, h, nb, sig, seed)
+        buf = _shift_streams(L.encode7(img), *pads)
+        ret, out = L.oracle_decode7(buf, w, h)
+        assert ret == w * h and np.array_equal(out, img)
+        if L.ref() is not None:
+            rr, orr = L.ref_decode7(buf, w, h)
+            assert np.array_equal(orr[:h], img)
+        items.append((7, w, h, buf))
+        expect.append((ret, out))
+    _check(gpu_ctx, items, expect)
