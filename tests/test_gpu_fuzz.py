@@ -36,7 +36,8 @@ def _compare(ctx, typ, w, h, bufs, decode):
             assert status[i] != 0 and written[i] == 0, (i, status[i], written[i])
         else:
             assert status[i] == 0 and written[i] == ret, (i, status[i], written[i], ret)
-            assert np.array_equal(outs[i], want), i
+            rows = ret // w  # a frame coded shorter than `height` leaves the rows below untouched
+            assert np.array_equal(outs[i][:rows], want[:rows]), i
             n_ok += 1
     return n_ok
 
@@ -54,6 +55,26 @@ def test_type7_mutants(gpu_ctx):
             bufs = [buf] + _mutants(buf, rng, 60, hot) + [buf]
             total_ok += _compare(gpu_ctx, 7, w, h, bufs, L.oracle_decode7)
     assert total_ok > 50  # plenty of mutants still decode (payload flips) -- and bit-exactly so
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_type7_side_stream_mutants_many_chunks(gpu_ctx, seed):
+    # frames whose side streams span many transition-map chunks; mutations confined to the streams
+    # (record headers change the chain, references and bits change the pixels or fail the frame)
+    rng = np.random.default_rng(700 + seed)
+    w, h = 1920, 1080
+    img = L.synth_image(w, h, 12, 1, 12.0, 9000 + seed)
+    buf = L.encode7(img)
+    bits_off = int(np.frombuffer(buf[8:12].tobytes(), np.uint32)[0])
+    bufs = [buf] + _mutants(buf, rng, 40, [(bits_off, buf.size)] * 3) + [buf]
+    # structured header mutants: offsets nudged, geometry changed
+    for off, delta in ((8, 1), (8, -2), (12, 1), (12, -7), (12, 2), (0, 64), (4, 4), (4, -4)):
+        b = buf.copy()
+        v = int(np.frombuffer(b[off:off + 4].tobytes(), np.uint32)[0]) + delta
+        b[off:off + 4] = np.frombuffer(np.uint32(v).tobytes(), np.uint8)
+        bufs.append(b)
+    n_ok = _compare(gpu_ctx, 7, w, h, bufs, L.oracle_decode7)
+    assert n_ok >= 2
 
 
 def test_type6_mutants(gpu_ctx):
