@@ -325,7 +325,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         row_base[k] = nrow;
         nmap += (p.nchunks + 11) / 12; // k6_maps: 12 chunks per workgroup
         nsup += p.nsuper;
-        nrow += (p.nchunks + 3) / 4; // k6_rows: one chunk per wave
+        nrow += (p.nchunks + 4 * ROWS_CH - 1) / (4 * ROWS_CH); // k6_rows: ROWS_CH chunks per wave, 4 waves
     }
     map_base[n6] = nmap;
     super_base[n6] = nsup;

@@ -178,114 +178,139 @@ __global__ __launch_bounds__(64) void k6_chunks(const Plan6 *__restrict__ plans,
 constexpr int ROW_STAGE = CHUNK6 + 64; // a record may start at byte 1022 and run 34 bytes; +8 for the bit window
 constexpr int ROW_MAXREC = CHUNK6 / 2;
 
-// 16 residuals of one record: an MSB-first bitstream of `sb`-bit fields
-// (sb = header nibble for <= 10, 16 for the big-endian raw form, RawData_Legacy.cpp:360-370).
-__device__ __forceinline__ void unpack16(const uint32_t *__restrict__ words, uint32_t boff, uint32_t sb,
-                                         uint32_t out[16])
+// Residual k of a record: field k of an MSB-first bitstream of `sb`-bit fields starting at byte
+// `boff` of the staged bytes (sb = header nibble for <= 10, 16 for the big-endian raw form,
+// RawData_Legacy.cpp:38-370).  Two aligned dwords around the field form a 64-bit big-endian window.
+__device__ __forceinline__ uint32_t field6(const uint32_t *__restrict__ words, uint32_t boff, uint32_t sb, uint32_t k)
 {
-#pragma unroll
-    for (uint32_t k = 0; k < 16u; k++) {
-        const uint32_t o = k * sb;            // bit offset of sample k in the payload
-        const uint32_t byte = boff + (o >> 3);
-        const uint32_t wi = byte >> 2;        // aligned dword pair holding the field
-        const uint32_t hi = __builtin_bswap32(words[wi]), lo = __builtin_bswap32(words[wi + 1u]);
-        const uint32_t bo = 8u * (byte & 3u) + (o & 7u);
-        const uint64_t win = ((static_cast<uint64_t>(hi) << 32) | lo) << bo;
-        out[k] = sb ? static_cast<uint32_t>(win >> (64u - sb)) : 0u;
-    }
+    const uint32_t o = k * sb;
+    const uint32_t byte = boff + (o >> 3);
+    const uint32_t wi = byte >> 2;
+    const uint32_t hi = __builtin_bswap32(words[wi]), lo = __builtin_bswap32(words[wi + 1u]);
+    const uint32_t bo = 8u * (byte & 3u) + (o & 7u);
+    const uint64_t win = ((static_cast<uint64_t>(hi) << 32) | lo) << bo;
+    return sb ? static_cast<uint32_t>(win >> (64u - sb)) : 0u;
 }
+
+// One wave per ROWS_CH consecutive chunks (8 KiB of stream).  Lane j < ROWS_CH walks chunk j from
+// its resolved entry and notes where every record starts; the records of the wave form one
+// contiguous index range, so the list is flat.  Then ALL lanes unpack, four lanes per record pair:
+// a lane owns samples 4q..4q+3 of the even-column record and of the odd-column record = 8
+// consecutive pixels = one 16-byte store; 8 lanes fill a 128-byte line.  (A wave-uniform walk of
+// ONE chunk per wave spent 64 lanes on a scalar chain and made this kernel issue-bound.)
+constexpr uint32_t ROWS_CAP = 1024; // records listed per round (typical: 8 chunks x ~70; worst case 8 x 512 -> 4 rounds)
 
 __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, const uint32_t *__restrict__ item_base,
                                                int nframes)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_bytes[4][ROW_STAGE + 16];
-    __shared__ uint16_t s_rec[4][ROW_MAXREC];
+    constexpr uint32_t STAGE = ROWS_CH * CHUNK6 + 64 + 16;
+    __shared__ __attribute__((aligned(16))) uint8_t s_bytes[4][STAGE];
+    __shared__ uint16_t s_pos[4][ROWS_CAP];
 
     const int f = find_frame(blockIdx.x, item_base, nframes);
     const Plan6 *P = plans + f;
     if (*P->status != 0)
         return;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t c = (blockIdx.x - item_base[f]) * 4u + wave;
-    if (c >= P->nchunks)
+    const uint32_t nchunks = P->nchunks, nrec = P->nrec, len = P->len;
+    const uint32_t c0 = ((blockIdx.x - item_base[f]) * 4u + wave) * ROWS_CH;
+    if (c0 >= nchunks)
         return;
-    const uint32_t entry = __builtin_amdgcn_readfirstlane(P->centry[c]);
-    const uint32_t ph = entry & 255u, i0 = entry >> 8;
-    const uint32_t nrec = P->nrec, len = P->len;
-    if (ph == DEAD || i0 >= nrec)
+    // entries of my chunks (lane j) and of the chunk after them (lane ROWS_CH)
+    uint32_t e = DEAD;
+    if (lane <= ROWS_CH && c0 + lane < nchunks)
+        e = P->centry[c0 + lane];
+    const uint32_t e0 = __builtin_amdgcn_readfirstlane(e);
+    if ((e0 & 255u) == DEAD)
+        return; // the chain ended before this wave's chunks
+    const uint32_t I0 = e0 >> 8;
+    const uint32_t enext = __shfl(e, ROWS_CH, 64);
+    const uint32_t Iend = min(nrec, (c0 + ROWS_CH < nchunks) ? (enext >> 8) : nrec);
+    if (I0 >= Iend)
         return;
-    const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
-    const uint32_t cs = c * CHUNK6;
+    const uint32_t N = Iend - I0;
 
+    const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
+    const uint32_t cs0 = c0 * CHUNK6;
     uint4 *dst = reinterpret_cast<uint4 *>(s_bytes[wave]);
-    dst[lane] = ld_b128(rs, cs + lane * 16u);
-    if (lane < (ROW_STAGE + 16 - CHUNK6) / 16)
-        dst[64 + lane] = ld_b128(rs, cs + CHUNK6 + lane * 16u);
+#pragma unroll
+    for (uint32_t q = 0; q < (STAGE / 16 + 63) / 64; q++)
+        if (lane + 64u * q < STAGE / 16)
+            dst[lane + 64u * q] = ld_b128(rs, cs0 + (lane + 64u * q) * 16u);
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_wave_barrier();
 
-    // list the records that start in this chunk (wave-uniform scalar walk)
     const uint8_t *bytes = s_bytes[wave];
     const uint32_t *words = reinterpret_cast<const uint32_t *>(s_bytes[wave]);
-    uint32_t pos = 2u * ph, n = 0;
-    while (pos < CHUNK6 && i0 + n < nrec) {
-        const uint32_t hb = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(bytes[pos])) >> 4;
-        const uint32_t L = len6_of(hb);
-        if (cs + pos + 2u + L >= len)
-            break; // k6_frame has already failed the frame if records are missing
-        if (lane == 0)
-            s_rec[wave][n] = static_cast<uint16_t>(pos);
-        pos += 2u + L;
-        n++;
-    }
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
-
     const uint32_t rpr = P->recs_per_row;
-    const int32_t width = P->width;
+    const uint32_t width = static_cast<uint32_t>(P->width);
     const bool fast = P->fast_store != 0u;
-    const uint32_t pair0 = i0 >> 1;
-    const uint32_t npairs = ((i0 + n + 1u) >> 1) - pair0;
-    for (uint32_t q = lane; q < npairs; q += 64u) {
-        const uint32_t ra = 2u * (pair0 + q), rb = ra + 1u; // even-column and odd-column record
-        const bool hasA = ra >= i0 && ra < i0 + n;
-        const bool hasB = rb >= i0 && rb < i0 + n;
-        uint32_t va[16], vb[16];
-        uint32_t refA = 0, refB = 0;
-        if (hasA) {
-            const uint32_t ro = s_rec[wave][ra - i0];
-            const uint32_t hb = bytes[ro] >> 4;                     // RawData_Legacy.cpp:372-375
-            refA = ((static_cast<uint32_t>(bytes[ro]) & 15u) << 8) | bytes[ro + 1u];
-            unpack16(words, ro + 2u, hb <= 10u ? hb : 16u, va);
-        }
-        if (hasB) {
-            const uint32_t ro = s_rec[wave][rb - i0];
-            const uint32_t hb = bytes[ro] >> 4;
-            refB = ((static_cast<uint32_t>(bytes[ro]) & 15u) << 8) | bytes[ro + 1u];
-            unpack16(words, ro + 2u, hb <= 10u ? hb : 16u, vb);
-        }
-        const uint32_t y = ra / rpr;
-        const uint32_t x = ((ra - y * rpr) >> 1) * 32u; // RawData_Legacy.cpp:479-486
-        uint16_t *row = P->out + static_cast<size_t>(y) * static_cast<size_t>(width);
-        if (hasA && hasB && fast && x + 32u <= static_cast<uint32_t>(width)) {
-            uint32_t o[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++)
-                o[i] = ((va[i] + refA) & 0xffffu) | ((vb[i] + refB) << 16);
-            uint4 *d4 = reinterpret_cast<uint4 *>(row + x);
-            d4[0] = make_uint4(o[0], o[1], o[2], o[3]);
-            d4[1] = make_uint4(o[4], o[5], o[6], o[7]);
-            d4[2] = make_uint4(o[8], o[9], o[10], o[11]);
-            d4[3] = make_uint4(o[12], o[13], o[14], o[15]);
-        } else {
-#pragma unroll
-            for (uint32_t i = 0; i < 16u; i++) {
-                if (hasA && x + 2u * i < static_cast<uint32_t>(width))
-                    row[x + 2u * i] = static_cast<uint16_t>(va[i] + refA);
-                if (hasB && x + 2u * i + 1u < static_cast<uint32_t>(width))
-                    row[x + 2u * i + 1u] = static_cast<uint16_t>(vb[i] + refB);
+    const bool walker = lane < ROWS_CH && (e & 255u) != DEAD && c0 + lane < nchunks;
+
+    for (uint32_t base = 0; base < N; base += ROWS_CAP) {
+        const uint32_t wlo = I0 + base, whi = min(Iend, wlo + ROWS_CAP); // records listed this round
+        if (walker) {
+            const uint32_t off = lane * CHUNK6;
+            uint32_t pos = 2u * (e & 255u), idx = e >> 8;
+            while (pos < CHUNK6 && idx < whi) {
+                const uint32_t nx = pos + 2u + len6_of(static_cast<uint32_t>(bytes[off + pos]) >> 4);
+                if (cs0 + off + nx >= len)
+                    break; // k6_frame has already failed the frame if records are missing
+                if (idx >= wlo)
+                    s_pos[wave][idx - wlo] = static_cast<uint16_t>(off + pos);
+                pos = nx;
+                idx++;
             }
         }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+
+        const uint32_t pair0 = wlo >> 1;
+        const uint32_t ntask = 4u * (((whi + 1u) >> 1) - pair0);
+        for (uint32_t t = lane; t < ntask; t += 64u) {
+            const uint32_t q = t >> 2, qt = t & 3u;
+            const uint32_t ra = 2u * (pair0 + q), rb = ra + 1u; // even-column and odd-column record
+            const bool hasA = ra >= wlo && ra < whi;
+            const bool hasB = rb >= wlo && rb < whi;
+            uint32_t va[4] = {0, 0, 0, 0}, vb[4] = {0, 0, 0, 0};
+            if (hasA) {
+                const uint32_t ro = s_pos[wave][ra - wlo];
+                const uint32_t b0 = bytes[ro], b1 = bytes[ro + 1u];
+                const uint32_t hb = b0 >> 4, ref = ((b0 & 15u) << 8) | b1; // RawData_Legacy.cpp:372-375
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; j++)
+                    va[j] = field6(words, ro + 2u, hb <= 10u ? hb : 16u, 4u * qt + j) + ref;
+            }
+            if (hasB) {
+                const uint32_t ro = s_pos[wave][rb - wlo];
+                const uint32_t b0 = bytes[ro], b1 = bytes[ro + 1u];
+                const uint32_t hb = b0 >> 4, ref = ((b0 & 15u) << 8) | b1;
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; j++)
+                    vb[j] = field6(words, ro + 2u, hb <= 10u ? hb : 16u, 4u * qt + j) + ref;
+            }
+            const uint32_t y = ra / rpr;
+            const uint32_t x = ((ra - y * rpr) >> 1) * 32u + 8u * qt; // RawData_Legacy.cpp:479-486
+            uint16_t *row = P->out + static_cast<size_t>(y) * static_cast<size_t>(width);
+            if (hasA && hasB && fast && x + 8u <= width) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; j++) // uint16 wrap; even column from A, odd column from B
+                    o[j] = (va[j] & 0xffffu) | (vb[j] << 16);
+                __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(row + x));
+            } else {
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; j++) {
+                    if (hasA && x + 2u * j < width)
+                        row[x + 2u * j] = static_cast<uint16_t>(va[j]);
+                    if (hasB && x + 2u * j + 1u < width)
+                        row[x + 2u * j + 1u] = static_cast<uint16_t>(vb[j]);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier(); // the list is rewritten by the next round
     }
 }
 

@@ -157,3 +157,23 @@ def test_side_streams_at_odd_offsets(gpu_ctx, pads):
         items.append((7, w, h, buf))
         expect.append((ret, out))
     _check(gpu_ctx, items, expect)
+
+
+def test_flat_frames_densest_chains(gpu_ctx):
+    # constant images: every legacy record is 2 bytes (512 records per KiB chunk -> k6_rows lists its
+    # 8-chunk window in several rounds), every type-7 block is 0 bytes (empty payload spans) and the
+    # side streams are runs of 2-byte records
+    items, expect = [], []
+    for (w, h, val) in ((4096, 64, 0), (1000, 37, 4095), (2048, 16, 65535)):
+        img = np.full((h, w), val, np.uint16)
+        b6 = L.encode6(img)
+        ret, out = L.oracle_decode6(b6, w, h)
+        assert ret == w * h and np.array_equal(out, img)
+        items.append((6, w, h, b6))
+        expect.append((ret, out))
+        b7 = L.encode7(img)
+        ret, out = L.oracle_decode7(b7, w, h)
+        assert ret == w * h and np.array_equal(out, img)
+        items.append((7, w, h, b7))
+        expect.append((ret, out))
+    _check(gpu_ctx, items, expect)
