@@ -5,6 +5,7 @@
 // positional reads, one index built up front, batched GPU decode.
 #include <motioncam/Decoder.hpp>
 #include <motioncam/RawData.hpp>
+#include <motioncam/mcraw_container.h>
 
 #include "mcraw_hip.h"
 
@@ -16,6 +17,8 @@
 namespace motioncam {
 
 namespace {
+
+using namespace container;
 
 constexpr int kTypeLegacy = MCRAW_TYPE_LEGACY; // frame JSON "compressionType" (lib/Decoder.cpp:20-21)
 constexpr int kTypeBlock = MCRAW_TYPE_BLOCK;
@@ -89,22 +92,22 @@ struct FrameSpan {
     uint32_t jsonSize = 0;
 };
 
-bool loadAudioChunkAt(const FileReader &r, const BufferOffset &o, AudioChunk &out)
+bool loadAudioChunkAt(const FileReader &r, const Locator &o, AudioChunk &out)
 {
-    Item item{};
-    if (!r.tryReadAt(o.offset, &item, sizeof(item)))
+    Chunk item{};
+    if (!r.tryReadAt(o.position, &item, sizeof(item)))
         return false;
-    if (item.type != Type::AUDIO_DATA)
+    if (item.kind != Kind::PCM)
         throw IOException("Invalid audio data");
-    std::vector<int16_t> samples((static_cast<size_t>(item.size) + 1) / 2);
-    r.readAt(o.offset + static_cast<int64_t>(sizeof(Item)), samples.data(), item.size);
+    std::vector<int16_t> samples((static_cast<size_t>(item.bytes) + 1) / 2);
+    r.readAt(o.position + static_cast<int64_t>(sizeof(Chunk)), samples.data(), item.bytes);
     // newer files follow the samples with their capture time; older ones do not
     Timestamp ts = -1;
-    const int64_t next = o.offset + static_cast<int64_t>(sizeof(Item)) + item.size;
-    Item meta{};
+    const int64_t next = o.position + static_cast<int64_t>(sizeof(Chunk)) + item.bytes;
+    Chunk meta{};
     r.readAt(next, &meta, sizeof(meta));
-    if (meta.type == Type::AUDIO_DATA_METADATA)
-        ts = readPod<AudioMetadata>(r, next + static_cast<int64_t>(sizeof(Item))).timestampNs;
+    if (meta.kind == Kind::PCM_TIME)
+        ts = readPod<PcmTime>(r, next + static_cast<int64_t>(sizeof(Chunk))).timeNs;
     out = std::make_pair(ts, std::move(samples));
     return true;
 }
@@ -118,10 +121,10 @@ struct Decoder::Impl {
     nlohmann::json metadata;
     std::vector<Timestamp> frames;               // ascending
     std::map<Timestamp, int64_t> frameOffsets;   // timestamp -> offset of its BUFFER item
-    std::vector<BufferOffset> audioOffsets;
+    std::vector<Locator> audioOffsets;
 
     struct Loader : AudioChunkLoader {
-        Loader(const FileReader &r, const std::vector<BufferOffset> &o) : reader(r), offsets(o) {}
+        Loader(const FileReader &r, const std::vector<Locator> &o) : reader(r), offsets(o) {}
         bool next(AudioChunk &output) override
         {
             if (index >= offsets.size() || !loadAudioChunkAt(reader, offsets[index], output))
@@ -130,7 +133,7 @@ struct Decoder::Impl {
             return true;
         }
         const FileReader &reader;
-        const std::vector<BufferOffset> &offsets;
+        const std::vector<Locator> &offsets;
         size_t index = 0;
     };
     std::unique_ptr<Loader> loader;
@@ -157,63 +160,63 @@ void Decoder::Impl::open()
     if (!reader.ok())
         throw IOException("Invalid file");
 
-    const Header header = readPod<Header>(reader, 0);
-    if (header.version != CONTAINER_VERSION)
+    const FileMagic header = readPod<FileMagic>(reader, 0);
+    if (header.version != kVersion)
         throw IOException("Invalid container version");
-    if (std::memcmp(header.ident, CONTAINER_ID, sizeof(CONTAINER_ID)) != 0)
+    if (std::memcmp(header.magic, kMagic, sizeof(kMagic)) != 0)
         throw IOException("Invalid header id");
 
     // camera metadata follows the header
-    const Item camera = readPod<Item>(reader, sizeof(Header));
-    if (camera.type != Type::METADATA)
+    const Chunk camera = readPod<Chunk>(reader, sizeof(FileMagic));
+    if (camera.kind != Kind::JSON)
         throw IOException("Invalid camera metadata");
-    metadata = readJson(reader, sizeof(Header) + sizeof(Item), camera.size);
+    metadata = readJson(reader, sizeof(FileMagic) + sizeof(Chunk), camera.bytes);
 
     // the frame index hangs off the last 24 bytes of the file
     const int64_t fileSize = reader.size();
-    const int64_t tail = fileSize - static_cast<int64_t>(sizeof(Item) + sizeof(BufferIndex));
-    Item indexItem{};
+    const int64_t tail = fileSize - static_cast<int64_t>(sizeof(Chunk) + sizeof(FrameTable));
+    Chunk indexItem{};
     if (tail < 0 || !reader.tryReadAt(tail, &indexItem, sizeof(indexItem)))
         throw IOException("Failed to get end chunk");
-    if (indexItem.type != Type::BUFFER_INDEX)
+    if (indexItem.kind != Kind::FRAME_TABLE)
         throw IOException("Invalid file");
-    const BufferIndex index = readPod<BufferIndex>(reader, tail + static_cast<int64_t>(sizeof(Item)));
-    if (static_cast<uint32_t>(index.magicNumber) != INDEX_MAGIC_NUMBER)
+    const FrameTable index = readPod<FrameTable>(reader, tail + static_cast<int64_t>(sizeof(Chunk)));
+    if (static_cast<uint32_t>(index.magic) != kFrameTableMagic)
         throw IOException("Corrupted file");
-    if (index.numOffsets < 0)
+    if (index.rows < 0)
         throw IOException("Invalid index");
 
-    std::vector<BufferOffset> offsets(static_cast<size_t>(index.numOffsets));
+    std::vector<Locator> offsets(static_cast<size_t>(index.rows));
     if (!offsets.empty())
-        reader.readAt(index.indexDataOffset, offsets.data(), offsets.size() * sizeof(BufferOffset));
+        reader.readAt(index.rowsPosition, offsets.data(), offsets.size() * sizeof(Locator));
     std::stable_sort(offsets.begin(), offsets.end(),
-                     [](const BufferOffset &a, const BufferOffset &b) { return a.timestamp < b.timestamp; });
-    for (const BufferOffset &o : offsets) {
-        frames.push_back(o.timestamp);
-        frameOffsets.insert({o.timestamp, o.offset});
+                     [](const Locator &a, const Locator &b) { return a.time < b.time; });
+    for (const Locator &o : offsets) {
+        frames.push_back(o.time);
+        frameOffsets.insert({o.time, o.position});
     }
 
     // The audio index, when present, is found by hopping over the items that follow the
     // last (by timestamp) frame.
     if (!offsets.empty()) {
-        int64_t pos = offsets.back().offset;
+        int64_t pos = offsets.back().position;
         for (;;) {
-            Item item{};
+            Chunk item{};
             if (!reader.tryReadAt(pos, &item, sizeof(item)))
                 break;
-            pos += static_cast<int64_t>(sizeof(Item));
-            if (item.type == Type::BUFFER || item.type == Type::METADATA || item.type == Type::AUDIO_DATA ||
-                item.type == Type::AUDIO_DATA_METADATA) {
-                pos += item.size;
-            } else if (item.type == Type::AUDIO_INDEX) {
-                const AudioIndex ai = readPod<AudioIndex>(reader, pos);
-                pos += static_cast<int64_t>(sizeof(AudioIndex));
-                if (ai.numOffsets < 0)
+            pos += static_cast<int64_t>(sizeof(Chunk));
+            if (item.kind == Kind::FRAME || item.kind == Kind::JSON || item.kind == Kind::PCM ||
+                item.kind == Kind::PCM_TIME) {
+                pos += item.bytes;
+            } else if (item.kind == Kind::PCM_TABLE) {
+                const PcmTable ai = readPod<PcmTable>(reader, pos);
+                pos += static_cast<int64_t>(sizeof(PcmTable));
+                if (ai.rows < 0)
                     break;
-                audioOffsets.resize(static_cast<size_t>(ai.numOffsets));
+                audioOffsets.resize(static_cast<size_t>(ai.rows));
                 if (!audioOffsets.empty())
-                    reader.readAt(pos, audioOffsets.data(), audioOffsets.size() * sizeof(BufferOffset));
-                pos += static_cast<int64_t>(audioOffsets.size() * sizeof(BufferOffset));
+                    reader.readAt(pos, audioOffsets.data(), audioOffsets.size() * sizeof(Locator));
+                pos += static_cast<int64_t>(audioOffsets.size() * sizeof(Locator));
             } else {
                 break;
             }
@@ -228,19 +231,19 @@ FrameSpan Decoder::Impl::locate(Timestamp ts) const
     if (it == frameOffsets.end())
         throw IOException("Frame not found (timestamp: " + std::to_string(ts) + ")");
     FrameSpan s;
-    Item buffer{};
+    Chunk buffer{};
     if (!reader.tryReadAt(it->second, &buffer, sizeof(buffer)))
         throw IOException("Invalid offset");
-    if (buffer.type != Type::BUFFER)
+    if (buffer.kind != Kind::FRAME)
         throw IOException("Invalid buffer type");
-    s.payload = it->second + static_cast<int64_t>(sizeof(Item));
-    s.payloadSize = buffer.size;
-    const int64_t metaPos = s.payload + buffer.size;
-    const Item meta = readPod<Item>(reader, metaPos);
-    if (meta.type != Type::METADATA)
+    s.payload = it->second + static_cast<int64_t>(sizeof(Chunk));
+    s.payloadSize = buffer.bytes;
+    const int64_t metaPos = s.payload + buffer.bytes;
+    const Chunk meta = readPod<Chunk>(reader, metaPos);
+    if (meta.kind != Kind::JSON)
         throw IOException("Invalid metadata");
-    s.json = metaPos + static_cast<int64_t>(sizeof(Item));
-    s.jsonSize = meta.size;
+    s.json = metaPos + static_cast<int64_t>(sizeof(Chunk));
+    s.jsonSize = meta.bytes;
     return s;
 }
 
@@ -270,7 +273,7 @@ int Decoder::numAudioChannels() const { return mImpl->metadata["extraData"]["aud
 
 void Decoder::loadAudio(std::vector<AudioChunk> &outAudioChunks)
 {
-    for (const BufferOffset &o : mImpl->audioOffsets) {
+    for (const Locator &o : mImpl->audioOffsets) {
         AudioChunk chunk;
         if (loadAudioChunkAt(mImpl->reader, o, chunk))
             outAudioChunks.emplace_back(std::move(chunk));
