@@ -47,3 +47,55 @@ def test_reference_example_compiles_unchanged(host_lib):
     und = subprocess.run(["nm", "-DC", "--undefined-only", os.path.join(ROOT, "oracle", "_ref", "example_dropin")],
                          capture_output=True, text=True, check=True).stdout
     assert "mcraw_decode7" in und  # its frames go through the HIP library, not a CPU codec
+
+
+@pytest.fixture(scope="module")
+def probe(host_lib, tmp_path_factory):
+    d = tmp_path_factory.mktemp("probe")
+    exe = str(d / "facade_probe")
+    host = os.path.join(ROOT, "motioncam_decoder_amd", "host")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I" + os.path.join(host, "include"), "-I" + os.path.join(host, "thirdparty"),
+                    "-o", exe, os.path.join(ROOT, "tests", "cpp", "facade_probe.cpp"), "-L" + LIB, "-lmotioncam_decoder",
+                    "-lmcraw_hip", "-Wl,-rpath," + LIB], check=True)
+    return exe, d
+
+
+def _probe(exe, *args):
+    r = subprocess.run([exe] + list(args), capture_output=True, text=True, timeout=120)
+    return r.returncode, r.stdout.splitlines()
+
+
+def test_container_reader_matches_reference_contract(probe):
+    import numpy as np
+    import _libs as L
+    exe, d = probe
+    img = L.natural_image_np(128, 8, 12, 12.0, 1)
+    frames = [(3000, 7, 128, 8, L.encode7(img)), (1000, 6, 128, 8, L.encode6(img)), (2000, 7, 128, 8, L.encode7(img))]
+    audio = [(111, np.arange(100, dtype=np.int16)), (None, np.full(60, 2, np.int16))]
+    good = L.write_mcraw(str(d / "good.mcraw"), frames, audio, audio_rate=44100, audio_channels=1)
+    rc, out = _probe(exe, good, "decode")
+    assert rc == 0
+    assert out[0] == "frames 1000 2000 3000"                       # sorted by timestamp (lib/Decoder.cpp:266-279)
+    assert out[1] == "camera rggb 44100 1"
+    assert out[2] == "audio 111 100 4950" and out[3] == "audio -1 60 120"   # timestamp -1 without metadata (:62-70)
+    assert out[4] == "loader 2"
+    assert out[5] == "missing: Frame not found (timestamp: 123456789)"      # :186
+    import torch
+    if not torch.cuda.is_available():
+        assert out[6] == "decode: Failed to uncompress legacy frame"        # no GPU: fails, never decodes on the CPU
+    else:
+        assert out[6] == "decoded 2048 128x8"
+
+    raw = open(good, "rb").read()
+    cases = {"missing.mcraw": (None, "error: Failed to open "),
+             "version.mcraw": (raw[:7] + bytes([2]) + raw[8:], "error: Invalid container version"),
+             "ident.mcraw": (b"NOTION " + raw[7:], "error: Invalid header id"),
+             "tail.mcraw": (raw[:-24] + bytes([9, 0, 0, 0]) + raw[-20:], "error: Invalid file"),
+             "magic.mcraw": (raw[:-16] + bytes(4) + raw[-12:], "error: Corrupted file"),
+             "short.mcraw": (raw[:20], "error: ")}
+    for name, (content, want) in cases.items():
+        p = str(d / name)
+        if content is not None:
+            open(p, "wb").write(content)
+        rc, out = _probe(exe, p)
+        assert rc == 1 and out and out[0].startswith(want), (name, out)
