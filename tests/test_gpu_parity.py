@@ -177,3 +177,21 @@ def test_flat_frames_densest_chains(gpu_ctx):
         items.append((7, w, h, b7))
         expect.append((ret, out))
     _check(gpu_ctx, items, expect)
+
+
+def test_many_small_frames_one_batch(gpu_ctx):
+    # 1200 frames of assorted small geometries, both encodings interleaved: exercises the batch
+    # indexing (uniform-stride workspace sized by the largest frame, work lists, status mapping)
+    rng = np.random.default_rng(1200)
+    shapes = [(64, 4), (128, 8), (192, 12), (100, 8), (77, 4), (256, 16), (320, 20), (33, 3)]
+    pool = []
+    for i, (w, h) in enumerate(shapes):
+        img = rng.integers(0, 1 << int(rng.integers(1, 15)), size=(h, w), dtype=np.uint16)
+        pool.append((7, w, h, L.encode7(img), img))
+        pool.append((6, w, h, L.encode6(img), img))
+    items, expect = [], []
+    for i in range(1200):
+        t, w, h, buf, img = pool[int(rng.integers(0, len(pool)))]
+        items.append((t, w, h, buf))
+        expect.append((w * h, img))
+    _check(gpu_ctx, items, expect)
