@@ -45,7 +45,8 @@ class Frame(C.Structure):
 
 
 def lib_path():
-    return os.path.join(_PKG, "lib", "libmcraw_hip.so")
+    # MCRAW_LIB_PATH: load another build of the same ABI (A/B timing of kernel variants on one box)
+    return os.environ.get("MCRAW_LIB_PATH") or os.path.join(_PKG, "lib", "libmcraw_hip.so")
 
 
 _lib = None

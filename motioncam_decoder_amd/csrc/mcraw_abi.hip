@@ -347,6 +347,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         W.list_maps = reinterpret_cast<uint4 *>(dev + w_lmaps);
         W.list_recs = reinterpret_cast<uint4 *>(dev + w_lrecs);
         W.counters = reinterpret_cast<uint32_t *>(dev + L.counters);
+        W.list_cap = static_cast<uint32_t>(2 * static_cast<size_t>(n7) * nch);
         W.bits = dev + w_bits;
         W.refs = reinterpret_cast<uint16_t *>(dev + w_refs);
         W.grp_off = reinterpret_cast<uint32_t *>(dev + w_grp);

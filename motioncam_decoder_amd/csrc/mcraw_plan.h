@@ -55,7 +55,8 @@ struct Work7 {
     uint4 *sinfo;        // [n7][2]           per stream: first record offset, chunks to map, extent hinted, -
     uint4 *list_maps;    // work list of k7_maps:    (stream, first of 3 chunks, its byte offset, chunks of the stream)
     uint4 *list_recs;    // work list of k7_records: (stream, chunk, its byte offset, entry phase | first record << 8)
-    uint32_t *counters;  // [2] lengths of the two lists (zeroed by the table upload)
+    uint32_t *counters;  // [0] k7_maps items, [1] sparse / [2] dense k7_records items (zeroed by the table upload)
+    uint32_t list_cap;   // capacity of list_recs (dense items are filled in from the back)
     uint8_t *bits;       // [n7][Rmax*64]  decoded `bits` stream  (:557)
     uint16_t *refs;      // [n7][Rmax*64]  decoded `refs` stream  (:560)
     uint32_t *grp_off;   // [n7][Rmax*ITEM_SPLIT+1] payload byte offset of every decode item (:562 + prefix of LEN)

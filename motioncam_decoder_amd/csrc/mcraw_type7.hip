@@ -142,6 +142,7 @@ constexpr uint32_t DEAD7 = 127u; // phase value: the chain has ended (record pas
 
 constexpr uint32_t MAPS_CH = 3; // chunks per 256-thread workgroup: 3 x 65 phases = 195 lanes
 constexpr uint32_t NODEAD = 0xFFFFu;
+constexpr uint32_t DENSE_RECORDS = 96; // k7_records lists chunks with more records by pointer doubling
 
 // Where the record whose header sits at staged offset `rel` ends (= where the next one
 // starts), or NODEAD when it would cross `len` (RawData.cpp:419-420 skips such a block).
@@ -316,13 +317,34 @@ __global__ __launch_bounds__(256) void k7_follow(const Work7 W)
             atomicOr(status, (p != DEAD7 && hinted) ? E_LAYOUT : MCRAW_E_TRUNCATED);
         return;
     }
-    // work list of k7_records: the chunks [0, creal) of this stream
-    if (tid == 0)
-        s_state[3] = atomicAdd(W.counters + 1, creal);
+    // Work lists of k7_records: the chunks [0, creal) of this stream.  Sparse chunks fill the list
+    // from the front, dense ones (runs of tiny records, listed by pointer doubling in a kernel of
+    // their own) from the back; the order inside either part does not matter.
+    if (tid < 3u)
+        s_state[tid] = 0; // [0] dense chunks of this stream, [1] sparse slots handed out, [2] dense slots handed out
     __syncthreads();
-    uint4 *dst = W.list_recs + s_state[3];
-    for (uint32_t i = tid; i < creal; i += 256u) // stream, chunk, its byte offset, its entry (phase | first record << 8)
-        dst[i] = make_uint4(fs, i, si.x + i * CH7, centry[i]);
+    for (uint32_t i = tid; i < creal; i += 256u) {
+        const uint32_t nexti = i + 1u < creal ? min(R, centry[i + 1u] >> 8) : R;
+        if (nexti - min(nexti, centry[i] >> 8) > DENSE_RECORDS)
+            atomicAdd(&s_state[0], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t nd = s_state[0];
+        s_entry[0] = atomicAdd(W.counters + 1, creal - nd);
+        s_entry[1] = nd ? atomicAdd(W.counters + 2, nd) : 0u;
+    }
+    __syncthreads();
+    const uint32_t baseS = s_entry[0], baseD = s_entry[1];
+    for (uint32_t i = tid; i < creal; i += 256u) { // stream, records in the chunk, its byte offset, entry (phase | first record << 8)
+        const uint32_t e = centry[i];
+        const uint32_t nexti = i + 1u < creal ? min(R, centry[i + 1u] >> 8) : R;
+        const uint32_t nrec = nexti - min(nexti, e >> 8);
+        const bool dense = nrec > DENSE_RECORDS;
+        const uint32_t slot = atomicAdd(&s_state[dense ? 2 : 1], 1u);
+        const uint32_t at = dense ? W.list_cap - 1u - (baseD + slot) : baseS + slot;
+        W.list_recs[at] = make_uint4(fs, nrec, si.x + i * CH7, e);
+    }
 }
 
 constexpr int REC_STAGE = CH7 + 130 + 8 + 16; // records starting in the chunk may run 130 bytes past it (+ read slack)
@@ -339,25 +361,30 @@ __device__ __forceinline__ uint32_t swz_xor(uint32_t v)
 // 2-byte LDS reads through the successor table), parses their headers in parallel, then
 // unpacks EIGHT records per pass: lane = (record, k) owns samples 8k..8k+7 exactly like a
 // payload lane (DecodeBlock on the record, RawData.cpp:489; + reference, :491-492).
-template <int ABL>
+template <int ABL, bool DENSE>
 __global__ __launch_bounds__(64) void k7_records(const Work7 W)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_b[REC_BYTES];
     __shared__ uint32_t s_hdr[REC_MAX + 8]; // per record: payload offset | hbits << 12 | reference << 16
+    __shared__ __attribute__((aligned(16))) uint16_t s_J[CH7 / 2 + 8]; // successor table of the chunk's candidates
+    __shared__ __attribute__((aligned(8))) uint8_t s_M[CH7 / 2 + 8];   // chain marks
     __shared__ uint4 s_tab[72];
 
     const uint32_t lane = threadIdx.x;
     s_tab[lane] = reinterpret_cast<const uint4 *>(c_tab7)[lane];
     if (lane < 8u)
         s_tab[64u + lane] = reinterpret_cast<const uint4 *>(c_tab7)[64u + lane];
-    const uint32_t nwork = W.counters[1];
+    const uint32_t nwork = W.counters[DENSE ? 2 : 1];
+    // sparse chunks are listed from the front of the work list, dense ones from its back
+    const uint4 *list = DENSE ? W.list_recs + (W.list_cap - 1u) : W.list_recs;
+    constexpr int STEP = DENSE ? -1 : 1;
     uint4 nextw = make_uint4(0, 0, 0, 0);
     if (blockIdx.x < nwork)
-        nextw = W.list_recs[blockIdx.x];
+        nextw = list[STEP * static_cast<int>(blockIdx.x)];
     for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
     const uint4 we = nextw;
     if (wi + gridDim.x < nwork) // descriptor of the next work item rides behind this one
-        nextw = W.list_recs[wi + gridDim.x];
+        nextw = list[STEP * static_cast<int>(wi + gridDim.x)];
     const uint32_t fs = __builtin_amdgcn_readfirstlane(we.x);
     const uint32_t f = fs >> 1, s = fs & 1u;
     int32_t *status = W.status + f;
@@ -376,23 +403,93 @@ __global__ __launch_bounds__(64) void k7_records(const Work7 W)
             reinterpret_cast<uint4 *>(s_b)[lane + 64u * q] = ld_b128(rs, base16 + (lane + 64u * q) * 16u);
     __syncthreads();
 
-    // Walk the records that start in this chunk (every lane runs the same chain) and note
-    // payload offset, class and reference of each (RawData.cpp:106-110).  One walk only, so the
-    // headers are read straight from the staged bytes (no successor table as in k7_maps).
-    uint32_t rel = 2u * ph, n = 0;
-    while (rel < CH7 && i0 + n < R) {
-        const uint32_t ro = head + rel;
-        const uint32_t b0 = s_b[ro], b1 = s_b[ro + 1u];
-        const uint32_t nx = rel + 2u + len7_of(b0 >> 4);
-        if (abs + nx > len)
-            break; // cannot happen for a chunk k7_follow listed
-        if (lane == 0)
-            s_hdr[n] = (ro + 2u) | ((b0 >> 4) << 12) | ((((b0 & 15u) << 8) | b1) << 16);
-        rel = nx;
-        n++;
+    uint32_t n = 0;
+    if (!DENSE) {
+        // Sparse chunk: walk the chain (every lane runs the same walk) and note payload offset,
+        // class and reference of each record (RawData.cpp:106-110).
+        uint32_t rel = 2u * ph;
+        while (ABL != 3 && rel < CH7 && i0 + n < R) {
+            const uint32_t ro = head + rel;
+            const uint32_t b0 = s_b[ro], b1 = s_b[ro + 1u];
+            const uint32_t nx = rel + 2u + len7_of(b0 >> 4);
+            if (abs + nx > len)
+                break; // cannot happen for a chunk k7_follow listed
+            if (lane == 0)
+                s_hdr[n] = (ro + 2u) | ((b0 >> 4) << 12) | ((((b0 & 15u) << 8) | b1) << 16);
+            rel = nx;
+            n++;
+        }
+        if (ABL == 2)
+            n = 0;
+    } else {
+    // Dense chunk (runs of 2-byte records: up to 512 per KiB).  Which of the chunk's 512 even offsets start a record of the true chain?  A serial walk
+    // costs ~45 scalar instructions per record on one lane; instead the chain is marked by
+    // POINTER DOUBLING over all candidates at once: J1[p] = where the record at p ends;
+    // level l marks J_{2^l}(q) for every marked q (marks then cover distance < 2^(l+1) from the
+    // entry) and squares the table; ~6 levels for a typical chunk, 10 at most.
+    constexpr uint32_t NP = CH7 / 2; // candidates; index NP = "beyond this chunk"
+    const uint32_t p0 = lane * 8u;   // this lane owns candidates p0 .. p0+7
+    uint32_t jn[8];
+#pragma unroll
+    for (uint32_t t = 0; t < 8u; t++) {
+        const uint32_t rel = 2u * (p0 + t);
+        const uint32_t nx = rel + 2u + len7_of(static_cast<uint32_t>(s_b[head + rel]) >> 4);
+        jn[t] = (abs + nx > len || nx >= CH7) ? NP : nx >> 1; // a record crossing `len` ends the chain
     }
-    if (ABL == 2)
+    *reinterpret_cast<uint4 *>(&s_J[p0]) = make_uint4(jn[0] | (jn[1] << 16), jn[2] | (jn[3] << 16), jn[4] | (jn[5] << 16), jn[6] | (jn[7] << 16));
+    *reinterpret_cast<uint2 *>(&s_M[p0]) = make_uint2(0u, 0u);
+    if (lane == 0)
+        s_J[NP] = static_cast<uint16_t>(NP);
+    __syncthreads();
+    if (lane == 0 && ABL != 3)
+        s_M[ph] = 1; // entry phase = candidate index (offset 2 * ph)
+    __syncthreads();
+    uint2 m = *reinterpret_cast<const uint2 *>(&s_M[p0]);
+    for (uint32_t level = 0; level < 10u; level++) {
+#pragma unroll
+        for (uint32_t t = 0; t < 8u; t++) {
+            const uint32_t mk = ((t < 4u ? m.x : m.y) >> (8u * (t & 3u))) & 1u;
+            s_M[mk ? jn[t] : NP + 1u] = 1; // branch-free: unmarked candidates hit a dummy slot (NP, NP+1 are never read as marks)
+        }
+        __syncthreads();
+        const uint2 m2 = *reinterpret_cast<const uint2 *>(&s_M[p0]);
+        const bool grew = __any((m2.x != m.x) || (m2.y != m.y));
+        m = m2;
+        if (!grew)
+            break;
+        uint32_t sq[8];
+#pragma unroll
+        for (uint32_t t = 0; t < 8u; t++)
+            sq[t] = s_J[jn[t]];
+        __syncthreads();
+#pragma unroll
+        for (uint32_t t = 0; t < 8u; t++)
+            jn[t] = sq[t];
+        *reinterpret_cast<uint4 *>(&s_J[p0]) = make_uint4(jn[0] | (jn[1] << 16), jn[2] | (jn[3] << 16), jn[4] | (jn[5] << 16), jn[6] | (jn[7] << 16));
+        __syncthreads();
+    }
+    // rank of every marked candidate = its record index inside the chunk (candidates are in stream order)
+    const uint32_t mine = static_cast<uint32_t>(__popc(m.x) + __popc(m.y));
+    uint32_t ntot;
+    const uint32_t rank0 = wave_excl_scan(mine, lane, &ntot);
+    n = min(ntot, R - i0);
+    if (ABL == 2 || ABL == 3)
         n = 0;
+    // payload offset, class and reference of each record (RawData.cpp:106-110)
+    uint32_t rk = rank0;
+#pragma unroll
+    for (uint32_t t = 0; t < 8u; t++) {
+        const uint32_t mk = ((t < 4u ? m.x : m.y) >> (8u * (t & 3u))) & 1u;
+        if (mk) {
+            if (rk < n) {
+                const uint32_t ro = head + 2u * (p0 + t);
+                const uint32_t b0 = s_b[ro], b1 = s_b[ro + 1u];
+                s_hdr[rk] = (ro + 2u) | ((b0 >> 4) << 12) | ((((b0 & 15u) << 8) | b1) << 16);
+            }
+            rk++;
+        }
+    }
+    }
     if (lane < 8u)
         s_hdr[n + lane] = 0u; // padding: idle lanes of the last pass unpack "class 0"
     __syncthreads();
@@ -707,7 +804,7 @@ static uint32_t persistent_grid(int which)
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
             cus = p.multiProcessorCount;
         hipError_t e = which == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k7_maps, 256, 0)
-                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k7_records<0>, 64, 0);
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k7_records<0, false>, 64, 0);
         if (e != hipSuccess || per_cu <= 0)
             per_cu = which == 0 ? 8 : 16;
         g[which] = static_cast<uint32_t>(cus * per_cu);
@@ -730,12 +827,17 @@ void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st)
                 const char *e = std::getenv("MCRAW_ABLATE_REC");
                 return e ? std::atoi(e) : 0;
             }();
+            const dim3 g(persistent_grid(1));
             if (abl == 1)
-                hipLaunchKernelGGL(k7_records<1>, dim3(persistent_grid(1)), dim3(64), 0, st, W);
+                hipLaunchKernelGGL((k7_records<1, false>), g, dim3(64), 0, st, W);
             else if (abl == 2)
-                hipLaunchKernelGGL(k7_records<2>, dim3(persistent_grid(1)), dim3(64), 0, st, W);
+                hipLaunchKernelGGL((k7_records<2, false>), g, dim3(64), 0, st, W);
+            else if (abl == 3)
+                hipLaunchKernelGGL((k7_records<3, false>), g, dim3(64), 0, st, W);
             else
-                hipLaunchKernelGGL(k7_records<0>, dim3(persistent_grid(1)), dim3(64), 0, st, W);
+                hipLaunchKernelGGL((k7_records<0, false>), g, dim3(64), 0, st, W);
+            // chunks made of runs of tiny records (flat image regions): usually none
+            hipLaunchKernelGGL((k7_records<0, true>), dim3(2048), dim3(64), 0, st, W);
         }
         break;
     case MCRAW_K7_SCAN:
