@@ -245,6 +245,10 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
             p.padded = static_cast<uint32_t>(up(f.width, 32));
             p.recs_per_row = 2 * p.padded / 32;
             p.nrec = p.recs_per_row * static_cast<uint32_t>(f.height);
+            if (p.nrec >= (1u << 24)) { // chunk entries carry the first record index in 24 bits
+                status[i] = MCRAW_E_ARGS;
+                continue;
+            }
             p.nchunks = static_cast<uint32_t>((f.len + CHUNK6 - 1) / CHUNK6);
             p.nsuper = (p.nchunks + SUPER6 - 1) / SUPER6;
             p.fast_store = fast ? 1u : 0u;

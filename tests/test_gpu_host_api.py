@@ -44,3 +44,55 @@ def test_host_memory_batch_many_sub_batches(gpu_ctx):
     assert status == [0] * n and written == [w * h] * n
     for i in range(n):
         assert np.array_equal(outs[i], imgs[i % 4]), i
+
+
+def test_concurrent_host_threads(gpu_ctx, golden):
+    # SURVEY 8b "threading": the ABI is callable from several host threads at once -- each with its
+    # own context (one per GPU/stream in production), and several sharing the default context of the
+    # five-argument entry points.
+    import threading
+    lib = M.load()
+    names = sorted(golden)
+    errors = []
+
+    def own_context(tid):
+        try:
+            ctx = M.Context(0)
+            import torch
+            dev = torch.device("cuda:0")
+            for rep in range(3):
+                for n in names[tid::4]:
+                    c = golden[n]
+                    ti = torch.from_numpy(np.ascontiguousarray(c["buf"])).to(dev)
+                    to = torch.zeros(c["w"] * c["h"] * 2, dtype=torch.uint8, device=dev)
+                    torch.cuda.synchronize()
+                    fr = M.Context.make_frames([(ti.data_ptr(), ti.numel(), c["w"], c["h"], c["type"], to.data_ptr(), c["w"] * c["h"])])
+                    written, status = ctx.decode_batch(fr)
+                    got = to.cpu().numpy().view(np.uint16).reshape(c["h"], c["w"])
+                    if status != [0] or written != [c["ret"]] or not np.array_equal(got, c["out"]):
+                        errors.append(("ctx", tid, n))
+            ctx.close()
+        except Exception as e:  # pragma: no cover
+            errors.append(("ctx", tid, repr(e)))
+
+    def default_context(tid):
+        try:
+            for rep in range(3):
+                for n in names[tid::4]:
+                    c = golden[n]
+                    out = np.zeros((c["h"], c["w"]), np.uint16)
+                    buf = np.ascontiguousarray(c["buf"])
+                    fn = lib.mcraw_decode7 if c["type"] == 7 else lib.mcraw_decode6
+                    ret = fn(out.ctypes.data, c["w"], c["h"], buf.ctypes.data, buf.size)
+                    if ret != c["ret"] or not np.array_equal(out, c["out"]):
+                        errors.append(("default", tid, n))
+        except Exception as e:  # pragma: no cover
+            errors.append(("default", tid, repr(e)))
+
+    threads = [threading.Thread(target=own_context, args=(t,)) for t in range(4)]
+    threads += [threading.Thread(target=default_context, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors[:5]
