@@ -12,9 +12,9 @@
 //   k6_super   compose 64 chunk maps into one super-chunk map
 //   k6_frame   follow the true phase over the super-chunks   -> entry of every super-chunk
 //   k6_chunks  follow it over a super-chunk's 64 chunks      -> entry of every chunk
-//   k6_rows    per chunk: list its records from the true entry, then unpack them
-//              (MSB-first bitstreams, RawData_Legacy.cpp:38-370), add the references,
-//              interleave even/odd columns (:483-486) and crop the padded row (:490)
+//   k6_rows    per 8 chunks: lanes list the records of one chunk each from its true entry, then
+//              all lanes unpack them (MSB-first bitstreams, RawData_Legacy.cpp:38-370), add the
+//              references, interleave even/odd columns (:483-486) and crop the padded row (:490)
 #include "mcraw_dev.h"
 
 #include "../../include/mcraw_hip.h"
@@ -28,7 +28,6 @@ __device__ __forceinline__ uint32_t len6_of(uint32_t b) { return b <= 10u ? 2u *
 
 // ------------------------------------------------------------------ k6_maps
 constexpr int MAP_CH_PER_WAVE = 3; // 3 x 17 phases = 51 of 64 lanes
-constexpr int MAP_CH_PER_WG = 4 * MAP_CH_PER_WAVE;
 
 __global__ __launch_bounds__(256) void k6_maps(const Plan6 *__restrict__ plans, const uint32_t *__restrict__ item_base,
                                                int nframes)
@@ -175,8 +174,6 @@ __global__ __launch_bounds__(64) void k6_chunks(const Plan6 *__restrict__ plans,
 }
 
 // ------------------------------------------------------------------ k6_rows
-constexpr int ROW_STAGE = CHUNK6 + 64; // a record may start at byte 1022 and run 34 bytes; +8 for the bit window
-constexpr int ROW_MAXREC = CHUNK6 / 2;
 
 // Residual k of a record: field k of an MSB-first bitstream of `sb`-bit fields starting at byte
 // `boff` of the staged bytes (sb = header nibble for <= 10, 16 for the big-endian raw form,

@@ -1,15 +1,17 @@
 // mcraw_type7.hip -- gfx950 kernels for the current MCRAW frame encoding
 // (compressionType 7).  Replaces motioncam::raw::Decode, lib/RawData.cpp:528-612.
 //
-//   k7_maps + k7_follow   side-stream chain resolve (RawData.cpp:463-498, the inline-header chain)
-//   k7_records            side-stream record decode (RawData.cpp:485-495) -> bits[], refs[], group lengths
-//   k7_scan   payload offsets             (RawData.cpp:562, 576-579: offset += LEN[bits])
-//   k7_tiles  tile unpack + reference add + Bayer interleave + crop
-//             (RawData.cpp:410-461, 112-408, 581-593, 598-608)   <- the roofline kernel
+//   k7_hdr, k7_maps, k7_follow   header checks + side-stream chain resolve
+//                                (RawData.cpp:500-524, 547-554; :463-498 the inline-header chain)
+//   k7_records (sparse / dense)  side-stream record decode (RawData.cpp:485-495)
+//                                -> bits[], refs[], byte length of every decode item
+//   k7_scan                      payload offsets (RawData.cpp:562, 576-579: offset += LEN[bits])
+//   k7_tiles                     tile unpack + reference add + Bayer interleave + crop
+//                                (RawData.cpp:410-461, 112-408, 581-593, 598-608)  <- the roofline kernel
 //
-// Integer bit-slicing on byte planes; no MFMA.  A "group" is the 64 payload
-// blocks (16 tiles of 64x4 px) described by one record of the bits stream; its
-// payload is one contiguous, 8-byte aligned span of <= 8 KiB.
+// Integer bit-slicing on byte planes; no MFMA.  A "group" is the 64 payload blocks (16 tiles of
+// 64x4 px) described by one record of the bits stream; a decode "item" is half of it (32 blocks,
+// 8 tiles): its payload is one contiguous, 8-byte aligned span of <= 4 KiB.
 #include <algorithm>
 #include <cstdlib>
 
