@@ -70,12 +70,12 @@ def build_host(force=False):
     inc = ["-I" + os.path.join(HOST, "include"), "-I" + os.path.join(HOST, "thirdparty"), "-I" + os.path.join(ROOT, "include")]
     if force or _newer(out, srcs + hdrs):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall"] + inc + ["-o", out] + srcs +
-             ["-L" + LIB, "-lmcraw_hip", "-Wl,-rpath,$ORIGIN"])
+             ["-L" + LIB, "-lmcraw_hip", "-lpthread", "-Wl,-rpath,$ORIGIN"])
     tool = os.path.join(LIB, "mcraw_export")
     tsrc = os.path.join(HOST, "mcraw_export.cpp")
     if os.path.exists(tsrc) and (force or _newer(tool, [tsrc, out])):
         _run(["g++", "-O2", "-std=c++17", "-Wall"] + inc + ["-o", tool, tsrc, "-L" + LIB, "-lmotioncam_decoder",
-             "-lmcraw_hip", "-Wl,-rpath,$ORIGIN"])
+             "-lmcraw_hip", "-lpthread", "-Wl,-rpath,$ORIGIN"])
     return out
 
 

@@ -10,7 +10,10 @@
 #include "mcraw_hip.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
+#include <future>
+#include <thread>
 #include <cstring>
 #include <unistd.h>
 
@@ -139,14 +142,16 @@ struct Decoder::Impl {
     std::unique_ptr<Loader> loader;
 
     // pinned staging reused across loadFrames() calls
-    uint8_t *pinIn = nullptr, *pinOut = nullptr;
-    size_t pinInCap = 0, pinOutCap = 0;
+    uint8_t *pinIn[2] = {nullptr, nullptr}, *pinOut[2] = {nullptr, nullptr};
+    size_t pinInCap[2] = {0, 0}, pinOutCap[2] = {0, 0};
     mcraw_ctx *ctx = nullptr;
 
     ~Impl()
     {
-        mcraw_host_free(pinIn);
-        mcraw_host_free(pinOut);
+        for (int s = 0; s < 2; s++) {
+            mcraw_host_free(pinIn[s]);
+            mcraw_host_free(pinOut[s]);
+        }
         if (ctx)
             mcraw_ctx_destroy(ctx);
     }
@@ -309,6 +314,28 @@ void Decoder::loadFrame(const Timestamp timestamp, std::vector<uint8_t> &outData
     }
 }
 
+// Run fn(i) for i in [0, n) on up to `threads` host threads (file reads and copies out of the
+// pinned staging are memory-bound and scale with a few threads).
+template <typename F> void parallelFor(size_t n, unsigned threads, F fn)
+{
+    if (n == 0)
+        return;
+    threads = static_cast<unsigned>(std::min<size_t>(std::max(1u, threads), n));
+    std::vector<std::future<void>> jobs;
+    std::atomic<size_t> next{0};
+    for (unsigned t = 0; t < threads; t++)
+        jobs.emplace_back(std::async(std::launch::async, [&]() {
+            for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1))
+                fn(i);
+        }));
+    for (auto &j : jobs)
+        j.get(); // rethrows the first exception of a worker
+}
+
+// Batched load: the frames are cut into chunks that fit two bounded pinned staging slots, and
+// three stages overlap -- chunk c+1 is read from the file (positional reads, several threads) while
+// chunk c is decoded on the GPU (one mcraw_decode_batch: H2D / kernels / D2H pipelined on the
+// context's streams) and chunk c-1 is copied out of pinned memory into the caller's vectors.
 void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<std::vector<uint8_t>> &outData,
                          std::vector<nlohmann::json> &outMetadata)
 {
@@ -321,10 +348,9 @@ void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<s
     if (!I.ctx && mcraw_ctx_create(-1, &I.ctx) != 0)
         throw IOException(std::string("GPU decode unavailable: ") + mcraw_last_error());
 
-    // pass 1: locate, parse the per-frame JSON, size the pinned staging
+    // locate every frame and parse its JSON
     std::vector<FrameSpan> spans(n);
     std::vector<mcraw_frame> frames(n);
-    size_t inBytes = 0, outBytes = 0;
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     for (size_t i = 0; i < n; i++) {
         spans[i] = I.locate(timestamps[i]);
@@ -337,14 +363,34 @@ void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<s
         if (width <= 0 || height <= 0)
             throw IOException("Failed to uncompress frame");
         mcraw_frame &f = frames[i];
+        f.in = nullptr;
+        f.out = nullptr;
         f.len = spans[i].payloadSize;
         f.width = width;
         f.height = height;
         f.type = type;
         f.reserved = 0;
         f.out_capacity = static_cast<size_t>(width) * static_cast<size_t>(height);
-        inBytes += up(f.len);
-        outBytes += up(f.out_capacity * 2);
+    }
+
+    // chunks: as many frames as fit the staging budget of one slot (at least one frame)
+    constexpr size_t kSlotBudget = 192ull << 20;
+    struct Chunk {
+        size_t first, count, inBytes, outBytes;
+    };
+    std::vector<Chunk> chunks;
+    for (size_t i = 0; i < n;) {
+        Chunk c{i, 0, 0, 0};
+        while (i < n) {
+            const size_t ib = up(frames[i].len), ob = up(frames[i].out_capacity * 2);
+            if (c.count > 0 && c.inBytes + c.outBytes + ib + ob > kSlotBudget)
+                break;
+            c.inBytes += ib;
+            c.outBytes += ob;
+            c.count++;
+            i++;
+        }
+        chunks.push_back(c);
     }
     auto grow = [](uint8_t *&p, size_t &cap, size_t want) {
         if (want <= cap)
@@ -355,34 +401,75 @@ void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<s
         if (!p)
             throw IOException("Failed to allocate pinned staging");
     };
-    grow(I.pinIn, I.pinInCap, inBytes);
-    grow(I.pinOut, I.pinOutCap, outBytes);
-
-    // pass 2: compressed payloads straight into pinned memory
-    size_t io = 0, oo = 0;
-    for (size_t i = 0; i < n; i++) {
-        mcraw_frame &f = frames[i];
-        if (f.len)
-            I.reader.readAt(spans[i].payload, I.pinIn + io, f.len);
-        f.in = I.pinIn + io;
-        f.out = reinterpret_cast<uint16_t *>(I.pinOut + oo);
-        io += up(f.len);
-        oo += up(f.out_capacity * 2);
+    size_t maxIn = 0, maxOut = 0;
+    for (const Chunk &c : chunks) {
+        maxIn = std::max(maxIn, c.inBytes);
+        maxOut = std::max(maxOut, c.outBytes);
     }
+    const int nslots = chunks.size() > 1 ? 2 : 1;
+    for (int s = 0; s < nslots; s++) {
+        grow(I.pinIn[s], I.pinInCap[s], maxIn);
+        grow(I.pinOut[s], I.pinOutCap[s], maxOut);
+    }
+    const unsigned hostThreads = std::max(2u, std::min(8u, std::thread::hardware_concurrency() / 2));
 
-    // one batch: copies and decode pipelined on the context's streams
+    auto readChunk = [&](size_t ci) { // file -> pinned input slot
+        const Chunk &c = chunks[ci];
+        uint8_t *base = I.pinIn[ci % nslots];
+        std::vector<size_t> off(c.count);
+        size_t o = 0;
+        for (size_t k = 0; k < c.count; k++) {
+            off[k] = o;
+            o += up(frames[c.first + k].len);
+        }
+        parallelFor(c.count, hostThreads, [&](size_t k) {
+            mcraw_frame &f = frames[c.first + k];
+            if (f.len)
+                I.reader.readAt(spans[c.first + k].payload, base + off[k], f.len);
+            f.in = base + off[k];
+        });
+    };
+    auto copyOut = [&](size_t ci) { // pinned output slot -> the caller's vectors
+        const Chunk &c = chunks[ci];
+        parallelFor(c.count, hostThreads, [&](size_t k) {
+            const mcraw_frame &f = frames[c.first + k];
+            const uint8_t *src = reinterpret_cast<const uint8_t *>(f.out);
+            outData[c.first + k].assign(src, src + f.out_capacity * 2);
+        });
+    };
+
     std::vector<size_t> written(n);
     std::vector<int32_t> status(n);
-    if (mcraw_decode_batch(I.ctx, frames.data(), static_cast<int>(n), MCRAW_MEM_HOST, nullptr, written.data(),
-                           status.data()) != 0)
-        throw IOException(std::string("GPU decode failed: ") + mcraw_last_error());
-    for (size_t i = 0; i < n; i++) {
-        if (status[i] != 0 || written[i] == 0)
-            throw IOException(frames[i].type == kTypeBlock ? "Failed to uncompress frame"
-                                                           : "Failed to uncompress legacy frame");
-        const uint8_t *src = reinterpret_cast<const uint8_t *>(frames[i].out);
-        outData[i].assign(src, src + frames[i].out_capacity * 2);
+    std::future<void> reading = std::async(std::launch::async, readChunk, size_t(0));
+    std::future<void> copying; // copy-out of the previous chunk
+    std::future<void> copying2; // ... and of the one before (it owns the output slot about to be reused)
+    for (size_t ci = 0; ci < chunks.size(); ci++) {
+        const Chunk &c = chunks[ci];
+        reading.get();
+        if (ci + 1 < chunks.size())
+            reading = std::async(std::launch::async, readChunk, ci + 1);
+        if (copying2.valid())
+            copying2.get(); // chunk ci-2 used this output slot
+        uint8_t *obase = I.pinOut[ci % nslots];
+        size_t oo = 0;
+        for (size_t k = 0; k < c.count; k++) {
+            frames[c.first + k].out = reinterpret_cast<uint16_t *>(obase + oo);
+            oo += up(frames[c.first + k].out_capacity * 2);
+        }
+        if (mcraw_decode_batch(I.ctx, frames.data() + c.first, static_cast<int>(c.count), MCRAW_MEM_HOST, nullptr,
+                               written.data() + c.first, status.data() + c.first) != 0)
+            throw IOException(std::string("GPU decode failed: ") + mcraw_last_error());
+        for (size_t k = c.first; k < c.first + c.count; k++)
+            if (status[k] != 0 || written[k] == 0)
+                throw IOException(frames[k].type == kTypeBlock ? "Failed to uncompress frame"
+                                                               : "Failed to uncompress legacy frame");
+        copying2 = std::move(copying);
+        copying = std::async(std::launch::async, copyOut, ci);
     }
+    if (copying2.valid())
+        copying2.get();
+    if (copying.valid())
+        copying.get();
 }
 
 } // namespace motioncam

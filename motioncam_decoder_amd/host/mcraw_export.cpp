@@ -1,6 +1,6 @@
 // mcraw_export -- decode a .mcraw file on the GPU and dump what it holds.
 //
-//   mcraw_export <file.mcraw> [-n frames] [-o outdir] [--single]
+//   mcraw_export <file.mcraw> [-n frames] [-o outdir] [--single] [--no-write]
 //
 // Writes outdir/frame_%06d.u16 (width*height uint16 LE, row-major Bayer mosaic) for the
 // first N frames (by timestamp) and outdir/audio.s16 (interleaved PCM), and prints one line
@@ -8,6 +8,7 @@
 // batch (Decoder::loadFrames); --single uses the per-frame loadFrame() path instead.
 #include <motioncam/Decoder.hpp>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -52,7 +53,7 @@ int main(int argc, char **argv)
     }
     std::string input = argv[1], outdir = ".";
     long limit = -1;
-    bool single = false;
+    bool single = false, nowrite = false;
     for (int i = 2; i < argc; i++) {
         if (!std::strcmp(argv[i], "-n") && i + 1 < argc)
             limit = std::atol(argv[++i]);
@@ -60,6 +61,8 @@ int main(int argc, char **argv)
             outdir = argv[++i];
         else if (!std::strcmp(argv[i], "--single"))
             single = true;
+        else if (!std::strcmp(argv[i], "--no-write"))
+            nowrite = true; // decode and checksum only (timing runs)
     }
     try {
         motioncam::Decoder decoder(input);
@@ -81,6 +84,7 @@ int main(int argc, char **argv)
 
         std::vector<std::vector<uint8_t>> data;
         std::vector<nlohmann::json> meta;
+        const auto t0 = std::chrono::steady_clock::now();
         if (single) {
             data.resize(frames.size());
             meta.resize(frames.size());
@@ -89,10 +93,13 @@ int main(int argc, char **argv)
         } else {
             decoder.loadFrames(frames, data, meta);
         }
+        const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::cout << "decoded " << frames.size() << " frames in " << secs << " s (" << (secs > 0 ? frames.size() / secs : 0.0)
+                  << " frames/s, file read + GPU decode + copy out)" << std::endl;
         for (size_t i = 0; i < frames.size(); i++) {
             char name[64];
             std::snprintf(name, sizeof(name), "/frame_%06zu.u16", i);
-            if (!writeFile(outdir + name, data[i].data(), data[i].size()))
+            if (!nowrite && !writeFile(outdir + name, data[i].data(), data[i].size()))
                 throw motioncam::IOException("Failed to write " + outdir + name);
             const int w = meta[i]["width"], h = meta[i]["height"], t = meta[i]["compressionType"];
             std::printf("frame %zu ts %lld %dx%d type %d crc32 %08x\n", i, static_cast<long long>(frames[i]), w, h, t,
