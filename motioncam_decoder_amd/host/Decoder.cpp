@@ -12,6 +12,8 @@
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
+#include <chrono>
+#include <cstdlib>
 #include <future>
 #include <thread>
 #include <cstring>
@@ -289,29 +291,18 @@ AudioChunkLoader &Decoder::loadAudio() const { return *mImpl->loader; }
 
 void Decoder::loadFrame(const Timestamp timestamp, std::vector<uint8_t> &outData, nlohmann::json &outMetadata)
 {
-    const FrameSpan span = mImpl->locate(timestamp);
-    std::vector<uint8_t> compressed(span.payloadSize);
-    if (span.payloadSize)
-        mImpl->reader.readAt(span.payload, compressed.data(), compressed.size());
-    outMetadata = readJson(mImpl->reader, span.json, span.jsonSize);
-
-    const int width = outMetadata["width"];
-    const int height = outMetadata["height"];
-    const int compressionType = outMetadata["compressionType"];
-    if (width <= 0 || height <= 0)
-        throw IOException("Failed to uncompress frame");
-    outData.resize(sizeof(uint16_t) * static_cast<size_t>(width) * static_cast<size_t>(height));
-    uint16_t *out = reinterpret_cast<uint16_t *>(outData.data());
-
-    if (compressionType == kTypeBlock) {
-        if (raw::Decode(out, width, height, compressed.data(), compressed.size()) <= 0)
-            throw IOException("Failed to uncompress frame");
-    } else if (compressionType == kTypeLegacy) {
-        if (raw::DecodeLegacy(out, width, height, compressed.data(), compressed.size()) <= 0)
-            throw IOException("Failed to uncompress legacy frame");
-    } else {
-        throw IOException("Invalid compression type");
+    // one-frame batch through the pinned staging of loadFrames (same checks, same error texts)
+    std::vector<std::vector<uint8_t>> data(1);
+    std::vector<nlohmann::json> meta(1);
+    data[0].swap(outData); // keep the caller's capacity across calls
+    try {
+        loadFrames(std::vector<Timestamp>{timestamp}, data, meta);
+    } catch (...) {
+        outData.swap(data[0]);
+        throw;
     }
+    outData.swap(data[0]);
+    outMetadata = std::move(meta[0]);
 }
 
 // Run fn(i) for i in [0, n) on up to `threads` host threads (file reads and copies out of the
@@ -341,7 +332,7 @@ void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<s
 {
     Impl &I = *mImpl;
     const size_t n = timestamps.size();
-    outData.assign(n, {});
+    outData.resize(n);
     outMetadata.assign(n, nlohmann::json());
     if (n == 0)
         return;
@@ -431,13 +422,36 @@ void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<s
     };
     auto copyOut = [&](size_t ci) { // pinned output slot -> the caller's vectors
         const Chunk &c = chunks[ci];
-        parallelFor(c.count, hostThreads, [&](size_t k) {
+        if (c.count >= 3) { // one frame per task
+            parallelFor(c.count, hostThreads, [&](size_t k) {
+                const mcraw_frame &f = frames[c.first + k];
+                const uint8_t *src = reinterpret_cast<const uint8_t *>(f.out);
+                outData[c.first + k].assign(src, src + f.out_capacity * 2);
+            });
+            return;
+        }
+        for (size_t k = 0; k < c.count; k++) { // few frames: slice every frame over the threads
             const mcraw_frame &f = frames[c.first + k];
+            const size_t bytes = f.out_capacity * 2;
+            std::vector<uint8_t> &dst = outData[c.first + k];
+            if (dst.size() != bytes)
+                dst.resize(bytes);
             const uint8_t *src = reinterpret_cast<const uint8_t *>(f.out);
-            outData[c.first + k].assign(src, src + f.out_capacity * 2);
-        });
+            const size_t slice = (bytes + hostThreads - 1) / hostThreads;
+            parallelFor(hostThreads, hostThreads, [&](size_t t) {
+                const size_t lo = std::min(bytes, t * slice), hi = std::min(bytes, lo + slice);
+                std::memcpy(dst.data() + lo, src + lo, hi - lo);
+            });
+        }
     };
 
+    static const bool trace = std::getenv("MCRAW_TRACE") != nullptr;
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    double tWaitRead = 0, tDecode = 0, tWaitCopy = 0;
+    const auto tStart = now();
     std::vector<size_t> written(n);
     std::vector<int32_t> status(n);
     std::future<void> reading = std::async(std::launch::async, readChunk, size_t(0));
@@ -445,20 +459,26 @@ void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<s
     std::future<void> copying2; // ... and of the one before (it owns the output slot about to be reused)
     for (size_t ci = 0; ci < chunks.size(); ci++) {
         const Chunk &c = chunks[ci];
+        auto t0 = now();
         reading.get();
+        tWaitRead += ms(t0, now());
         if (ci + 1 < chunks.size())
             reading = std::async(std::launch::async, readChunk, ci + 1);
+        t0 = now();
         if (copying2.valid())
             copying2.get(); // chunk ci-2 used this output slot
+        tWaitCopy += ms(t0, now());
         uint8_t *obase = I.pinOut[ci % nslots];
         size_t oo = 0;
         for (size_t k = 0; k < c.count; k++) {
             frames[c.first + k].out = reinterpret_cast<uint16_t *>(obase + oo);
             oo += up(frames[c.first + k].out_capacity * 2);
         }
+        t0 = now();
         if (mcraw_decode_batch(I.ctx, frames.data() + c.first, static_cast<int>(c.count), MCRAW_MEM_HOST, nullptr,
                                written.data() + c.first, status.data() + c.first) != 0)
             throw IOException(std::string("GPU decode failed: ") + mcraw_last_error());
+        tDecode += ms(t0, now());
         for (size_t k = c.first; k < c.first + c.count; k++)
             if (status[k] != 0 || written[k] == 0)
                 throw IOException(frames[k].type == kTypeBlock ? "Failed to uncompress frame"
@@ -466,10 +486,14 @@ void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<s
         copying2 = std::move(copying);
         copying = std::async(std::launch::async, copyOut, ci);
     }
+    const auto t1 = now();
     if (copying2.valid())
         copying2.get();
     if (copying.valid())
         copying.get();
+    if (trace)
+        std::fprintf(stderr, "[mcraw] loadFrames n=%zu chunks=%zu total %.2f ms: wait-read %.2f, gpu batch %.2f, wait-copy %.2f, tail copy %.2f\n",
+                     n, chunks.size(), ms(tStart, now()), tWaitRead, tDecode, tWaitCopy, ms(t1, now()));
 }
 
 } // namespace motioncam
