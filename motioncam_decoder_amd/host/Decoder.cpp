@@ -336,10 +336,7 @@ void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<s
     outMetadata.assign(n, nlohmann::json());
     if (n == 0)
         return;
-    if (!I.ctx && mcraw_ctx_create(-1, &I.ctx) != 0)
-        throw IOException(std::string("GPU decode unavailable: ") + mcraw_last_error());
-
-    // locate every frame and parse its JSON
+    // locate every frame and parse its JSON (container errors come first, like in the reference)
     std::vector<FrameSpan> spans(n);
     std::vector<mcraw_frame> frames(n);
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
@@ -363,6 +360,11 @@ void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<s
         f.reserved = 0;
         f.out_capacity = static_cast<size_t>(width) * static_cast<size_t>(height);
     }
+
+    if (!I.ctx && mcraw_ctx_create(-1, &I.ctx) != 0) // no GPU: decoding fails, there is no CPU codec behind this class
+        throw IOException(std::string(frames[0].type == kTypeBlock ? "Failed to uncompress frame"
+                                                                   : "Failed to uncompress legacy frame") +
+                          " (" + mcraw_last_error() + ")");
 
     // chunks: as many frames as fit the staging budget of one slot (at least one frame)
     constexpr size_t kSlotBudget = 192ull << 20;

@@ -82,7 +82,7 @@ def test_container_reader_matches_reference_contract(probe):
     assert out[5] == "missing: Frame not found (timestamp: 123456789)"      # :186
     import torch
     if not torch.cuda.is_available():
-        assert out[6] == "decode: Failed to uncompress legacy frame"        # no GPU: fails, never decodes on the CPU
+        assert out[6].startswith("decode: Failed to uncompress legacy frame")  # no GPU: fails, never decodes on the CPU
     else:
         assert out[6] == "decoded 2048 128x8"
 
