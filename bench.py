@@ -297,7 +297,7 @@ def main():
                                                              "Nat (smooth field + noise sigma %g)" % args.sigma if args.dist == "nat" else "U (uniform)")
         key = "%dx%d_%dbit_%d_%s" % (args.width, args.height, args.nbits, args.frames, args.dist)
         out = {
-            "metric": "MPixels/s unpacked (4K 12-bit MCRAW frame decode)",
+            "metric": "MPixels/s unpacked + achieved HBM GB/s %peak, 4K 12-bit, 1/2/4/8 GPUs",
             "value": round(s["mpix_s"], 1),
             "unit": "MPixels/s",
             "n_gpus": world,

@@ -58,6 +58,13 @@ def load():
     if _lib is not None:
         return _lib
     p = lib_path()
+    if not os.path.exists(p) and "MCRAW_LIB_PATH" not in os.environ:
+        try:  # a fresh checkout: compile the kernels now (hipcc, ~40 s); this is a build step, not a fallback
+            from . import build as _build
+            _build.build_hip()
+        except Exception as e:
+            raise McrawError("HIP decode library not built and building it failed (%s): %s; "
+                             "there is no CPU fallback" % (e, p))
     if not os.path.exists(p):
         raise McrawError("HIP decode library not built: %s (run `python -m motioncam_decoder_amd.build`); "
                          "there is no CPU fallback" % p)
