@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def counters(path):
-    files = glob.glob(os.path.join(path, "**", "*_counter_collection.csv"), recursive=True)
+    files = sorted(glob.glob(os.path.join(path, "**", "*_counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     disp = collections.defaultdict(set)
     for f in files:
@@ -36,8 +36,9 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    for f in glob.glob(os.path.join(src, "stats", "**", "*_kernel_stats.csv"), recursive=True):
-        shutil.copy(f, os.path.join(dst, tag + "_kernel_stats.csv"))
+    stats = sorted(glob.glob(os.path.join(src, "stats", "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
+    if stats:  # the newest run (gpurun merges every run's files into the same directory)
+        shutil.copy(stats[-1], os.path.join(dst, tag + "_kernel_stats.csv"))
     out = {"tag": tag, "command": "rocprofv3 ... -- python3 bench.py --steps N --warmup W --no-cpu --no-also (tools/profile_bench.sh)"}
     per = {}
     for name in ("fetch", "write", "sq"):
