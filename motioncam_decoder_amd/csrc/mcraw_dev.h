@@ -71,16 +71,23 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n)
     return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + i;
 }
 
+// Exclusive prefix sum over the 64 lanes (all lanes must be active) and the wave total.
+// DPP form (no LDS traffic): Hillis-Steele inside each 16-lane row with row_shr:1,2,4,8, then
+// row_bcast:15 / row_bcast:31 carry the row totals across (gfx9 DPP controls).
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, uint32_t *total)
 {
+    (void)lane;
     uint32_t inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(inc, d, 64);
-        if (lane >= static_cast<uint32_t>(d))
-            inc += o;
-    }
-    *total = __shfl(inc, 63, 64);
+#define MCRAW_DPP_ADD(ctrl, rowmask)                                                                                   \
+    inc += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(inc), ctrl, rowmask, 0xf, true))
+    MCRAW_DPP_ADD(0x111, 0xf); // row_shr:1
+    MCRAW_DPP_ADD(0x112, 0xf); // row_shr:2
+    MCRAW_DPP_ADD(0x114, 0xf); // row_shr:4
+    MCRAW_DPP_ADD(0x118, 0xf); // row_shr:8
+    MCRAW_DPP_ADD(0x142, 0xa); // row_bcast:15 -> rows 1 and 3
+    MCRAW_DPP_ADD(0x143, 0xc); // row_bcast:31 -> rows 2 and 3
+#undef MCRAW_DPP_ADD
+    *total = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(inc), 63));
     return inc - v;
 }
 
