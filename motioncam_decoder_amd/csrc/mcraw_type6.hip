@@ -27,12 +27,28 @@ constexpr uint32_t DEAD = 31; // phase value: the chain ended (a record crossed 
 __device__ __forceinline__ uint32_t len6_of(uint32_t b) { return b <= 10u ? 2u * b : 32u; }
 
 // ------------------------------------------------------------------ k6_maps
-constexpr int MAP_CH_PER_WAVE = 3; // 3 x 17 phases = 51 of 64 lanes
+constexpr int MAP_CH_PER_WAVE = 3;           // 3 x 17 phases = 51 of 64 lanes
+constexpr uint32_t HALF6 = CHUNK6 / 2;       // even byte positions ("half positions") per chunk
+constexpr uint32_t TAB6 = HALF6 + 32;        // stride table per chunk, padded so a finished lane still reads LDS it owns
 
+// Stride of the record whose header byte is `b`, in half positions: (2 + LEN)/2 = 1 + bits for
+// bits <= 10, 17 above (RawData_Legacy.cpp:13-32).  Four header bytes per call, one per byte lane.
+__device__ __forceinline__ uint32_t stride4(uint32_t hdr4)
+{
+    const uint32_t x = (hdr4 >> 4) & 0x0F0F0F0Fu;
+    const uint32_t g = ((x + 0x05050505u) >> 4) & 0x01010101u;
+    const uint32_t big = (g << 8) - g; // 0xFF in the byte lanes where bits >= 11
+    return (big & 0x11111111u) | (~big & (x + 0x01010101u));
+}
+
+// One wave per 3 chunks.  All 64 lanes first turn the chunk bytes into a table of record strides
+// (one byte per even position -- the only places a header can sit); then lane (chunk, phase)
+// follows the table from its entry to the chunk end: 1 LDS read + 3 VALU per record instead of
+// decoding the header at every step of all 17 walks.
 __global__ __launch_bounds__(256) void k6_maps(const Plan6 *__restrict__ plans, const uint32_t *__restrict__ item_base,
                                                int nframes)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_bytes[4][MAP_CH_PER_WAVE * CHUNK6];
+    __shared__ __attribute__((aligned(16))) uint8_t s_tab[4][MAP_CH_PER_WAVE * TAB6];
 
     const int f = find_frame(blockIdx.x, item_base, nframes);
     const Plan6 *P = plans + f;
@@ -43,33 +59,46 @@ __global__ __launch_bounds__(256) void k6_maps(const Plan6 *__restrict__ plans, 
         return;
     const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
 
-    // 3 KiB of stream for this wave (reads past `len` give 0)
-    uint4 *dst = reinterpret_cast<uint4 *>(s_bytes[wave]);
+    // 3 KiB of stream for this wave (reads past `len` give 0); 16 bytes -> 8 strides per lane
+    uint2 *tab2 = reinterpret_cast<uint2 *>(s_tab[wave]);
 #pragma unroll
-    for (int q = 0; q < MAP_CH_PER_WAVE; q++)
-        dst[q * 64 + lane] = ld_b128(rs, (c0 + q) * CHUNK6 + lane * 16u);
-    __builtin_amdgcn_wave_barrier();
+    for (int q = 0; q < MAP_CH_PER_WAVE; q++) {
+        const uint4 v = ld_b128(rs, (c0 + q) * CHUNK6 + lane * 16u);
+        // header candidates are bytes 0 and 2 of every dword
+        const uint32_t lo = stride4(__builtin_amdgcn_perm(v.y, v.x, 0x06040200u));
+        const uint32_t hi = stride4(__builtin_amdgcn_perm(v.w, v.z, 0x06040200u));
+        tab2[q * (TAB6 / 8u) + lane] = make_uint2(lo, hi);
+    }
     __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
 
     const uint32_t sub = lane / PHASES6, ph = lane - sub * PHASES6;
     const uint32_t c = c0 + sub;
     if (sub >= MAP_CH_PER_WAVE || c >= nchunks)
         return;
-    const uint8_t *bytes = s_bytes[wave] + sub * CHUNK6;
+    const uint8_t *tab = s_tab[wave] + sub * TAB6;
     const uint32_t cs = c * CHUNK6;
-    uint32_t pos = 2u * ph, count = 0, exitph = 0;
-    while (pos < CHUNK6) {
-        const uint32_t L = len6_of(bytes[pos] >> 4);
-        // RawData_Legacy.cpp:387-388,398-399: a record must end before len-1
-        if (cs + pos + 2u + L >= len) {
-            exitph = DEAD;
-            break;
+    // RawData_Legacy.cpp:387-388,398-399: a record must end before len-1, i.e. the record at half
+    // position q with stride d is the chain's end when cs + 2*(q + d) >= len
+    const uint32_t limq = len > cs ? (len - cs + 1u) >> 1 : 0u;
+    uint32_t q = ph, count = 0;
+    if (limq > HALF6 + 17u) { // no record of this chunk can reach `len`
+        const uint8_t *pp = tab + q, *const pe = tab + HALF6;
+        while (pp < pe) {
+            pp += *pp;
+            count++;
         }
-        pos += 2u + L;
-        count++;
+        q = static_cast<uint32_t>(pp - tab);
+    } else {
+        while (q < HALF6) {
+            const uint32_t nq = q + tab[q];
+            if (nq >= limq)
+                break;
+            q = nq;
+            count++;
+        }
     }
-    if (exitph != DEAD)
-        exitph = (pos - CHUNK6) >> 1;
+    const uint32_t exitph = q < HALF6 ? DEAD : q - HALF6;
     P->cmap[c * PHASES6 + ph] = exitph | (count << 8);
 }
 
@@ -175,18 +204,37 @@ __global__ __launch_bounds__(64) void k6_chunks(const Plan6 *__restrict__ plans,
 
 // ------------------------------------------------------------------ k6_rows
 
-// Residual k of a record: field k of an MSB-first bitstream of `sb`-bit fields starting at byte
-// `boff` of the staged bytes (sb = header nibble for <= 10, 16 for the big-endian raw form,
-// RawData_Legacy.cpp:38-370).  Two aligned dwords around the field form a 64-bit big-endian window.
-__device__ __forceinline__ uint32_t field6(const uint32_t *__restrict__ words, uint32_t boff, uint32_t sb, uint32_t k)
+// Samples 4*qt..4*qt+3 of the record at byte `ro` of the staged stream, reference NOT yet added;
+// *ref receives the header's 12-bit reference (RawData_Legacy.cpp:372-375).  The payload is an
+// MSB-first bitstream of sb-bit fields (sb = header nibble for <= 10, 16 big-endian raw bits above,
+// RawData_Legacy.cpp:38-370), so the lane's four fields are the top 4*sb bits of a 64-bit
+// big-endian window that starts 4*qt*sb bits into the payload.  The window is cut out of three
+// aligned dwords with two byte permutes (alignment and byte swap in one selector).
+__device__ __forceinline__ void quad6(const uint8_t *__restrict__ bytes, uint32_t ro, uint32_t qt, uint32_t v[4],
+                                      uint32_t *ref)
 {
-    const uint32_t o = k * sb;
-    const uint32_t byte = boff + (o >> 3);
-    const uint32_t wi = byte >> 2;
-    const uint32_t hi = __builtin_bswap32(words[wi]), lo = __builtin_bswap32(words[wi + 1u]);
-    const uint32_t bo = 8u * (byte & 3u) + (o & 7u);
-    const uint64_t win = ((static_cast<uint64_t>(hi) << 32) | lo) << bo;
-    return sb ? static_cast<uint32_t>(win >> (64u - sb)) : 0u;
+    const uint32_t h = *reinterpret_cast<const uint16_t *>(bytes + ro); // records start on even bytes
+    const uint32_t hb = (h >> 4) & 15u;
+    *ref = ((h & 15u) << 8) | (h >> 8);
+    const uint32_t sb = hb <= 10u ? hb : 16u;
+    const uint32_t ob = 4u * qt * sb;              // bit offset of my fields in the payload
+    const uint32_t B = ro + 2u + (ob >> 3);        // first byte of the window
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(bytes + (B & ~3u));
+    const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
+    const uint32_t sel = 0x00010203u + (B & 3u) * 0x01010101u;
+    uint32_t hi = __builtin_amdgcn_perm(d1, d0, sel), lo = __builtin_amdgcn_perm(d2, d1, sel);
+    if (ob & 4u) { // odd field width and odd quarter: the window starts on a nibble
+        hi = (hi << 4) | (lo >> 28);
+        lo <<= 4;
+    }
+    // fields 0 and 1 end within the high dword for every width; 2 and 3 can reach into the low one
+    v[0] = __builtin_amdgcn_ubfe(hi, (32u - sb) & 31u, sb);
+    v[1] = __builtin_amdgcn_ubfe(hi, (32u - 2u * sb) & 31u, sb);
+    const bool raw = sb == 16u;
+    v[2] = __builtin_amdgcn_ubfe(raw ? lo : hi, raw ? 16u : (32u - 3u * sb) & 31u, sb);
+    const bool big = sb >= 9u;
+    const uint32_t s3 = big ? __builtin_amdgcn_alignbit(hi, lo, (64u - 4u * sb) & 31u) : hi;
+    v[3] = __builtin_amdgcn_ubfe(s3, big ? 0u : (32u - 4u * sb) & 31u, sb);
 }
 
 // One wave per ROWS_CH consecutive chunks (8 KiB of stream).  Lane j < ROWS_CH walks chunk j from
@@ -202,7 +250,7 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
 {
     constexpr uint32_t STAGE = ROWS_CH * CHUNK6 + 64 + 16;
     __shared__ __attribute__((aligned(16))) uint8_t s_bytes[4][STAGE];
-    __shared__ uint16_t s_pos[4][ROWS_CAP];
+    __shared__ __attribute__((aligned(4))) uint16_t s_pos[4][ROWS_CAP + 2]; // indexed from the round's first PAIR
 
     const int f = find_frame(blockIdx.x, item_base, nframes);
     const Plan6 *P = plans + f;
@@ -238,7 +286,6 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
     __builtin_amdgcn_wave_barrier();
 
     const uint8_t *bytes = s_bytes[wave];
-    const uint32_t *words = reinterpret_cast<const uint32_t *>(s_bytes[wave]);
     const uint32_t rpr = P->recs_per_row;
     const uint32_t width = static_cast<uint32_t>(P->width);
     const bool fast = P->fast_store != 0u;
@@ -246,7 +293,12 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
 
     for (uint32_t base = 0; base < N; base += ROWS_CAP) {
         const uint32_t wlo = I0 + base, whi = min(Iend, wlo + ROWS_CAP); // records listed this round
-        if (walker) {
+        const uint32_t pair0 = wlo >> 1;
+        const uint32_t *s_pos32 = reinterpret_cast<const uint32_t *>(s_pos[wave]);
+#ifndef K6_ABL
+#define K6_ABL 0
+#endif
+        if (K6_ABL != 3 && walker) {
             const uint32_t off = lane * CHUNK6;
             uint32_t pos = 2u * (e & 255u), idx = e >> 8;
             while (pos < CHUNK6 && idx < whi) {
@@ -254,7 +306,7 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
                 if (cs0 + off + nx >= len)
                     break; // k6_frame has already failed the frame if records are missing
                 if (idx >= wlo)
-                    s_pos[wave][idx - wlo] = static_cast<uint16_t>(off + pos);
+                    s_pos[wave][idx - 2u * pair0] = static_cast<uint16_t>(off + pos);
                 pos = nx;
                 idx++;
             }
@@ -262,47 +314,40 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
 
-        const uint32_t pair0 = wlo >> 1;
-        const uint32_t ntask = 4u * (((whi + 1u) >> 1) - pair0);
+        const uint32_t ntask = K6_ABL == 2 ? 0u : 4u * (((whi + 1u) >> 1) - pair0);
         for (uint32_t t = lane; t < ntask; t += 64u) {
             const uint32_t q = t >> 2, qt = t & 3u;
             const uint32_t ra = 2u * (pair0 + q), rb = ra + 1u; // even-column and odd-column record
-            const bool hasA = ra >= wlo && ra < whi;
-            const bool hasB = rb >= wlo && rb < whi;
-            uint32_t va[4] = {0, 0, 0, 0}, vb[4] = {0, 0, 0, 0};
-            if (hasA) {
-                const uint32_t ro = s_pos[wave][ra - wlo];
-                const uint32_t b0 = bytes[ro], b1 = bytes[ro + 1u];
-                const uint32_t hb = b0 >> 4, ref = ((b0 & 15u) << 8) | b1; // RawData_Legacy.cpp:372-375
-#pragma unroll
-                for (uint32_t j = 0; j < 4u; j++)
-                    va[j] = field6(words, ro + 2u, hb <= 10u ? hb : 16u, 4u * qt + j) + ref;
-            }
-            if (hasB) {
-                const uint32_t ro = s_pos[wave][rb - wlo];
-                const uint32_t b0 = bytes[ro], b1 = bytes[ro + 1u];
-                const uint32_t hb = b0 >> 4, ref = ((b0 & 15u) << 8) | b1;
-#pragma unroll
-                for (uint32_t j = 0; j < 4u; j++)
-                    vb[j] = field6(words, ro + 2u, hb <= 10u ? hb : 16u, 4u * qt + j) + ref;
-            }
+            const bool hasA = ra >= wlo; // only the first and the last pair of a round can be halves
+            const bool hasB = rb < whi;
+            const uint32_t ro2 = s_pos32[q];
+            uint32_t va[4] = {0, 0, 0, 0}, vb[4] = {0, 0, 0, 0}, refa = 0, refb = 0;
+            if (hasA)
+                quad6(bytes, ro2 & 0xffffu, qt, va, &refa);
+            if (hasB)
+                quad6(bytes, ro2 >> 16, qt, vb, &refb);
             const uint32_t y = ra / rpr;
             const uint32_t x = ((ra - y * rpr) >> 1) * 32u + 8u * qt; // RawData_Legacy.cpp:479-486
             uint16_t *row = P->out + static_cast<size_t>(y) * static_cast<size_t>(width);
-            if (hasA && hasB && fast && x + 8u <= width) {
+            if (K6_ABL == 1) {
+                if ((va[0] ^ vb[0] ^ va[1] ^ vb[1] ^ va[2] ^ vb[2] ^ va[3] ^ vb[3] ^ refa ^ refb) == 0x12345678u)
+                    row[x] = 1;
+            } else if (hasA && hasB && fast && x + 8u <= width) {
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+                const u16x2 refs = __builtin_bit_cast(u16x2, refa | (refb << 16));
                 u32x4 o;
 #pragma unroll
                 for (int j = 0; j < 4; j++) // uint16 wrap; even column from A, odd column from B
-                    o[j] = (va[j] & 0xffffu) | (vb[j] << 16);
+                    o[j] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, va[j] | (vb[j] << 16)) + refs);
                 __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(row + x));
             } else {
 #pragma unroll
                 for (uint32_t j = 0; j < 4u; j++) {
                     if (hasA && x + 2u * j < width)
-                        row[x + 2u * j] = static_cast<uint16_t>(va[j]);
+                        row[x + 2u * j] = static_cast<uint16_t>(va[j] + refa);
                     if (hasB && x + 2u * j + 1u < width)
-                        row[x + 2u * j + 1u] = static_cast<uint16_t>(vb[j]);
+                        row[x + 2u * j + 1u] = static_cast<uint16_t>(vb[j] + refb);
                 }
             }
         }
