@@ -217,24 +217,21 @@ __device__ __forceinline__ void quad6(const uint8_t *__restrict__ bytes, uint32_
     const uint32_t hb = (h >> 4) & 15u;
     *ref = ((h & 15u) << 8) | (h >> 8);
     const uint32_t sb = hb <= 10u ? hb : 16u;
-    const uint32_t ob = 4u * qt * sb;              // bit offset of my fields in the payload
-    const uint32_t B = ro + 2u + (ob >> 3);        // first byte of the window
+    const uint32_t ob = 4u * qt * sb;       // bit offset of my fields in the payload
+    const uint32_t B = ro + 2u + (ob >> 3); // first byte of the window
     const uint32_t *w = reinterpret_cast<const uint32_t *>(bytes + (B & ~3u));
     const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
-    const uint32_t sel = 0x00010203u + (B & 3u) * 0x01010101u;
-    uint32_t hi = __builtin_amdgcn_perm(d1, d0, sel), lo = __builtin_amdgcn_perm(d2, d1, sel);
-    if (ob & 4u) { // odd field width and odd quarter: the window starts on a nibble
-        hi = (hi << 4) | (lo >> 28);
-        lo <<= 4;
-    }
+    const uint32_t k = B & 3u;
+    const uint32_t sel = 0x00010203u + __builtin_amdgcn_perm(k, k, 0u); // k in every byte lane
+    const uint32_t hi0 = __builtin_amdgcn_perm(d1, d0, sel), lo0 = __builtin_amdgcn_perm(d2, d1, sel);
+    // odd field width and odd quarter: the fields start on a nibble
+    const uint64_t W = ((static_cast<uint64_t>(hi0) << 32) | lo0) << (ob & 4u);
+    const uint32_t hi = static_cast<uint32_t>(W >> 32);
     // fields 0 and 1 end within the high dword for every width; 2 and 3 can reach into the low one
     v[0] = __builtin_amdgcn_ubfe(hi, (32u - sb) & 31u, sb);
     v[1] = __builtin_amdgcn_ubfe(hi, (32u - 2u * sb) & 31u, sb);
-    const bool raw = sb == 16u;
-    v[2] = __builtin_amdgcn_ubfe(raw ? lo : hi, raw ? 16u : (32u - 3u * sb) & 31u, sb);
-    const bool big = sb >= 9u;
-    const uint32_t s3 = big ? __builtin_amdgcn_alignbit(hi, lo, (64u - 4u * sb) & 31u) : hi;
-    v[3] = __builtin_amdgcn_ubfe(s3, big ? 0u : (32u - 4u * sb) & 31u, sb);
+    v[2] = __builtin_amdgcn_ubfe(static_cast<uint32_t>(W >> ((64u - 3u * sb) & 63u)), 0u, sb);
+    v[3] = __builtin_amdgcn_ubfe(static_cast<uint32_t>(W >> ((64u - 4u * sb) & 63u)), 0u, sb);
 }
 
 // One wave per ROWS_CH consecutive chunks (8 KiB of stream).  Lane j < ROWS_CH walks chunk j from
@@ -244,6 +241,10 @@ __device__ __forceinline__ void quad6(const uint8_t *__restrict__ bytes, uint32_
 // consecutive pixels = one 16-byte store; 8 lanes fill a 128-byte line.  (A wave-uniform walk of
 // ONE chunk per wave spent 64 lanes on a scalar chain and made this kernel issue-bound.)
 constexpr uint32_t ROWS_CAP = 1024; // records listed per round (typical: 8 chunks x ~70; worst case 8 x 512 -> 4 rounds)
+
+#ifndef K6_ABL
+#define K6_ABL 0 // timing experiments only: 1 no stores, 3 no walk
+#endif
 
 __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, const uint32_t *__restrict__ item_base,
                                                int nframes)
@@ -270,6 +271,7 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
         return; // the chain ended before this wave's chunks
     const uint32_t I0 = e0 >> 8;
     const uint32_t enext = __shfl(e, ROWS_CH, 64);
+    const bool inner = c0 + ROWS_CH < nchunks && (enext & 255u) != DEAD && (enext >> 8) <= nrec;
     const uint32_t Iend = min(nrec, (c0 + ROWS_CH < nchunks) ? (enext >> 8) : nrec);
     if (I0 >= Iend)
         return;
@@ -286,53 +288,67 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
     __builtin_amdgcn_wave_barrier();
 
     const uint8_t *bytes = s_bytes[wave];
-    const uint32_t rpr = P->recs_per_row;
     const uint32_t width = static_cast<uint32_t>(P->width);
     const bool fast = P->fast_store != 0u;
     const bool walker = lane < ROWS_CH && (e & 255u) != DEAD && c0 + lane < nchunks;
+    uint16_t *const out = P->out;
+
+    // row arithmetic without per-lane division: pairs per row `ppr`; a round spans < 2 rows when
+    // ppr >= 512, otherwise n / ppr for n < 1024 is exact as (n * ceil(2^20 / ppr)) >> 20
+    const uint32_t ppr = P->recs_per_row >> 1;
+    const bool widerow = ppr >= 512u;
+    const uint32_t m20 = widerow ? 0u : ((1u << 20) + ppr - 1u) / ppr;
 
     for (uint32_t base = 0; base < N; base += ROWS_CAP) {
         const uint32_t wlo = I0 + base, whi = min(Iend, wlo + ROWS_CAP); // records listed this round
         const uint32_t pair0 = wlo >> 1;
         const uint32_t *s_pos32 = reinterpret_cast<const uint32_t *>(s_pos[wave]);
-#ifndef K6_ABL
-#define K6_ABL 0
-#endif
         if (K6_ABL != 3 && walker) {
             const uint32_t off = lane * CHUNK6;
-            uint32_t pos = 2u * (e & 255u), idx = e >> 8;
-            while (pos < CHUNK6 && idx < whi) {
-                const uint32_t nx = pos + 2u + len6_of(static_cast<uint32_t>(bytes[off + pos]) >> 4);
-                if (cs0 + off + nx >= len)
-                    break; // k6_frame has already failed the frame if records are missing
-                if (idx >= wlo)
-                    s_pos[wave][idx - 2u * pair0] = static_cast<uint16_t>(off + pos);
-                pos = nx;
-                idx++;
+            if (inner && N <= ROWS_CAP && cs0 + STAGE < len) {
+                // every chunk of this wave runs to its end, the next entry bounds the last one, and no
+                // record can reach `len`: walk with nothing but the stride decode in the loop
+                const uint8_t *p = bytes + off + 2u * (e & 255u), *const pe = bytes + off + CHUNK6;
+                uint16_t *lp = s_pos[wave] + ((e >> 8) - 2u * pair0);
+                while (p < pe) {
+                    const uint32_t hb = static_cast<uint32_t>(*p) >> 4;
+                    *lp++ = static_cast<uint16_t>(p - bytes);
+                    p += 2u + len6_of(hb);
+                }
+            } else {
+                uint32_t pos = 2u * (e & 255u), idx = e >> 8;
+                while (pos < CHUNK6 && idx < whi) {
+                    const uint32_t nx = pos + 2u + len6_of(static_cast<uint32_t>(bytes[off + pos]) >> 4);
+                    if (cs0 + off + nx >= len)
+                        break; // k6_frame has already failed the frame if records are missing
+                    if (idx >= wlo)
+                        s_pos[wave][idx - 2u * pair0] = static_cast<uint16_t>(off + pos);
+                    pos = nx;
+                    idx++;
+                }
             }
         }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
 
-        const uint32_t ntask = K6_ABL == 2 ? 0u : 4u * (((whi + 1u) >> 1) - pair0);
+        // full pairs: four lanes each, no per-record guards
+        const uint32_t qlo = wlo & 1u, qhi = (whi >> 1) - pair0;
+        const uint32_t y0 = pair0 / ppr, r0 = pair0 - y0 * ppr; // wave-uniform
+        const uint32_t ntask = qhi > qlo ? 4u * (qhi - qlo) : 0u;
         for (uint32_t t = lane; t < ntask; t += 64u) {
-            const uint32_t q = t >> 2, qt = t & 3u;
-            const uint32_t ra = 2u * (pair0 + q), rb = ra + 1u; // even-column and odd-column record
-            const bool hasA = ra >= wlo; // only the first and the last pair of a round can be halves
-            const bool hasB = rb < whi;
+            const uint32_t q = qlo + (t >> 2), qt = t & 3u;
             const uint32_t ro2 = s_pos32[q];
-            uint32_t va[4] = {0, 0, 0, 0}, vb[4] = {0, 0, 0, 0}, refa = 0, refb = 0;
-            if (hasA)
-                quad6(bytes, ro2 & 0xffffu, qt, va, &refa);
-            if (hasB)
-                quad6(bytes, ro2 >> 16, qt, vb, &refb);
-            const uint32_t y = ra / rpr;
-            const uint32_t x = ((ra - y * rpr) >> 1) * 32u + 8u * qt; // RawData_Legacy.cpp:479-486
-            uint16_t *row = P->out + static_cast<size_t>(y) * static_cast<size_t>(width);
+            uint32_t va[4], vb[4], refa, refb;
+            quad6(bytes, ro2 & 0xffffu, qt, va, &refa);
+            quad6(bytes, ro2 >> 16, qt, vb, &refb);
+            const uint32_t n = r0 + q;
+            const uint32_t dy = widerow ? (n >= ppr ? 1u : 0u) : (n * m20) >> 20;
+            const uint32_t x = (n - dy * ppr) * 32u + 8u * qt; // RawData_Legacy.cpp:479-486
+            uint16_t *px = out + ((y0 + dy) * width + x);
             if (K6_ABL == 1) {
                 if ((va[0] ^ vb[0] ^ va[1] ^ vb[1] ^ va[2] ^ vb[2] ^ va[3] ^ vb[3] ^ refa ^ refb) == 0x12345678u)
-                    row[x] = 1;
-            } else if (hasA && hasB && fast && x + 8u <= width) {
+                    px[0] = 1;
+            } else if (fast && x + 8u <= width) {
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                 typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
                 const u16x2 refs = __builtin_bit_cast(u16x2, refa | (refb << 16));
@@ -340,14 +356,34 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
 #pragma unroll
                 for (int j = 0; j < 4; j++) // uint16 wrap; even column from A, odd column from B
                     o[j] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, va[j] | (vb[j] << 16)) + refs);
-                __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(row + x));
+                __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(px));
             } else {
 #pragma unroll
-                for (uint32_t j = 0; j < 4u; j++) {
-                    if (hasA && x + 2u * j < width)
-                        row[x + 2u * j] = static_cast<uint16_t>(va[j] + refa);
-                    if (hasB && x + 2u * j + 1u < width)
-                        row[x + 2u * j + 1u] = static_cast<uint16_t>(vb[j] + refb);
+                for (uint32_t j = 0; j < 4u; j++) { // padded columns are cropped (RawData_Legacy.cpp:490)
+                    if (x + 2u * j < width)
+                        px[2u * j] = static_cast<uint16_t>(va[j] + refa);
+                    if (x + 2u * j + 1u < width)
+                        px[2u * j + 1u] = static_cast<uint16_t>(vb[j] + refb);
+                }
+            }
+        }
+        // a round that starts on an odd record or ends on an even one leaves half a pair at that end
+        if (lane < 8u) {
+            const uint32_t side = lane >> 2, qt = lane & 3u;
+            const uint32_t rec = side == 0u ? wlo : whi - 1u;
+            const bool need = side == 0u ? (wlo & 1u) != 0u : (whi & 1u) != 0u && !(whi - 1u == wlo && (wlo & 1u));
+            if (need && rec >= wlo && rec < whi) {
+                uint32_t v[4], ref;
+                quad6(bytes, s_pos[wave][rec - 2u * pair0], qt, v, &ref);
+                const uint32_t y = rec / (2u * ppr);
+                const uint32_t rr = rec - y * 2u * ppr;
+                const uint32_t x = (rr >> 1) * 32u + 8u * qt + (rr & 1u);
+                uint16_t *px = out + (static_cast<size_t>(y) * width + x);
+                if (K6_ABL != 1) {
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; j++)
+                        if (x + 2u * j < width)
+                            px[2u * j] = static_cast<uint16_t>(v[j] + ref);
                 }
             }
         }
