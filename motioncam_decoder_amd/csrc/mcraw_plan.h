@@ -86,7 +86,7 @@ struct Plan6 {
 
 constexpr int CHUNK6 = 1024; // bytes of legacy stream per transition-map chunk
 constexpr int SUPER6 = 64;   // chunks per super-chunk
-constexpr int ROWS_CH = 8;   // chunks per wave of k6_rows
+constexpr int ROWS_CH = 4;   // chunks per wave of k6_rows
 constexpr int PHASES6 = 17;  // entry offsets 0,2,..,32 (record stride <= 34, all even)
 
 } // namespace mcraw

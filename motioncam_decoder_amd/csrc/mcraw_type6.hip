@@ -8,11 +8,12 @@
 // transition maps: record strides are even and <= 34 bytes, so a fixed 1 KiB
 // chunk of the stream can be entered at only 17 offsets ("phases" 0,2,..,32).
 //
-//   k6_maps    per chunk, per phase: walk to the chunk end -> (exit phase, records started)
+//   k6_maps    per chunk: table of record strides, then per phase a walk over it to the chunk end
+//              -> (exit phase, records started)
 //   k6_super   compose 64 chunk maps into one super-chunk map
 //   k6_frame   follow the true phase over the super-chunks   -> entry of every super-chunk
 //   k6_chunks  follow it over a super-chunk's 64 chunks      -> entry of every chunk
-//   k6_rows    per 8 chunks: lanes list the records of one chunk each from its true entry, then
+//   k6_rows    per 4 chunks: lanes list the records of one chunk each from its true entry, then
 //              all lanes unpack them (MSB-first bitstreams, RawData_Legacy.cpp:38-370), add the
 //              references, interleave even/odd columns (:483-486) and crop the padded row (:490)
 #include "mcraw_dev.h"
@@ -234,13 +235,16 @@ __device__ __forceinline__ void quad6(const uint8_t *__restrict__ bytes, uint32_
     v[3] = __builtin_amdgcn_ubfe(static_cast<uint32_t>(W >> ((64u - 4u * sb) & 63u)), 0u, sb);
 }
 
-// One wave per ROWS_CH consecutive chunks (8 KiB of stream).  Lane j < ROWS_CH walks chunk j from
+// One wave per ROWS_CH consecutive chunks (4 KiB of stream).  Lane j < ROWS_CH walks chunk j from
 // its resolved entry and notes where every record starts; the records of the wave form one
 // contiguous index range, so the list is flat.  Then ALL lanes unpack, four lanes per record pair:
 // a lane owns samples 4q..4q+3 of the even-column record and of the odd-column record = 8
 // consecutive pixels = one 16-byte store; 8 lanes fill a 128-byte line.  (A wave-uniform walk of
-// ONE chunk per wave spent 64 lanes on a scalar chain and made this kernel issue-bound.)
-constexpr uint32_t ROWS_CAP = 1024; // records listed per round (typical: 8 chunks x ~70; worst case 8 x 512 -> 4 rounds)
+// ONE chunk per wave spent 64 lanes on a scalar chain and made this kernel issue-bound; more chunks
+// per wave spread the walk over more lanes but cost LDS, and 4 measured best: 0.261 ms against
+// 0.274 ms with 8 on 32 x 12 MP.)
+constexpr uint32_t ROWS_CAP = 128u * ROWS_CH; // records listed per round (typical: ~70 per chunk; worst case 512 -> 4 rounds)
+static_assert(ROWS_CAP <= 1024u, "the division-free row arithmetic in k6_rows assumes at most 512 pairs per round");
 
 #ifndef K6_ABL
 #define K6_ABL 0 // timing experiments only: 1 no stores, 3 no walk
@@ -335,37 +339,44 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
         const uint32_t qlo = wlo & 1u, qhi = (whi >> 1) - pair0;
         const uint32_t y0 = pair0 / ppr, r0 = pair0 - y0 * ppr; // wave-uniform
         const uint32_t ntask = qhi > qlo ? 4u * (qhi - qlo) : 0u;
-        for (uint32_t t = lane; t < ntask; t += 64u) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+        // one task: 8 pixels (even columns from record A, odd columns from record B, uint16 wrap on
+        // the reference add) and where they go
+        auto decode = [&](uint32_t t, u32x4 &o, uint32_t &x, uint16_t *&px) {
             const uint32_t q = qlo + (t >> 2), qt = t & 3u;
             const uint32_t ro2 = s_pos32[q];
             uint32_t va[4], vb[4], refa, refb;
             quad6(bytes, ro2 & 0xffffu, qt, va, &refa);
             quad6(bytes, ro2 >> 16, qt, vb, &refb);
             const uint32_t n = r0 + q;
-            const uint32_t dy = widerow ? (n >= ppr ? 1u : 0u) : (n * m20) >> 20;
-            const uint32_t x = (n - dy * ppr) * 32u + 8u * qt; // RawData_Legacy.cpp:479-486
-            uint16_t *px = out + ((y0 + dy) * width + x);
+            const uint32_t dy = widerow ? (n >= ppr ? 1u : 0u) : __umul24(n, m20) >> 20;
+            x = (n - __umul24(dy, ppr)) * 32u + 8u * qt; // RawData_Legacy.cpp:479-486
+            px = out + (__umul24(y0 + dy, width) + x);
+            const u16x2 refs = __builtin_bit_cast(u16x2, refa | (refb << 16));
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                o[j] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, va[j] | (vb[j] << 16)) + refs);
+        };
+        auto store = [&](const u32x4 &o, uint32_t x, uint16_t *px) {
             if (K6_ABL == 1) {
-                if ((va[0] ^ vb[0] ^ va[1] ^ vb[1] ^ va[2] ^ vb[2] ^ va[3] ^ vb[3] ^ refa ^ refb) == 0x12345678u)
+                if ((o[0] ^ o[1] ^ o[2] ^ o[3]) == 0x12345678u)
                     px[0] = 1;
             } else if (fast && x + 8u <= width) {
-                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
-                const u16x2 refs = __builtin_bit_cast(u16x2, refa | (refb << 16));
-                u32x4 o;
-#pragma unroll
-                for (int j = 0; j < 4; j++) // uint16 wrap; even column from A, odd column from B
-                    o[j] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, va[j] | (vb[j] << 16)) + refs);
                 __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(px));
             } else {
 #pragma unroll
-                for (uint32_t j = 0; j < 4u; j++) { // padded columns are cropped (RawData_Legacy.cpp:490)
-                    if (x + 2u * j < width)
-                        px[2u * j] = static_cast<uint16_t>(va[j] + refa);
-                    if (x + 2u * j + 1u < width)
-                        px[2u * j + 1u] = static_cast<uint16_t>(vb[j] + refb);
-                }
+                for (uint32_t j = 0; j < 8u; j++) // padded columns are cropped (RawData_Legacy.cpp:490)
+                    if (x + j < width)
+                        px[j] = static_cast<uint16_t>(o[j >> 1] >> (16u * (j & 1u)));
             }
+        };
+        for (uint32_t t = lane; t < ntask; t += 64u) {
+            u32x4 o;
+            uint32_t x;
+            uint16_t *px;
+            decode(t, o, x, px);
+            store(o, x, px);
         }
         // a round that starts on an odd record or ends on an even one leaves half a pair at that end
         if (lane < 8u) {
