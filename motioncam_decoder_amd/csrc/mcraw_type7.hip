@@ -145,6 +145,7 @@ constexpr uint32_t DEAD7 = 127u; // phase value: the chain has ended (record pas
 constexpr uint32_t MAPS_CH = 3; // chunks per 256-thread workgroup: 3 x 65 phases = 195 lanes
 constexpr uint32_t NODEAD = 0xFFFFu;
 constexpr uint32_t DENSE_RECORDS = 96; // k7_records lists chunks with more records by pointer doubling
+constexpr uint32_t REC_GROUP = 4;      // consecutive sparse chunks per k7_records work item (one walking lane each)
 
 // Where the record whose header sits at staged offset `rel` ends (= where the next one
 // starts), or NODEAD when it would cross `len` (RawData.cpp:419-420 skips such a block).
@@ -319,39 +320,63 @@ __global__ __launch_bounds__(256) void k7_follow(const Work7 W)
             atomicOr(status, (p != DEAD7 && hinted) ? E_LAYOUT : MCRAW_E_TRUNCATED);
         return;
     }
-    // Work lists of k7_records: the chunks [0, creal) of this stream.  Sparse chunks fill the list
-    // from the front, dense ones (runs of tiny records, listed by pointer doubling in a kernel of
-    // their own) from the back; the order inside either part does not matter.
-    if (tid < 3u)
-        s_state[tid] = 0; // [0] dense chunks of this stream, [1] sparse slots handed out, [2] dense slots handed out
+    // Work lists of k7_records: the chunks [0, creal) of this stream, REC_GROUP consecutive chunks
+    // per item (one lane walks each).  A chunk of tiny records (more than DENSE_RECORDS of them) is
+    // listed by pointer doubling in a kernel of its own: it goes to the dense list, which grows
+    // from the back of the same array, and the rest of its group is listed chunk by chunk.
+    if (tid < 4u)
+        s_state[tid] = 0; // [0] dense items of this stream, [1] sparse slots handed out, [2] dense slots handed out, [3] sparse items
     __syncthreads();
-    for (uint32_t i = tid; i < creal; i += 256u) {
-        const uint32_t nexti = i + 1u < creal ? min(R, centry[i + 1u] >> 8) : R;
-        if (nexti - min(nexti, centry[i] >> 8) > DENSE_RECORDS)
-            atomicAdd(&s_state[0], 1u);
+    const uint32_t ngrp = (creal + REC_GROUP - 1u) / REC_GROUP;
+    auto first_record = [&](uint32_t i) { return i < creal ? min(R, centry[i] >> 8) : R; };
+    for (uint32_t g = tid; g < ngrp; g += 256u) {
+        const uint32_t c0 = g * REC_GROUP, cnt = min(REC_GROUP, creal - c0);
+        uint32_t nd = 0;
+        for (uint32_t j = 0; j < cnt; j++)
+            nd += first_record(c0 + j + 1u) - min(first_record(c0 + j + 1u), centry[c0 + j] >> 8) > DENSE_RECORDS ? 1u : 0u;
+        if (nd) {
+            atomicAdd(&s_state[0], nd);
+            atomicAdd(&s_state[3], cnt - nd);
+        } else {
+            atomicAdd(&s_state[3], 1u);
+        }
     }
     __syncthreads();
     if (tid == 0) {
         const uint32_t nd = s_state[0];
-        s_entry[0] = atomicAdd(W.counters + 1, creal - nd);
+        s_entry[0] = atomicAdd(W.counters + 1, s_state[3]);
         s_entry[1] = nd ? atomicAdd(W.counters + 2, nd) : 0u;
     }
     __syncthreads();
     const uint32_t baseS = s_entry[0], baseD = s_entry[1];
-    for (uint32_t i = tid; i < creal; i += 256u) { // stream, records in the chunk, its byte offset, entry (phase | first record << 8)
-        const uint32_t e = centry[i];
-        const uint32_t nexti = i + 1u < creal ? min(R, centry[i + 1u] >> 8) : R;
-        const uint32_t nrec = nexti - min(nexti, e >> 8);
-        const bool dense = nrec > DENSE_RECORDS;
-        const uint32_t slot = atomicAdd(&s_state[dense ? 2 : 1], 1u);
-        const uint32_t at = dense ? W.list_cap - 1u - (baseD + slot) : baseS + slot;
-        W.list_recs[at] = make_uint4(fs, nrec, si.x + i * CH7, e);
+    for (uint32_t g = tid; g < ngrp; g += 256u) {
+        const uint32_t c0 = g * REC_GROUP, cnt = min(REC_GROUP, creal - c0);
+        uint32_t dmask = 0;
+        for (uint32_t j = 0; j < cnt; j++)
+            dmask |= (first_record(c0 + j + 1u) - min(first_record(c0 + j + 1u), centry[c0 + j] >> 8) > DENSE_RECORDS ? 1u : 0u) << j;
+        if (dmask == 0u) {
+            // sparse item: stream, first chunk | chunks << 24, byte offset of the first chunk, end of its record range
+            W.list_recs[baseS + atomicAdd(&s_state[1], 1u)] =
+                make_uint4(fs, c0 | (cnt << 24), si.x + c0 * CH7, first_record(c0 + cnt));
+            continue;
+        }
+        for (uint32_t j = 0; j < cnt; j++) {
+            const uint32_t i = c0 + j, e = centry[i];
+            if ((dmask >> j) & 1u) { // dense item: stream, records in the chunk, its byte offset, entry (phase | first record << 8)
+                const uint32_t nrec = first_record(i + 1u) - min(first_record(i + 1u), e >> 8);
+                W.list_recs[W.list_cap - 1u - (baseD + atomicAdd(&s_state[2], 1u))] = make_uint4(fs, nrec, si.x + i * CH7, e);
+            } else {
+                W.list_recs[baseS + atomicAdd(&s_state[1], 1u)] =
+                    make_uint4(fs, i | (1u << 24), si.x + i * CH7, first_record(i + 1u));
+            }
+        }
     }
 }
 
-constexpr int REC_STAGE = CH7 + 130 + 8 + 16; // records starting in the chunk may run 130 bytes past it (+ read slack)
-constexpr int REC_BYTES = (REC_STAGE + 15) / 16 * 16 + 16;
-constexpr int REC_MAX = CH7 / 2;
+// staged bytes of an item of `chunks` chunks: records starting in the last one may run 130 bytes
+// past it (+ read slack), and the first chunk starts up to 15 bytes into the first 16-byte line
+constexpr int rec_bytes(int chunks) { return (chunks * CH7 + 130 + 8 + 16 + 15) / 16 * 16 + 16; }
+constexpr int REC_MAX = CH7 / 2; // records that can start in one chunk
 
 template <int PATTERN>
 __device__ __forceinline__ uint32_t swz_xor(uint32_t v)
@@ -359,17 +384,22 @@ __device__ __forceinline__ uint32_t swz_xor(uint32_t v)
     return static_cast<uint32_t>(__builtin_amdgcn_ds_swizzle(static_cast<int>(v), PATTERN));
 }
 
-// One wave per chunk.  The wave lists the records that start in its chunk (a chain of
-// 2-byte LDS reads through the successor table), parses their headers in parallel, then
-// unpacks EIGHT records per pass: lane = (record, k) owns samples 8k..8k+7 exactly like a
-// payload lane (DecodeBlock on the record, RawData.cpp:489; + reference, :491-492).
+// One wave per work item.  Sparse form: REC_GROUP consecutive chunks, lane j walks chunk j from
+// its resolved entry and notes payload offset, class and reference of every record it meets (the
+// record indices of the item are contiguous, so the notes form one flat list).  Dense form: one
+// chunk of tiny records, listed by pointer doubling.  Then EIGHT records are unpacked per pass:
+// lane = (record, k) owns samples 8k..8k+7 exactly like a payload lane (DecodeBlock on the
+// record, RawData.cpp:489; + reference, :491-492).
 template <int ABL, bool DENSE>
 __global__ __launch_bounds__(64) void k7_records(const Work7 W)
 {
+    constexpr int NCHUNK = DENSE ? 1 : static_cast<int>(REC_GROUP);
+    constexpr int REC_BYTES = rec_bytes(NCHUNK);
+    constexpr uint32_t HDR_CAP = DENSE ? REC_MAX : REC_GROUP * DENSE_RECORDS;
     __shared__ __attribute__((aligned(16))) uint8_t s_b[REC_BYTES];
-    __shared__ uint32_t s_hdr[REC_MAX + 8]; // per record: payload offset | hbits << 12 | reference << 16
-    __shared__ __attribute__((aligned(16))) uint16_t s_J[CH7 / 2 + 8]; // successor table of the chunk's candidates
-    __shared__ __attribute__((aligned(8))) uint8_t s_M[CH7 / 2 + 8];   // chain marks
+    __shared__ uint32_t s_hdr[HDR_CAP + 8]; // per record: payload offset | hbits << 14 | reference << 18
+    __shared__ __attribute__((aligned(16))) uint16_t s_J[DENSE ? CH7 / 2 + 8 : 8]; // successor table of the chunk's candidates
+    __shared__ __attribute__((aligned(8))) uint8_t s_M[DENSE ? CH7 / 2 + 8 : 8];   // chain marks
     __shared__ uint4 s_tab[72];
 
     const uint32_t lane = threadIdx.x;
@@ -377,7 +407,7 @@ __global__ __launch_bounds__(64) void k7_records(const Work7 W)
     if (lane < 8u)
         s_tab[64u + lane] = reinterpret_cast<const uint4 *>(c_tab7)[64u + lane];
     const uint32_t nwork = W.counters[DENSE ? 2 : 1];
-    // sparse chunks are listed from the front of the work list, dense ones from its back
+    // sparse items are listed from the front of the work list, dense ones from its back
     const uint4 *list = DENSE ? W.list_recs + (W.list_cap - 1u) : W.list_recs;
     constexpr int STEP = DENSE ? -1 : 1;
     uint4 nextw = make_uint4(0, 0, 0, 0);
@@ -390,40 +420,55 @@ __global__ __launch_bounds__(64) void k7_records(const Work7 W)
     const uint32_t fs = __builtin_amdgcn_readfirstlane(we.x);
     const uint32_t f = fs >> 1, s = fs & 1u;
     int32_t *status = W.status + f;
-    const uint32_t entry = __builtin_amdgcn_readfirstlane(we.w);
-    const uint32_t ph = entry & 255u, i0 = entry >> 8;
     const Plan7 *P = W.plans + f;
     const uint32_t R = P->ngroups, nblk = P->nblk;
     const uint32_t len = P->len;
     const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
     const uint32_t abs = __builtin_amdgcn_readfirstlane(we.z);
     const uint32_t base16 = abs & ~15u, head = abs - base16;
+    // sparse: entries of my chunks, one per lane (issued before the staging loads)
+    const uint32_t first = __builtin_amdgcn_readfirstlane(we.y) & 0xffffffu;
+    const uint32_t nchunk = DENSE ? 1u : __builtin_amdgcn_readfirstlane(we.y) >> 24;
+    uint32_t ce = 0;
+    if (!DENSE && lane < nchunk)
+        ce = W.centry[static_cast<size_t>(fs) * W.nch + first + lane];
     __syncthreads(); // previous work item is done with the staging buffers
+    const uint32_t n16 = (head + nchunk * CH7 + 130u + 8u + 16u + 15u) >> 4; // <= REC_BYTES / 16
 #pragma unroll
     for (uint32_t q = 0; q < (REC_BYTES / 16 + 63) / 64; q++)
-        if (lane + 64u * q < REC_BYTES / 16)
+        if (lane + 64u * q < n16)
             reinterpret_cast<uint4 *>(s_b)[lane + 64u * q] = ld_b128(rs, base16 + (lane + 64u * q) * 16u);
     __syncthreads();
 
-    uint32_t n = 0;
+    uint32_t n = 0, i0;
     if (!DENSE) {
-        // Sparse chunk: walk the chain (every lane runs the same walk) and note payload offset,
-        // class and reference of each record (RawData.cpp:106-110).
-        uint32_t rel = 2u * ph;
-        while (ABL != 3 && rel < CH7 && i0 + n < R) {
-            const uint32_t ro = head + rel;
-            const uint32_t b0 = s_b[ro], b1 = s_b[ro + 1u];
-            const uint32_t nx = rel + 2u + len7_of(b0 >> 4);
-            if (abs + nx > len)
-                break; // cannot happen for a chunk k7_follow listed
-            if (lane == 0)
-                s_hdr[n] = (ro + 2u) | ((b0 >> 4) << 12) | ((((b0 & 15u) << 8) | b1) << 16);
-            rel = nx;
-            n++;
+        // Sparse item: lane j follows chunk j's chain from its true entry up to the first record of
+        // chunk j+1 (the item's end for the last lane) and parses each header (RawData.cpp:106-110).
+        i0 = __builtin_amdgcn_readfirstlane(ce) >> 8;
+        const uint32_t iend = min(R, __builtin_amdgcn_readfirstlane(we.w));
+        n = iend - min(iend, i0);
+        const uint32_t cnext = __shfl_down(ce, 1, 64);
+        if (ABL != 3 && lane < nchunk) {
+            const uint32_t myend = lane + 1u < nchunk ? min(iend, cnext >> 8) : iend;
+            uint32_t rel = 2u * (ce & 255u), idx = ce >> 8;
+            const uint32_t cb = lane * CH7; // my chunk inside the staged bytes
+            while (rel < CH7 && idx < myend) {
+                const uint32_t ro = head + cb + rel;
+                const uint32_t b0 = s_b[ro], b1 = s_b[ro + 1u];
+                const uint32_t nx = rel + 2u + len7_of(b0 >> 4);
+                if (abs + cb + nx > len)
+                    break; // cannot happen for a chunk k7_follow listed
+                s_hdr[idx - i0] = (ro + 2u) | ((b0 >> 4) << 14) | ((((b0 & 15u) << 8) | b1) << 18);
+                rel = nx;
+                idx++;
+            }
         }
-        if (ABL == 2)
+        if (ABL == 2 || ABL == 3)
             n = 0;
     } else {
+    const uint32_t entry = __builtin_amdgcn_readfirstlane(we.w);
+    const uint32_t ph = entry & 255u;
+    i0 = entry >> 8;
     // Dense chunk (runs of 2-byte records: up to 512 per KiB).  Which of the chunk's 512 even offsets start a record of the true chain?  A serial walk
     // costs ~45 scalar instructions per record on one lane; instead the chain is marked by
     // POINTER DOUBLING over all candidates at once: J1[p] = where the record at p ends;
@@ -486,7 +531,7 @@ __global__ __launch_bounds__(64) void k7_records(const Work7 W)
             if (rk < n) {
                 const uint32_t ro = head + 2u * (p0 + t);
                 const uint32_t b0 = s_b[ro], b1 = s_b[ro + 1u];
-                s_hdr[rk] = (ro + 2u) | ((b0 >> 4) << 12) | ((((b0 & 15u) << 8) | b1) << 16);
+                s_hdr[rk] = (ro + 2u) | ((b0 >> 4) << 14) | ((((b0 & 15u) << 8) | b1) << 18);
             }
             rk++;
         }
@@ -504,8 +549,8 @@ __global__ __launch_bounds__(64) void k7_records(const Work7 W)
         const uint32_t q = qb + sub;
         const bool live = q < n;
         const uint32_t h = s_hdr[q];
-        const uint32_t hb = (h >> 12) & 15u, ref = h >> 16;
-        Unpacked U = unpack8<false>(s_b, h & 0xfffu, cls7_of(hb), k, s_tab);
+        const uint32_t hb = (h >> 14) & 15u, ref = h >> 18;
+        Unpacked U = unpack8<false>(s_b, h & 0x3fffu, cls7_of(hb), k, s_tab);
         const u16x2 rr = __builtin_bit_cast(u16x2, ref | (ref << 16));
 #pragma unroll
         for (int i = 0; i < 4; i++) // uint16 wrap (RawData.cpp:492)
