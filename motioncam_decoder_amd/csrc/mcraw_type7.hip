@@ -562,27 +562,40 @@ __global__ __launch_bounds__(64) void k7_records(const Work7 W)
                 *reinterpret_cast<uint4 *>(refs + idx) = make_uint4(U.x[0], U.x[1], U.x[2], U.x[3]);
             continue;
         }
-        // bits stream: validate, narrow to bytes, and add up the byte length of the group
-        uint32_t l8 = 0, bytes_lo = 0, bytes_hi = 0;
-        bool over = false;
+        // bits stream: validate, narrow to bytes, and add up the byte length of the lane's 8 blocks
+        const uint32_t nvalid = live ? min(8u, nblk - min(nblk, idx)) : 0u;
+        if (nvalid < 8u) { // the record's entries past the last block are decoded by the reference but never used
 #pragma unroll
-        for (uint32_t j = 0; j < 8u; j++) {
-            uint32_t v = (U.x[j >> 1] >> (16u * (j & 1u))) & 0xffffu;
-            const bool used = live && idx + j < nblk;
-            if (used && v > 16u) { // would index past ENCODING_BLOCK_LENGTH (RawData.cpp:419)
-                over = true;
-                v = 16u;
-            }
-            l8 += used ? len7_of(v) >> 3 : 0u;
-            if (j < 4u)
-                bytes_lo |= (v & 0xffu) << (8u * j);
-            else
-                bytes_hi |= (v & 0xffu) << (8u * (j - 4u));
+            for (uint32_t i = 0; i < 4u; i++)
+                U.x[i] &= nvalid >= 2u * i + 2u ? 0xffffffffu : nvalid == 2u * i + 1u ? 0xffffu : 0u;
+        }
+        uint32_t c[4], over = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; i++) { // an entry above 16 would index past ENCODING_BLOCK_LENGTH (RawData.cpp:419)
+            c[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, U.x[i]),
+                                                                          __builtin_bit_cast(u16x2, 0x00100010u)));
+            over |= c[i] ^ U.x[i];
         }
         if (over)
             atomicOr(status, MCRAW_E_SIDESTREAM);
+        const uint32_t bytes_lo = __builtin_amdgcn_perm(c[1], c[0], 0x06040200u);
+        const uint32_t bytes_hi = __builtin_amdgcn_perm(c[3], c[2], 0x06040200u);
         if (live)
             *reinterpret_cast<uint2 *>(bits + idx) = make_uint2(bytes_lo, bytes_hi);
+        // LEN[v] / 8 for four entries at a time (RawData.cpp:27-45): two 8-entry byte tables picked by
+        // bit 3, 16 for v == 16; then a byte sum
+        uint32_t l8 = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 2u; i++) {
+            const uint32_t v4 = i ? bytes_hi : bytes_lo;
+            const uint32_t sel = v4 & 0x07070707u;
+            const uint32_t lo = __builtin_amdgcn_perm(0x08060504u, 0x03020100u, sel); // v = 0..7
+            const uint32_t hi = __builtin_amdgcn_perm(0x10101010u, 0x100A0A08u, sel); // v = 8..15
+            const uint32_t g = (v4 >> 3) & 0x01010101u;
+            const uint32_t m = (g << 8) - g;
+            const uint32_t l4 = ((hi & m) | (lo & ~m)) | (v4 & 0x10101010u);
+            l8 = __builtin_amdgcn_sad_u8(l4, 0u, l8);
+        }
         // sum over the lanes of one decode item (ds_swizzle bit-mask mode: lane ^ 1, ^ 2, ^ 4)
         l8 += swz_xor<0x041F>(l8);
         l8 += swz_xor<0x081F>(l8);
