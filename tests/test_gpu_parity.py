@@ -179,6 +179,26 @@ def test_flat_frames_densest_chains(gpu_ctx):
     _check(gpu_ctx, items, expect)
 
 
+def test_flat_and_textured_bands_mix_dense_and_sparse_chunks(gpu_ctx):
+    # bands of constant rows between bands of noise: the side streams alternate between runs of
+    # 2-byte records (dense chunks, listed by pointer doubling) and ordinary records (sparse chunks,
+    # grouped four to a work item), so groups that hold both kinds occur; likewise the legacy chain
+    # alternates between 2-byte and long records inside one k6_rows window
+    rng = np.random.default_rng(77)
+    items, expect = [], []
+    for (w, h, band) in ((2048, 192, 24), (1024, 1536, 512), (1000, 150, 10)):
+        img = rng.integers(0, 4096, size=(h, w), dtype=np.uint16)
+        for y0 in range(0, h, 2 * band):
+            img[y0:y0 + band] = 517
+        for typ, enc, dec in ((7, L.encode7, L.oracle_decode7), (6, L.encode6, L.oracle_decode6)):
+            buf = enc(img)
+            ret, out = dec(buf, w, h)
+            assert ret == w * h and np.array_equal(out, img)
+            items.append((typ, w, h, buf))
+            expect.append((ret, out))
+    _check(gpu_ctx, items, expect)
+
+
 def test_many_small_frames_one_batch(gpu_ctx):
     # 1200 frames of assorted small geometries, both encodings interleaved: exercises the batch
     # indexing (uniform-stride workspace sized by the largest frame, work lists, status mapping)
