@@ -218,6 +218,8 @@ __global__ __launch_bounds__(256) void k7_maps(const Work7 W)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_b[MAPS_CH * CH7 + 32];
     __shared__ uint16_t s_nxt[MAPS_CH * CH7 / 2];
+    constexpr uint32_t HALF7 = CH7 / 2;
+    __shared__ __attribute__((aligned(16))) uint8_t s_stride[MAPS_CH * HALF7 + 16 + 80]; // + head, + the last stride's reach
 
     const uint32_t tid = threadIdx.x;
     const uint32_t sub = tid / PH7, ph = tid - sub * PH7;
@@ -235,25 +237,61 @@ __global__ __launch_bounds__(256) void k7_maps(const Work7 W)
         const uint32_t len = P->len;
         const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
         const uint32_t base16 = abs0 & ~15u, head = abs0 - base16;
-        const uint32_t n16 = (head + MAPS_CH * CH7 + 15u) >> 4;
-        for (uint32_t q = tid; q < n16; q += 256u)
-            reinterpret_cast<uint4 *>(s_b)[q] = ld_b128(rs, base16 + q * 16u);
-        __syncthreads();
-        // every even offset is a candidate header: tabulate its successor once, so the 65
-        // walks of a chunk are chains of 2-byte LDS reads
-        for (uint32_t i = tid; i < MAPS_CH * CH7 / 2; i += 256u)
-            s_nxt[i] = static_cast<uint16_t>(next_of(s_b, head, 2u * i, abs0, len));
-        __syncthreads();
+        const uint32_t n16 = (head + MAPS_CH * CH7 + 15u) >> 4; // <= 194 lines: one per thread
         const uint32_t c = c0 + sub;
-        if (sub < MAPS_CH && c < nchunk) {
-            const uint32_t hi = (sub + 1u) * CH7; // end of this chunk inside the staged bytes
-            uint32_t rel = sub * CH7 + 2u * ph, count = 0;
-            while (rel < hi) { // NODEAD ends the loop too
-                rel = s_nxt[rel >> 1];
-                count += rel != NODEAD ? 1u : 0u;
+        if (len >= MAPS_CH * CH7 + 130u && abs0 <= len - (MAPS_CH * CH7 + 130u)) {
+            // No record that starts in these chunks can reach `len`.  Headers can sit at every
+            // second byte from `head` on; each thread turns the 8 candidates of one 16-byte line
+            // into record strides in half positions, 1 + LEN/2 (RawData.cpp:27-45), so that the 65
+            // walks of a chunk are chains of single-byte LDS reads
+            if (tid < n16) {
+                const uint4 v = ld_b128(rs, base16 + tid * 16u);
+                const uint32_t pick = (head & 1u) ? 0x07050301u : 0x06040200u;
+                uint32_t st[2];
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    const uint32_t h4 = i ? __builtin_amdgcn_perm(v.w, v.z, pick) : __builtin_amdgcn_perm(v.y, v.x, pick);
+                    const uint32_t hb = (h4 >> 4) & 0x0F0F0F0Fu;
+                    const uint32_t sel = hb & 0x07070707u;
+                    const uint32_t lo = __builtin_amdgcn_perm(0x08060504u, 0x03020100u, sel); // LEN/8, bits 0..7
+                    const uint32_t hi = __builtin_amdgcn_perm(0x10101010u, 0x100A0A08u, sel); // LEN/8, bits 8..15
+                    const uint32_t g = (hb >> 3) & 0x01010101u;
+                    const uint32_t m = (g << 8) - g;
+                    st[i] = (((hi & m) | (lo & ~m)) << 2) + 0x01010101u;
+                }
+                reinterpret_cast<uint2 *>(s_stride)[tid] = make_uint2(st[0], st[1]);
             }
-            W.cmap[(static_cast<size_t>(fs) * W.nch + c) * PH7 + ph] =
-                (rel == NODEAD ? DEAD7 : (rel - hi) >> 1) | (count << 8);
+            __syncthreads();
+            if (sub < MAPS_CH && c < nchunk) {
+                // table index u <-> staged byte 2u + (head & 1); chunk `sub` spans HALF7 indices from here
+                const uint8_t *pp = s_stride + (head >> 1) + sub * HALF7 + ph;
+                const uint8_t *const pe = s_stride + (head >> 1) + (sub + 1u) * HALF7;
+                uint32_t count = 0;
+                while (pp < pe) {
+                    pp += *pp;
+                    count++;
+                }
+                W.cmap[(static_cast<size_t>(fs) * W.nch + c) * PH7 + ph] = static_cast<uint32_t>(pp - pe) | (count << 8);
+            }
+        } else {
+            // the stream's last chunks: successor table with the `len` check (a record that would
+            // cross `len` ends the chain, RawData.cpp:419-420)
+            for (uint32_t q = tid; q < n16; q += 256u)
+                reinterpret_cast<uint4 *>(s_b)[q] = ld_b128(rs, base16 + q * 16u);
+            __syncthreads();
+            for (uint32_t i = tid; i < MAPS_CH * CH7 / 2; i += 256u)
+                s_nxt[i] = static_cast<uint16_t>(next_of(s_b, head, 2u * i, abs0, len));
+            __syncthreads();
+            if (sub < MAPS_CH && c < nchunk) {
+                const uint32_t hi = (sub + 1u) * CH7; // end of this chunk inside the staged bytes
+                uint32_t rel = sub * CH7 + 2u * ph, count = 0;
+                while (rel < hi) { // NODEAD ends the loop too
+                    rel = s_nxt[rel >> 1];
+                    count += rel != NODEAD ? 1u : 0u;
+                }
+                W.cmap[(static_cast<size_t>(fs) * W.nch + c) * PH7 + ph] =
+                    (rel == NODEAD ? DEAD7 : (rel - hi) >> 1) | (count << 8);
+            }
         }
         __syncthreads(); // the staging buffers are reused by the next work item
     }
