@@ -103,15 +103,24 @@ __device__ __forceinline__ Unpacked unpack8(const uint8_t *__restrict__ base, ui
 #pragma unroll
     for (int t = 0; t < 3; t++) {
         const uint32_t tm = tms[t];
+        // payload lanes run all terms branch-free (one aligned 8-byte read each); for side-stream
+        // records a term costs three reads and two funnel shifts, and most (class, k) rows have
+        // one term only: skip the ones no lane of the wave needs
+        if (!ALIGNED8 && t > 0 && !__any(tm != 0u))
+            continue;
         const uint2 p = lds_read8<ALIGNED8>(base, blk + term_off(tm));
         const uint32_t m = ((1u << term_bits(tm)) - 1u) * 0x01010101u;
         lo |= ((p.x >> term_shr(tm)) & m) << term_shl(tm);
         hi |= ((p.y >> term_shr(tm)) & m) << term_shl(tm);
     }
     const uint32_t th = row.w; // Decode10's bits 8..9
-    const uint2 ph = lds_read8<ALIGNED8>(base, blk + term_off(th));
-    const uint32_t mh = ((1u << term_bits(th)) - 1u) * 0x01010101u;
-    const uint32_t lo8 = (ph.x >> term_shr(th)) & mh, hi8 = (ph.y >> term_shr(th)) & mh;
+    uint32_t lo8 = 0, hi8 = 0;
+    if (ALIGNED8 || __any(th != 0u)) {
+        const uint2 ph = lds_read8<ALIGNED8>(base, blk + term_off(th));
+        const uint32_t mh = ((1u << term_bits(th)) - 1u) * 0x01010101u;
+        lo8 = (ph.x >> term_shr(th)) & mh;
+        hi8 = (ph.y >> term_shr(th)) & mh;
+    }
     // bytes -> packed u16 pairs: {lo.b0 | lo8.b0 << 8, lo.b1 | lo8.b1 << 8} ...
     u.x[0] = __builtin_amdgcn_perm(lo8, lo, 0x05010400u);
     u.x[1] = __builtin_amdgcn_perm(lo8, lo, 0x07030602u);
