@@ -103,9 +103,12 @@ int mcraw_ctx_synchronize(mcraw_ctx *ctx, int32_t *status, int nframes);
 #define MCRAW_K6_ROWS    6 /* legacy: record decode               */
 #define MCRAW_K_COUNT    7
 
-/* Enable (1) / disable (0) hipEvent bracketing of every kernel launch on the
- * launch stream.  mcraw_ctx_kernel_ms returns, for kernel `id`, the summed
- * duration (ms) and launch count since the last reset (synchronises). */
+/* hipEvent bracketing of kernel launches on the launch stream: 0 = off, 1 = every
+ * kernel, MCRAW_PROFILE_ONLY(id) [| MCRAW_PROFILE_ONLY(id2) ...] = those kernels only
+ * (each bracket costs two event records in the stream).  mcraw_ctx_kernel_ms returns,
+ * for kernel `id`, the summed duration (ms) and launch count since the last reset
+ * (synchronises). */
+#define MCRAW_PROFILE_ONLY(id) (2 << (id))
 int mcraw_ctx_profile(mcraw_ctx *ctx, int enable);
 int mcraw_ctx_kernel_ms(mcraw_ctx *ctx, int id, double *ms, int *launches, int reset);
 

@@ -158,8 +158,15 @@ class Context:
             raise McrawError("mcraw_ctx_synchronize failed (%d): %s" % (rc, self._lib.mcraw_last_error().decode()))
         return list(status)[:nframes]
 
-    def profile(self, enable=True):
-        self._lib.mcraw_ctx_profile(self._h, 1 if enable else 0)
+    def profile(self, enable=True, only=None):
+        """Bracket kernel launches with events: all kernels, or just the names in `only`."""
+        if only:
+            mode = 0
+            for name in only:
+                mode |= 2 << KERNELS[name]
+        else:
+            mode = 1 if enable else 0
+        self._lib.mcraw_ctx_profile(self._h, mode)
 
     def kernel_ms(self, name, reset=False):
         ms = C.c_double()

@@ -84,7 +84,7 @@ struct mcraw_ctx {
     hipStream_t stream = nullptr;
     Slot slots[NSLOT];
     int next_slot = 0;
-    bool profile = false;
+    uint32_t profile = 0; // bit id: bracket launches of kernel id with events
     KStat kstat[MCRAW_K_COUNT];
     std::vector<hipEvent_t> event_pool;
     // last device-memory batch, for mcraw_ctx_synchronize
@@ -138,7 +138,7 @@ struct KTimer { // brackets one launch with events on the launch stream
     hipEvent_t a = nullptr, b = nullptr;
     KTimer(mcraw_ctx *c_, int id_, hipStream_t st_) : c(c_), id(id_), st(st_)
     {
-        if (c->profile) {
+        if (c->profile & (1u << id)) {
             a = get_event(c);
             b = get_event(c);
             if (a && b)
@@ -777,7 +777,7 @@ int mcraw_ctx_profile(mcraw_ctx *c, int enable)
     if (!c)
         return -1;
     std::lock_guard<std::mutex> lk(c->mu);
-    c->profile = enable != 0;
+    c->profile = enable == 1 ? ~0u : static_cast<uint32_t>(enable) >> 1;
     return 0;
 }
 
