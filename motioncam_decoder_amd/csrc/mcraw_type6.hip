@@ -338,6 +338,7 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
         // full pairs: four lanes each, no per-record guards
         const uint32_t qlo = wlo & 1u, qhi = (whi >> 1) - pair0;
         const uint32_t y0 = pair0 / ppr, r0 = pair0 - y0 * ppr; // wave-uniform
+        const uint32_t row0 = y0 * width;
         const uint32_t ntask = qhi > qlo ? 4u * (qhi - qlo) : 0u;
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
@@ -352,7 +353,9 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
             const uint32_t n = r0 + q;
             const uint32_t dy = widerow ? (n >= ppr ? 1u : 0u) : __umul24(n, m20) >> 20;
             x = (n - __umul24(dy, ppr)) * 32u + 8u * qt; // RawData_Legacy.cpp:479-486
-            px = out + (__umul24(y0 + dy, width) + x);
+            // (y0 + dy) * width without a per-lane 32-bit multiply: a wide row (width can exceed 24
+            // bits) advances by at most one row per round, a narrow one has width < 2^14
+            px = out + (row0 + (widerow ? (dy ? width : 0u) : __umul24(dy, width)) + x);
             const u16x2 refs = __builtin_bit_cast(u16x2, refa | (refb << 16));
 #pragma unroll
             for (int j = 0; j < 4; j++)

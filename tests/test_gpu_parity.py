@@ -199,6 +199,22 @@ def test_flat_and_textured_bands_mix_dense_and_sparse_chunks(gpu_ctx):
     _check(gpu_ctx, items, expect)
 
 
+def test_rows_wider_than_24_bits(gpu_ctx):
+    # a strip wider than 2^24 pixels: row offsets and column arithmetic must not assume 24-bit widths
+    rng = np.random.default_rng(2424)
+    w, h = (1 << 24) + 4000, 3
+    img = rng.integers(0, 1024, size=(h, w), dtype=np.uint16)
+    img[:, 5_000_000:9_000_000] = 77 # a long run of 2-byte records / empty blocks in the middle
+    items, expect = [], []
+    for typ, enc, dec in ((6, L.encode6, L.oracle_decode6), (7, L.encode7, L.oracle_decode7)):
+        buf = enc(img)
+        ret, out = dec(buf, w, h)
+        assert ret == w * h and np.array_equal(out, img)
+        items.append((typ, w, h, buf))
+        expect.append((w * h, img))
+    _check(gpu_ctx, items, expect)
+
+
 def test_many_small_frames_one_batch(gpu_ctx):
     # 1200 frames of assorted small geometries, both encodings interleaved: exercises the batch
     # indexing (uniform-stride workspace sized by the largest frame, work lists, status mapping)
