@@ -256,45 +256,52 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
     constexpr uint32_t STAGE = ROWS_CH * CHUNK6 + 64 + 16;
     __shared__ __attribute__((aligned(16))) uint8_t s_bytes[4][STAGE];
     __shared__ __attribute__((aligned(4))) uint16_t s_pos[4][ROWS_CAP + 2]; // indexed from the round's first PAIR
+    __shared__ uint32_t s_ent[4 * ROWS_CH];
 
     const int f = find_frame(blockIdx.x, item_base, nframes);
     const Plan6 *P = plans + f;
     if (*P->status != 0)
-        return;
+        return; // whole workgroup
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t nchunks = P->nchunks, nrec = P->nrec, len = P->len;
     const uint32_t c0 = ((blockIdx.x - item_base[f]) * 4u + wave) * ROWS_CH;
-    if (c0 >= nchunks)
-        return;
+    const bool have = c0 < nchunks;
     // entries of my chunks (lane j) and of the chunk after them (lane ROWS_CH)
     uint32_t e = DEAD;
-    if (lane <= ROWS_CH && c0 + lane < nchunks)
+    if (have && lane <= ROWS_CH && c0 + lane < nchunks)
         e = P->centry[c0 + lane];
     const uint32_t e0 = __builtin_amdgcn_readfirstlane(e);
-    if ((e0 & 255u) == DEAD)
-        return; // the chain ended before this wave's chunks
     const uint32_t I0 = e0 >> 8;
     const uint32_t enext = __shfl(e, ROWS_CH, 64);
     const bool inner = c0 + ROWS_CH < nchunks && (enext & 255u) != DEAD && (enext >> 8) <= nrec;
     const uint32_t Iend = min(nrec, (c0 + ROWS_CH < nchunks) ? (enext >> 8) : nrec);
-    if (I0 >= Iend)
-        return;
-    const uint32_t N = Iend - I0;
+    // live: the chain reaches this wave's chunks and there are records left for them
+    const bool live = have && (e0 & 255u) != DEAD && I0 < Iend;
+    const uint32_t N = live ? Iend - I0 : 0u;
 
     const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
     const uint32_t cs0 = c0 * CHUNK6;
-    uint4 *dst = reinterpret_cast<uint4 *>(s_bytes[wave]);
+    if (live) {
+        uint4 *dst = reinterpret_cast<uint4 *>(s_bytes[wave]);
 #pragma unroll
-    for (uint32_t q = 0; q < (STAGE / 16 + 63) / 64; q++)
-        if (lane + 64u * q < STAGE / 16)
-            dst[lane + 64u * q] = ld_b128(rs, cs0 + (lane + 64u * q) * 16u);
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
+        for (uint32_t q = 0; q < (STAGE / 16 + 63) / 64; q++)
+            if (lane + 64u * q < STAGE / 16)
+                dst[lane + 64u * q] = ld_b128(rs, cs0 + (lane + 64u * q) * 16u);
+        if (lane < ROWS_CH)
+            s_ent[wave * ROWS_CH + lane] = e;
+    }
+    // lean: every chunk of this wave runs to its end, the next entry bounds the last one, no record can
+    // reach `len`, and the records fit one round of the list
+    const bool lean = live && inner && N <= ROWS_CAP && cs0 + STAGE < len;
+    // When that holds for all four waves (everywhere but at the ends of a frame and in runs of tiny
+    // records), ONE wave walks the 16 chunks of the workgroup, a lane each: a walk keeps a wave busy for
+    // ~70 dependent steps whatever the number of walking lanes, so four waves walking four chunks each
+    // would spend four times the issue slots on it.
+    const bool coop = __syncthreads_and(lean) != 0;
 
     const uint8_t *bytes = s_bytes[wave];
     const uint32_t width = static_cast<uint32_t>(P->width);
     const bool fast = P->fast_store != 0u;
-    const bool walker = lane < ROWS_CH && (e & 255u) != DEAD && c0 + lane < nchunks;
     uint16_t *const out = P->out;
 
     // row arithmetic without per-lane division: pairs per row `ppr`; a round spans < 2 rows when
@@ -303,48 +310,20 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
     const bool widerow = ppr >= 512u;
     const uint32_t m20 = widerow ? 0u : ((1u << 20) + ppr - 1u) / ppr;
 
-    for (uint32_t base = 0; base < N; base += ROWS_CAP) {
-        const uint32_t wlo = I0 + base, whi = min(Iend, wlo + ROWS_CAP); // records listed this round
+    // Unpack the records [wlo, whi) listed in s_pos[wave]: four lanes per record pair
+    auto unpack_round = [&](uint32_t wlo, uint32_t whi) {
         const uint32_t pair0 = wlo >> 1;
         const uint32_t *s_pos32 = reinterpret_cast<const uint32_t *>(s_pos[wave]);
-        if (K6_ABL != 3 && walker) {
-            const uint32_t off = lane * CHUNK6;
-            if (inner && N <= ROWS_CAP && cs0 + STAGE < len) {
-                // every chunk of this wave runs to its end, the next entry bounds the last one, and no
-                // record can reach `len`: walk with nothing but the stride decode in the loop
-                const uint8_t *p = bytes + off + 2u * (e & 255u), *const pe = bytes + off + CHUNK6;
-                uint16_t *lp = s_pos[wave] + ((e >> 8) - 2u * pair0);
-                while (p < pe) {
-                    const uint32_t hb = static_cast<uint32_t>(*p) >> 4;
-                    *lp++ = static_cast<uint16_t>(p - bytes);
-                    p += 2u + len6_of(hb);
-                }
-            } else {
-                uint32_t pos = 2u * (e & 255u), idx = e >> 8;
-                while (pos < CHUNK6 && idx < whi) {
-                    const uint32_t nx = pos + 2u + len6_of(static_cast<uint32_t>(bytes[off + pos]) >> 4);
-                    if (cs0 + off + nx >= len)
-                        break; // k6_frame has already failed the frame if records are missing
-                    if (idx >= wlo)
-                        s_pos[wave][idx - 2u * pair0] = static_cast<uint16_t>(off + pos);
-                    pos = nx;
-                    idx++;
-                }
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
-
-        // full pairs: four lanes each, no per-record guards
+        // full pairs: no per-record guards
         const uint32_t qlo = wlo & 1u, qhi = (whi >> 1) - pair0;
         const uint32_t y0 = pair0 / ppr, r0 = pair0 - y0 * ppr; // wave-uniform
         const uint32_t row0 = y0 * width;
         const uint32_t ntask = qhi > qlo ? 4u * (qhi - qlo) : 0u;
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
-        // one task: 8 pixels (even columns from record A, odd columns from record B, uint16 wrap on
-        // the reference add) and where they go
-        auto decode = [&](uint32_t t, u32x4 &o, uint32_t &x, uint16_t *&px) {
+        for (uint32_t t = lane; t < ntask; t += 64u) {
+            // one task: 8 pixels (even columns from record A, odd columns from record B, uint16 wrap
+            // on the reference add) and where they go
             const uint32_t q = qlo + (t >> 2), qt = t & 3u;
             const uint32_t ro2 = s_pos32[q];
             uint32_t va[4], vb[4], refa, refb;
@@ -352,16 +331,15 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
             quad6(bytes, ro2 >> 16, qt, vb, &refb);
             const uint32_t n = r0 + q;
             const uint32_t dy = widerow ? (n >= ppr ? 1u : 0u) : __umul24(n, m20) >> 20;
-            x = (n - __umul24(dy, ppr)) * 32u + 8u * qt; // RawData_Legacy.cpp:479-486
+            const uint32_t x = (n - __umul24(dy, ppr)) * 32u + 8u * qt; // RawData_Legacy.cpp:479-486
             // (y0 + dy) * width without a per-lane 32-bit multiply: a wide row (width can exceed 24
             // bits) advances by at most one row per round, a narrow one has width < 2^14
-            px = out + (row0 + (widerow ? (dy ? width : 0u) : __umul24(dy, width)) + x);
+            uint16_t *px = out + (row0 + (widerow ? (dy ? width : 0u) : __umul24(dy, width)) + x);
             const u16x2 refs = __builtin_bit_cast(u16x2, refa | (refb << 16));
+            u32x4 o;
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 o[j] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, va[j] | (vb[j] << 16)) + refs);
-        };
-        auto store = [&](const u32x4 &o, uint32_t x, uint16_t *px) {
             if (K6_ABL == 1) {
                 if ((o[0] ^ o[1] ^ o[2] ^ o[3]) == 0x12345678u)
                     px[0] = 1;
@@ -373,19 +351,12 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
                     if (x + j < width)
                         px[j] = static_cast<uint16_t>(o[j >> 1] >> (16u * (j & 1u)));
             }
-        };
-        for (uint32_t t = lane; t < ntask; t += 64u) {
-            u32x4 o;
-            uint32_t x;
-            uint16_t *px;
-            decode(t, o, x, px);
-            store(o, x, px);
         }
         // a round that starts on an odd record or ends on an even one leaves half a pair at that end
         if (lane < 8u) {
             const uint32_t side = lane >> 2, qt = lane & 3u;
             const uint32_t rec = side == 0u ? wlo : whi - 1u;
-            const bool need = side == 0u ? (wlo & 1u) != 0u : (whi & 1u) != 0u && !(whi - 1u == wlo && (wlo & 1u));
+            const bool need = side == 0u ? (wlo & 1u) != 0u : (whi & 1u) != 0u;
             if (need && rec >= wlo && rec < whi) {
                 uint32_t v[4], ref;
                 quad6(bytes, s_pos[wave][rec - 2u * pair0], qt, v, &ref);
@@ -401,6 +372,47 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
                 }
             }
         }
+    };
+
+    if (coop) {
+        if (K6_ABL != 3 && wave == 0u && lane < 4u * ROWS_CH) {
+            const uint32_t w = lane / ROWS_CH, j = lane - w * ROWS_CH; // chunk j of wave w
+            const uint32_t ej = s_ent[lane], first = s_ent[w * ROWS_CH] >> 8;
+            const uint8_t *base = s_bytes[w];
+            const uint8_t *p = base + j * CHUNK6 + 2u * (ej & 255u), *const pe = base + (j + 1u) * CHUNK6;
+            uint16_t *lp = s_pos[w] + ((ej >> 8) - 2u * (first >> 1));
+            while (p < pe) { // nothing but the stride decode in the loop
+                const uint32_t hb = static_cast<uint32_t>(*p) >> 4;
+                *lp++ = static_cast<uint16_t>(p - base);
+                p += 2u + len6_of(hb);
+            }
+        }
+        __syncthreads();
+        unpack_round(I0, Iend);
+        return;
+    }
+    if (!live)
+        return;
+    const bool walker = lane < ROWS_CH && (e & 255u) != DEAD && c0 + lane < nchunks;
+    for (uint32_t base = 0; base < N; base += ROWS_CAP) {
+        const uint32_t wlo = I0 + base, whi = min(Iend, wlo + ROWS_CAP); // records listed this round
+        const uint32_t pair0 = wlo >> 1;
+        if (K6_ABL != 3 && walker) {
+            const uint32_t off = lane * CHUNK6;
+            uint32_t pos = 2u * (e & 255u), idx = e >> 8;
+            while (pos < CHUNK6 && idx < whi) {
+                const uint32_t nx = pos + 2u + len6_of(static_cast<uint32_t>(bytes[off + pos]) >> 4);
+                if (cs0 + off + nx >= len)
+                    break; // k6_frame has already failed the frame if records are missing
+                if (idx >= wlo)
+                    s_pos[wave][idx - 2u * pair0] = static_cast<uint16_t>(off + pos);
+                pos = nx;
+                idx++;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        unpack_round(wlo, whi);
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier(); // the list is rewritten by the next round
     }
