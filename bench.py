@@ -134,15 +134,16 @@ def run_timed(torch, dist_mod, ctx, M, wl, steps, warmup, world):
     for i in range(max(0, warmup - 1)):
         ctx.decode_batch(wl.desc_sets[i % nset], mem=M.MEM_DEVICE, stream=streams[i % nset].cuda_stream, want_status=False)
     torch.cuda.synchronize()
-    # untimed: two steps on one stream with every kernel bracketed by events, for the per-kernel breakdown
+    # untimed: a few steps on one stream with every kernel bracketed by events, for the per-kernel breakdown
     names = ("k7_walk", "k7_meta", "k7_scan", "k7_tiles")
     ctx.profile(True)
-    for k in M.KERNELS:
-        ctx.kernel_ms(k, reset=True)
-    for _ in range(2):
+    for i in range(4):
+        if i == 1: # the first step after the synchronise runs on an idle, down-clocked GPU
+            for k in M.KERNELS:
+                ctx.kernel_ms(k, reset=True)
         ctx.decode_batch(wl.descs, mem=M.MEM_DEVICE, stream=streams[0].cuda_stream, want_status=False)
     torch.cuda.synchronize()
-    kms = {k: ctx.kernel_ms(k, reset=True)[0] / 2.0 for k in names}
+    kms = {k: ctx.kernel_ms(k, reset=True)[0] / 3.0 for k in names}
     for t in wl.t_outs:
         t.zero_()
     # timed: only the roofline kernel carries events (each bracket is two event records in the stream)
