@@ -112,6 +112,25 @@ int mcraw_ctx_synchronize(mcraw_ctx *ctx, int32_t *status, int nframes);
 int mcraw_ctx_profile(mcraw_ctx *ctx, int enable);
 int mcraw_ctx_kernel_ms(mcraw_ctx *ctx, int id, double *ms, int *launches, int reset);
 
+/* Optional stage fused behind the decode, for consumers that take the mosaic further on the
+ * device or ship it as a DNG strip (what example.cpp:80-92 hands to the DNG writer: the raw strip,
+ * BlackLevel, BitsPerSample).  It applies to every batch submitted on `ctx` after the call;
+ * NULL (or flags 0) restores the reference's output, the plain uint16 mosaic.
+ *   MCRAW_POST_BLACK   sample = max(sample - black[(row & 1) * 2 + (col & 1)], 0)   (after the decode)
+ *   MCRAW_POST_PACK12  rows are written as 12-bit strips: ceil(width * 12 / 8) bytes per row, rows
+ *                      back to back, samples MSB-first, 3 bytes per 2 samples (TIFF / DNG
+ *                      BitsPerSample = 12, FillOrder 1); samples above 4095 saturate.  `out` must be
+ *                      2-byte aligned (4-byte aligned and width % 8 == 0 for the vector-store path);
+ *                      `out_capacity` still counts uint16 units (2 bytes) of the buffer and `written`
+ *                      still counts samples. */
+#define MCRAW_POST_BLACK  1u
+#define MCRAW_POST_PACK12 2u
+typedef struct mcraw_post {
+    uint32_t flags;
+    uint16_t black[4];
+} mcraw_post;
+int mcraw_ctx_set_post(mcraw_ctx *ctx, const mcraw_post *post);
+
 /* Pinned host memory for MCRAW_MEM_HOST batches (hipHostMalloc / hipHostFree). */
 void *mcraw_host_alloc(size_t bytes);
 void mcraw_host_free(void *p);

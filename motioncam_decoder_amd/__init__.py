@@ -30,8 +30,15 @@ KERNELS = {"k7_walk": 0, "k7_meta": 1, "k7_scan": 2, "k7_tiles": 3, "k6_maps": 4
 ABI_SYMBOLS = [
     "mcraw_ctx_create", "mcraw_ctx_destroy", "mcraw_last_error", "mcraw_decode7", "mcraw_decode6",
     "mcraw_decode_batch", "mcraw_ctx_synchronize", "mcraw_ctx_profile", "mcraw_ctx_kernel_ms",
-    "mcraw_host_alloc", "mcraw_host_free",
+    "mcraw_host_alloc", "mcraw_host_free", "mcraw_ctx_set_post",
 ]
+
+POST_BLACK, POST_PACK12 = 1, 2
+
+
+class Post(C.Structure):
+    """struct mcraw_post (include/mcraw_hip.h)."""
+    _fields_ = [("flags", C.c_uint32), ("black", C.c_uint16 * 4)]
 
 
 class McrawError(RuntimeError):
@@ -100,6 +107,8 @@ def load():
     lib.mcraw_host_alloc.argtypes = [C.c_size_t]
     lib.mcraw_host_free.restype = None
     lib.mcraw_host_free.argtypes = [C.c_void_p]
+    lib.mcraw_ctx_set_post.restype = C.c_int
+    lib.mcraw_ctx_set_post.argtypes = [C.c_void_p, C.POINTER(Post)]
     _lib = lib
     return lib
 
@@ -157,6 +166,23 @@ class Context:
         if rc != 0:
             raise McrawError("mcraw_ctx_synchronize failed (%d): %s" % (rc, self._lib.mcraw_last_error().decode()))
         return list(status)[:nframes]
+
+    def set_post(self, black=None, pack12=False):
+        """Fused post-decode stage of the batches to come: black levels (4 values, CFA order
+        (row & 1) * 2 + (col & 1)) and/or 12-bit strip rows; no arguments = the plain uint16 mosaic."""
+        if black is None and not pack12:
+            rc = self._lib.mcraw_ctx_set_post(self._h, None)
+        else:
+            p = Post()
+            if black is not None:
+                p.flags |= POST_BLACK
+                for i in range(4):
+                    p.black[i] = int(black[i])
+            if pack12:
+                p.flags |= POST_PACK12
+            rc = self._lib.mcraw_ctx_set_post(self._h, C.byref(p))
+        if rc != 0:
+            raise McrawError("mcraw_ctx_set_post failed (%d): %s" % (rc, self._lib.mcraw_last_error().decode()))
 
     def profile(self, enable=True, only=None):
         """Bracket kernel launches with events: all kernels, or just the names in `only`."""

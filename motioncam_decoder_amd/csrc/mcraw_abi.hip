@@ -23,7 +23,8 @@ void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st);
 void launch_k6_maps(const Plan6 *plans, const uint32_t *item_base, int nframes, uint32_t nitems, hipStream_t st);
 void launch_k6_resolve(const Plan6 *plans, const uint32_t *super_base, int nframes, uint32_t nsuper_items,
                        hipStream_t st);
-void launch_k6_rows(const Plan6 *plans, const uint32_t *item_base, int nframes, uint32_t nitems, hipStream_t st);
+void launch_k6_rows(const Plan6 *plans, const uint32_t *item_base, int nframes, uint32_t nitems, const Post &post,
+                    hipStream_t st);
 } // namespace mcraw
 
 using namespace mcraw;
@@ -85,6 +86,7 @@ struct mcraw_ctx {
     Slot slots[NSLOT];
     int next_slot = 0;
     uint32_t profile = 0; // bit id: bracket launches of kernel id with events
+    Post post{0, 0, 0};   // fused post-decode stage of the batches to come (mcraw_ctx_set_post)
     KStat kstat[MCRAW_K_COUNT];
     std::vector<hipEvent_t> event_pool;
     // last device-memory batch, for mcraw_ctx_synchronize
@@ -201,7 +203,9 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
             status[i] = MCRAW_E_ARGS;
             continue;
         }
-        const bool fast = (reinterpret_cast<uintptr_t>(out) % 16 == 0) && (f.width % 8 == 0);
+        const uint32_t pmode = c->post.mode;
+        // vector stores: 16-byte rows pieces of uint16, or 12-byte pieces of a 12-bit strip (dword aligned)
+        const bool fast = (reinterpret_cast<uintptr_t>(out) % ((pmode & POST_PACK12) ? 4 : 16) == 0) && (f.width % 8 == 0);
         if (f.type == MCRAW_TYPE_BLOCK) {
             Plan7 p{};
             p.in = in;
@@ -221,7 +225,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
                 status[i] = MCRAW_E_HEADER;
                 continue;
             }
-            if (f.out_capacity < static_cast<size_t>(f.width) * static_cast<size_t>(p.rows)) {
+            if (f.out_capacity * 2 < static_cast<size_t>(p.rows) * post_row_bytes(static_cast<uint32_t>(f.width), pmode)) {
                 status[i] = MCRAW_E_CAPACITY;
                 continue;
             }
@@ -238,7 +242,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
             p.len = static_cast<uint32_t>(f.len);
             p.width = f.width;
             p.height = f.height;
-            if (f.out_capacity < static_cast<size_t>(f.width) * static_cast<size_t>(f.height)) {
+            if (f.out_capacity * 2 < static_cast<size_t>(f.height) * post_row_bytes(static_cast<uint32_t>(f.width), pmode)) {
                 status[i] = MCRAW_E_CAPACITY;
                 continue;
             }
@@ -357,6 +361,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         W.grp_off = reinterpret_cast<uint32_t *>(dev + w_grp);
         W.Rmax = static_cast<uint32_t>(Rmax);
         W.n7 = n7;
+        W.post = c->post;
         for (uint32_t stage : {MCRAW_K7_WALK, MCRAW_K7_META, MCRAW_K7_SCAN, MCRAW_K7_TILES}) {
             KTimer t(c, static_cast<int>(stage), st);
             launch_k7(W, stage, st);
@@ -374,7 +379,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         }
         {
             KTimer t(c, MCRAW_K6_ROWS, st);
-            launch_k6_rows(dp, reinterpret_cast<const uint32_t *>(dev + L.row_base), n6, nrow, st);
+            launch_k6_rows(dp, reinterpret_cast<const uint32_t *>(dev + L.row_base), n6, nrow, c->post, st);
         }
     }
     HIP_TRY(hipGetLastError());
@@ -556,7 +561,7 @@ int decode_host(mcraw_ctx *c, const mcraw_frame *frames, int n, size_t *written,
             const mcraw_frame &f = frames[first + i];
             if (!dout[i] || !din[i] || f.width <= 0 || f.height <= 0)
                 continue;
-            size_t nbytes = std::min(f.out_capacity, static_cast<size_t>(f.width) * f.height) * 2;
+            size_t nbytes = std::min(f.out_capacity * 2, static_cast<size_t>(f.height) * post_row_bytes(static_cast<uint32_t>(f.width), c->post.mode));
             HIP_TRY(hipMemcpyAsync(f.out, dout[i], nbytes, hipMemcpyDeviceToHost, st));
         }
         HIP_TRY(hipEventRecord(s.done, st));
@@ -598,7 +603,7 @@ int decode_host(mcraw_ctx *c, const mcraw_frame *frames, int n, size_t *written,
             size_t so = 0;
             if (int rc = submit(c, s, &f, 1, &g, &din, &dout, st, &so))
                 return rc;
-            size_t nbytes = std::min(f.out_capacity, static_cast<size_t>(f.width) * f.height) * 2;
+            size_t nbytes = std::min(f.out_capacity * 2, static_cast<size_t>(f.height) * post_row_bytes(static_cast<uint32_t>(f.width), c->post.mode));
             HIP_TRY(hipMemcpyAsync(f.out, dout, nbytes, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipEventRecord(s.done, st));
             s.busy = true;
@@ -770,6 +775,31 @@ size_t mcraw_decode7(uint16_t *output, int width, int height, const uint8_t *inp
 size_t mcraw_decode6(uint16_t *output, int width, int height, const uint8_t *input, size_t len)
 {
     return decode_one(MCRAW_TYPE_LEGACY, output, width, height, input, len);
+}
+
+int mcraw_ctx_set_post(mcraw_ctx *c, const mcraw_post *post)
+{
+    if (!c)
+        return -1;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!post) {
+        c->post = Post{0, 0, 0};
+        return 0;
+    }
+    if ((post->flags & ~(MCRAW_POST_BLACK | MCRAW_POST_PACK12)) != 0u) {
+        g_err = "mcraw: unknown post-stage flags";
+        return -1;
+    }
+    Post p{0, 0, 0};
+    if (post->flags & MCRAW_POST_BLACK) {
+        p.mode |= POST_BLACK;
+        p.black01 = static_cast<uint32_t>(post->black[0]) | (static_cast<uint32_t>(post->black[1]) << 16);
+        p.black23 = static_cast<uint32_t>(post->black[2]) | (static_cast<uint32_t>(post->black[3]) << 16);
+    }
+    if (post->flags & MCRAW_POST_PACK12)
+        p.mode |= POST_PACK12;
+    c->post = p;
+    return 0;
 }
 
 int mcraw_ctx_profile(mcraw_ctx *c, int enable)

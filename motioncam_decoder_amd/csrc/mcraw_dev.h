@@ -99,4 +99,85 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
     return v;
 }
 
+
+// ---- fused post-decode stage (Post in mcraw_plan.h) ---------------------------------------------
+//
+// 8 consecutive samples of row y starting at an even column arrive as four dwords of (even column |
+// odd column << 16).  post_black: saturating subtraction of the row's two black levels.  post_pack12:
+// the same 8 samples as 12 bytes of an MSB-first 12-bit stream (sample pair a, b -> a>>4,
+// (a&15)<<4 | b>>8, b&255), samples above 4095 saturate.
+typedef uint16_t mcraw_u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void post_black(uint32_t p[4], const Post &post, uint32_t y)
+{
+    const mcraw_u16x2 bl = __builtin_bit_cast(mcraw_u16x2, (y & 1u) ? post.black23 : post.black01);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        p[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(mcraw_u16x2, p[i]), bl));
+}
+
+__device__ __forceinline__ void post_pack12(const uint32_t p[4], uint32_t o[3])
+{
+    uint32_t t[4]; // 24-bit big-endian groups a << 12 | b
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t c = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(mcraw_u16x2, p[i]),
+                                                                                  __builtin_bit_cast(mcraw_u16x2, 0x0FFF0FFFu)));
+        t[i] = ((c << 12) & 0x00FFF000u) | (c >> 16);
+    }
+    // memory order: t0.b2 t0.b1 t0.b0 | t1.b2 t1.b1 t1.b0 | ...
+    o[0] = __builtin_amdgcn_perm(t[1], t[0], 0x06000102u);
+    o[1] = __builtin_amdgcn_perm(t[2], t[1], 0x05060001u);
+    o[2] = __builtin_amdgcn_perm(t[3], t[2], 0x04050600u);
+}
+
+// Store 8 samples (columns x..x+7, x % 8 == 0, of which the first `n` exist) of row y in the
+// post-stage layout.  `quick`: rows are dword multiples and the buffer is dword aligned (12-bit
+// form) / 16-byte friendly (16-bit form).
+template <bool NT>
+__device__ __forceinline__ void post_store8(uint16_t *out, const Post &post, uint32_t width, uint32_t y, uint32_t x,
+                                            uint32_t p[4], uint32_t n, bool quick)
+{
+    if (post.mode & POST_BLACK)
+        post_black(p, post, y);
+    if (post.mode & POST_PACK12) {
+        uint32_t o[3];
+        post_pack12(p, o);
+        uint8_t *dst = reinterpret_cast<uint8_t *>(out) + static_cast<size_t>(y) * post_row_bytes(width, post.mode) + (x >> 3) * 12u;
+        if (quick && n == 8u) {
+            typedef uint32_t u32x3 __attribute__((ext_vector_type(3), aligned(4)));
+            const u32x3 v = {o[0], o[1], o[2]};
+            if (NT)
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x3 *>(dst));
+            else
+                *reinterpret_cast<u32x3 *>(dst) = v;
+        } else { // cropped or unaligned row: bytes; an odd last sample owns the high nibble of its second byte
+            const uint32_t nb = (n * 12u + 7u) >> 3;
+#pragma unroll
+            for (uint32_t i = 0; i < 12u; i++)
+                if (i < nb) {
+                    uint32_t b = (o[i >> 2] >> (8u * (i & 3u))) & 0xffu;
+                    if ((n & 1u) && i == nb - 1u)
+                        b &= 0xf0u;
+                    dst[i] = static_cast<uint8_t>(b);
+                }
+        }
+        return;
+    }
+    uint16_t *dst = out + static_cast<size_t>(y) * width + x;
+    if (quick && n == 8u) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = {p[0], p[1], p[2], p[3]};
+        if (NT)
+            __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst));
+        else
+            *reinterpret_cast<u32x4 *>(dst) = v;
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i < 8u; i++)
+            if (i < n)
+                dst[i] = static_cast<uint16_t>(p[i >> 1] >> (16u * (i & 1u)));
+    }
+}
+
 } // namespace mcraw

@@ -27,6 +27,21 @@ constexpr int SPAN_MAX = 64 * 128; // largest payload span of one group (all raw
 constexpr int CH7 = 1024;          // bytes of side stream per transition-map chunk
 constexpr int PH7 = 65;            // entry offsets 0,2,..,128 (record stride 2 + LEN <= 130, all even)
 
+// Optional stage fused behind the decode (what a DNG writer does next with the mosaic,
+// example.cpp:80-92): black-level subtraction and 12-bit strip packing.  Batch-wide, passed by value.
+struct Post {
+    uint32_t mode;             // POST_* bits; 0 = plain uint16 mosaic (the reference's output)
+    uint32_t black01, black23; // black levels of CFA positions (row & 1, col & 1): (0,0) | (0,1) << 16 and (1,0) | (1,1) << 16
+};
+constexpr uint32_t POST_BLACK = 1;  // sample = max(sample - black[row & 1][col & 1], 0)
+constexpr uint32_t POST_PACK12 = 2; // rows of min(sample, 4095) packed MSB-first, 3 bytes per 2 samples (TIFF/DNG BitsPerSample 12)
+
+// Bytes of one output row of `width` samples.
+__host__ __device__ inline uint32_t post_row_bytes(uint32_t width, uint32_t mode)
+{
+    return (mode & POST_PACK12) ? (width * 12u + 7u) >> 3 : width * 2u;
+}
+
 // Per-frame plan of the current ("type 7") encoding; lives in HBM for the
 // duration of one batch.
 struct Plan7 {
@@ -54,7 +69,8 @@ struct Work7 {
     uint32_t *centry;    // [n7][2][nch]      resolved entry of every chunk (phase | first record << 8)
     uint4 *sinfo;        // [n7][2]           per stream: first record offset, chunks to map, extent hinted, -
     uint4 *list_maps;    // work list of k7_maps:    (stream, first of 3 chunks, its byte offset, chunks of the stream)
-    uint4 *list_recs;    // work list of k7_records: (stream, chunk, its byte offset, entry phase | first record << 8)
+    uint4 *list_recs;    // work lists of k7_records: sparse items (stream, first chunk | chunks << 24, byte offset, end of
+                         // the record range) from the front, dense items (stream, records, byte offset, entry) from the back
     uint32_t *counters;  // [0] k7_maps items, [1] sparse / [2] dense k7_records items (zeroed by the table upload)
     uint32_t list_cap;   // capacity of list_recs (dense items are filled in from the back)
     uint8_t *bits;       // [n7][Rmax*64]  decoded `bits` stream  (:557)
@@ -63,6 +79,7 @@ struct Work7 {
     uint32_t Rmax;       // largest ngroups in the batch
     uint32_t nch;        // side-stream chunks planned per stream (covers Rmax records of 130 bytes)
     int32_t n7;
+    Post post;           // fused post-decode stage (mode 0: none)
 };
 
 // Per-frame plan of the legacy ("type 6") encoding.

@@ -235,27 +235,33 @@ __device__ __forceinline__ void quad6(const uint8_t *__restrict__ bytes, uint32_
     v[3] = __builtin_amdgcn_ubfe(static_cast<uint32_t>(W >> ((64u - 4u * sb) & 63u)), 0u, sb);
 }
 
-// One wave per ROWS_CH consecutive chunks (4 KiB of stream).  Lane j < ROWS_CH walks chunk j from
-// its resolved entry and notes where every record starts; the records of the wave form one
-// contiguous index range, so the list is flat.  Then ALL lanes unpack, four lanes per record pair:
-// a lane owns samples 4q..4q+3 of the even-column record and of the odd-column record = 8
-// consecutive pixels = one 16-byte store; 8 lanes fill a 128-byte line.  (A wave-uniform walk of
-// ONE chunk per wave spent 64 lanes on a scalar chain and made this kernel issue-bound; more chunks
-// per wave spread the walk over more lanes but cost LDS, and 4 measured best: 0.261 ms against
-// 0.274 ms with 8 on 32 x 12 MP.)
+// One wave per ROWS_CH consecutive chunks (4 KiB of stream), four waves per workgroup.  Lanes walk
+// one chunk each from its resolved entry and note where every record starts; the records of the wave
+// form one contiguous index range, so the list is flat.  Then ALL lanes unpack, four lanes per record
+// PAIR: a lane owns samples 4q..4q+3 of the even-column record and of the odd-column record = 8
+// consecutive pixels = one 16-byte store; 8 lanes fill a 128-byte line.
+//
+// A wave owns the pairs whose EVEN record starts in its chunks.  When its range ends on an even
+// record, the odd partner starts right behind it, at most 32 bytes into the next wave's first chunk and
+// inside this wave's staged slack (STAGE); when its range starts on an odd record, that record belongs
+// to the previous wave's last pair.  So every pair is decoded whole, by one lane quartet.
+//
+// (A wave-uniform walk of ONE chunk per wave spent 64 lanes on a scalar chain and made this kernel
+// issue-bound; more chunks per wave spread the walk over more lanes but cost LDS, and 4 measured best.)
 constexpr uint32_t ROWS_CAP = 128u * ROWS_CH; // records listed per round (typical: ~70 per chunk; worst case 512 -> 4 rounds)
-static_assert(ROWS_CAP <= 1024u, "the division-free row arithmetic in k6_rows assumes at most 512 pairs per round");
+static_assert(ROWS_CAP <= 1024u && ROWS_CAP % 2u == 0u, "the division-free row arithmetic in k6_rows assumes at most 512 pairs per round");
 
 #ifndef K6_ABL
 #define K6_ABL 0 // timing experiments only: 1 no stores, 3 no walk
 #endif
 
+template <bool POST>
 __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, const uint32_t *__restrict__ item_base,
-                                               int nframes)
+                                               int nframes, const Post post)
 {
-    constexpr uint32_t STAGE = ROWS_CH * CHUNK6 + 64 + 16;
+    constexpr uint32_t STAGE = ROWS_CH * CHUNK6 + 64 + 16; // + the reach of a record that starts 32 bytes past the chunks
     __shared__ __attribute__((aligned(16))) uint8_t s_bytes[4][STAGE];
-    __shared__ __attribute__((aligned(4))) uint16_t s_pos[4][ROWS_CAP + 2]; // indexed from the round's first PAIR
+    __shared__ __attribute__((aligned(4))) uint16_t s_pos[4][ROWS_CAP + 2]; // record r of a round at [r - wlo], wlo even
     __shared__ uint32_t s_ent[4 * ROWS_CH];
 
     const int f = find_frame(blockIdx.x, item_base, nframes);
@@ -271,13 +277,16 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
     if (have && lane <= ROWS_CH && c0 + lane < nchunks)
         e = P->centry[c0 + lane];
     const uint32_t e0 = __builtin_amdgcn_readfirstlane(e);
-    const uint32_t I0 = e0 >> 8;
     const uint32_t enext = __shfl(e, ROWS_CH, 64);
     const bool inner = c0 + ROWS_CH < nchunks && (enext & 255u) != DEAD && (enext >> 8) <= nrec;
+    // records that start in my chunks: [I0, Iend); nrec is even (two records per 32 columns)
+    const uint32_t I0 = e0 >> 8;
     const uint32_t Iend = min(nrec, (c0 + ROWS_CH < nchunks) ? (enext >> 8) : nrec);
-    // live: the chain reaches this wave's chunks and there are records left for them
-    const bool live = have && (e0 & 255u) != DEAD && I0 < Iend;
-    const uint32_t N = live ? Iend - I0 : 0u;
+    // records I decode: the pairs whose even record is among them
+    const uint32_t R0 = (I0 + 1u) & ~1u, R1 = (Iend + 1u) & ~1u;
+    // live: the chain reaches this wave's chunks and there are pairs for it
+    const bool live = have && (e0 & 255u) != DEAD && R0 < R1;
+    const uint32_t N = live ? R1 - R0 : 0u;
 
     const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
     const uint32_t cs0 = c0 * CHUNK6;
@@ -310,21 +319,19 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
     const bool widerow = ppr >= 512u;
     const uint32_t m20 = widerow ? 0u : ((1u << 20) + ppr - 1u) / ppr;
 
-    // Unpack the records [wlo, whi) listed in s_pos[wave]: four lanes per record pair
+    // Unpack the pairs of records [wlo, whi) (both even) listed in s_pos[wave]: four lanes per pair
     auto unpack_round = [&](uint32_t wlo, uint32_t whi) {
         const uint32_t pair0 = wlo >> 1;
         const uint32_t *s_pos32 = reinterpret_cast<const uint32_t *>(s_pos[wave]);
-        // full pairs: no per-record guards
-        const uint32_t qlo = wlo & 1u, qhi = (whi >> 1) - pair0;
         const uint32_t y0 = pair0 / ppr, r0 = pair0 - y0 * ppr; // wave-uniform
         const uint32_t row0 = y0 * width;
-        const uint32_t ntask = qhi > qlo ? 4u * (qhi - qlo) : 0u;
+        const uint32_t ntask = 2u * (whi - wlo);
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
         for (uint32_t t = lane; t < ntask; t += 64u) {
             // one task: 8 pixels (even columns from record A, odd columns from record B, uint16 wrap
             // on the reference add) and where they go
-            const uint32_t q = qlo + (t >> 2), qt = t & 3u;
+            const uint32_t q = t >> 2, qt = t & 3u;
             const uint32_t ro2 = s_pos32[q];
             uint32_t va[4], vb[4], refa, refb;
             quad6(bytes, ro2 & 0xffffu, qt, va, &refa);
@@ -332,19 +339,25 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
             const uint32_t n = r0 + q;
             const uint32_t dy = widerow ? (n >= ppr ? 1u : 0u) : __umul24(n, m20) >> 20;
             const uint32_t x = (n - __umul24(dy, ppr)) * 32u + 8u * qt; // RawData_Legacy.cpp:479-486
-            // (y0 + dy) * width without a per-lane 32-bit multiply: a wide row (width can exceed 24
-            // bits) advances by at most one row per round, a narrow one has width < 2^14
-            uint16_t *px = out + (row0 + (widerow ? (dy ? width : 0u) : __umul24(dy, width)) + x);
             const u16x2 refs = __builtin_bit_cast(u16x2, refa | (refb << 16));
-            u32x4 o;
+            uint32_t o[4];
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 o[j] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, va[j] | (vb[j] << 16)) + refs);
+            if (POST) { // black levels / 12-bit strip rows (mcraw_dev.h); padded columns are cropped
+                if (x < width)
+                    post_store8<true>(out, post, width, y0 + dy, x, o, min(8u, width - x), fast);
+                continue;
+            }
+            // (y0 + dy) * width without a per-lane 32-bit multiply: a wide row (width can exceed 24
+            // bits) advances by at most one row per round, a narrow one has width < 2^14
+            uint16_t *px = out + (row0 + (widerow ? (dy ? width : 0u) : __umul24(dy, width)) + x);
             if (K6_ABL == 1) {
                 if ((o[0] ^ o[1] ^ o[2] ^ o[3]) == 0x12345678u)
                     px[0] = 1;
             } else if (fast && x + 8u <= width) {
-                __builtin_nontemporal_store(o, reinterpret_cast<u32x4 *>(px));
+                const u32x4 v = {o[0], o[1], o[2], o[3]};
+                __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(px));
             } else {
 #pragma unroll
                 for (uint32_t j = 0; j < 8u; j++) // padded columns are cropped (RawData_Legacy.cpp:490)
@@ -352,60 +365,49 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
                         px[j] = static_cast<uint16_t>(o[j >> 1] >> (16u * (j & 1u)));
             }
         }
-        // a round that starts on an odd record or ends on an even one leaves half a pair at that end
-        if (lane < 8u) {
-            const uint32_t side = lane >> 2, qt = lane & 3u;
-            const uint32_t rec = side == 0u ? wlo : whi - 1u;
-            const bool need = side == 0u ? (wlo & 1u) != 0u : (whi & 1u) != 0u;
-            if (need && rec >= wlo && rec < whi) {
-                uint32_t v[4], ref;
-                quad6(bytes, s_pos[wave][rec - 2u * pair0], qt, v, &ref);
-                const uint32_t y = rec / (2u * ppr);
-                const uint32_t rr = rec - y * 2u * ppr;
-                const uint32_t x = (rr >> 1) * 32u + 8u * qt + (rr & 1u);
-                uint16_t *px = out + (static_cast<size_t>(y) * width + x);
-                if (K6_ABL != 1) {
-#pragma unroll
-                    for (uint32_t j = 0; j < 4u; j++)
-                        if (x + 2u * j < width)
-                            px[2u * j] = static_cast<uint16_t>(v[j] + ref);
-                }
-            }
-        }
     };
 
     if (coop) {
         if (K6_ABL != 3 && wave == 0u && lane < 4u * ROWS_CH) {
             const uint32_t w = lane / ROWS_CH, j = lane - w * ROWS_CH; // chunk j of wave w
-            const uint32_t ej = s_ent[lane], first = s_ent[w * ROWS_CH] >> 8;
+            const uint32_t ej = s_ent[lane], first = ((s_ent[w * ROWS_CH] >> 8) + 1u) & ~1u;
             const uint8_t *base = s_bytes[w];
             const uint8_t *p = base + j * CHUNK6 + 2u * (ej & 255u), *const pe = base + (j + 1u) * CHUNK6;
-            uint16_t *lp = s_pos[w] + ((ej >> 8) - 2u * (first >> 1));
+            uint16_t *lp = s_pos[w] + static_cast<int32_t>((ej >> 8) - first); // wave w's first record sits at [-1] when it is odd:
+            if ((ej >> 8) < first) {                     // it belongs to the previous wave's last pair
+                p += 2u + len6_of(static_cast<uint32_t>(*p) >> 4);
+                lp++;
+            }
             while (p < pe) { // nothing but the stride decode in the loop
                 const uint32_t hb = static_cast<uint32_t>(*p) >> 4;
                 *lp++ = static_cast<uint16_t>(p - base);
                 p += 2u + len6_of(hb);
             }
+            // the walk of a wave's last chunk stops on the next wave's first record: the partner of my
+            // last record when my range ends on an even one (lp is then at an odd list index)
+            if (j == ROWS_CH - 1u && ((lp - s_pos[w]) & 1))
+                *lp = static_cast<uint16_t>(p - base);
         }
         __syncthreads();
-        unpack_round(I0, Iend);
+        unpack_round(R0, R1);
         return;
     }
     if (!live)
         return;
     const bool walker = lane < ROWS_CH && (e & 255u) != DEAD && c0 + lane < nchunks;
+    // the last walking lane carries on past its chunk for the partner of an even last record
+    const bool lastw = walker && (lane + 1u == ROWS_CH || c0 + lane + 1u >= nchunks);
     for (uint32_t base = 0; base < N; base += ROWS_CAP) {
-        const uint32_t wlo = I0 + base, whi = min(Iend, wlo + ROWS_CAP); // records listed this round
-        const uint32_t pair0 = wlo >> 1;
+        const uint32_t wlo = R0 + base, whi = min(R1, wlo + ROWS_CAP); // records listed this round (both even)
         if (K6_ABL != 3 && walker) {
             const uint32_t off = lane * CHUNK6;
             uint32_t pos = 2u * (e & 255u), idx = e >> 8;
-            while (pos < CHUNK6 && idx < whi) {
+            while (idx < whi && (pos < CHUNK6 || (lastw && idx < R1))) {
                 const uint32_t nx = pos + 2u + len6_of(static_cast<uint32_t>(bytes[off + pos]) >> 4);
                 if (cs0 + off + nx >= len)
                     break; // k6_frame has already failed the frame if records are missing
                 if (idx >= wlo)
-                    s_pos[wave][idx - 2u * pair0] = static_cast<uint16_t>(off + pos);
+                    s_pos[wave][idx - wlo] = static_cast<uint16_t>(off + pos);
                 pos = nx;
                 idx++;
             }
@@ -433,9 +435,13 @@ void launch_k6_resolve(const Plan6 *plans, const uint32_t *super_base, int nfram
     hipLaunchKernelGGL(k6_chunks, dim3(nsuper_items), dim3(64), 0, st, plans, super_base, nframes);
 }
 
-void launch_k6_rows(const Plan6 *plans, const uint32_t *item_base, int nframes, uint32_t nitems, hipStream_t st)
+void launch_k6_rows(const Plan6 *plans, const uint32_t *item_base, int nframes, uint32_t nitems, const Post &post,
+                    hipStream_t st)
 {
-    hipLaunchKernelGGL(k6_rows, dim3(nitems), dim3(256), 0, st, plans, item_base, nframes);
+    if (post.mode != 0u)
+        hipLaunchKernelGGL(k6_rows<true>, dim3(nitems), dim3(256), 0, st, plans, item_base, nframes, post);
+    else
+        hipLaunchKernelGGL(k6_rows<false>, dim3(nitems), dim3(256), 0, st, plans, item_base, nframes, post);
 }
 
 } // namespace mcraw

@@ -749,12 +749,16 @@ __device__ __forceinline__ ItemS item_scalars(const Work7 &W, uint32_t item)
 
 // Store 8 consecutive pixels (16 B) of row y starting at column x, cropped to `width`
 // (RawData.cpp:598-608 copies `width` pixels of the coded row).
-template <bool NT = false>
-__device__ __forceinline__ void store_px8(const ItemS &I, uint32_t y, uint32_t x, const uint32_t p[4])
+template <bool NT = false, bool POST = false>
+__device__ __forceinline__ void store_px8(const ItemS &I, const Post &post, uint32_t y, uint32_t x, uint32_t p[4])
 {
     const uint32_t width = static_cast<uint32_t>(I.width);
     if (y >= static_cast<uint32_t>(I.rows) || x >= width)
         return;
+    if (POST) { // black levels / 12-bit strip rows (mcraw_dev.h)
+        post_store8<NT>(I.out, post, width, y, x, p, min(8u, width - x), I.fast != 0u);
+        return;
+    }
     uint16_t *dst = I.out + static_cast<size_t>(y) * static_cast<size_t>(width) + x;
     if (I.fast && x + 8u <= width) {
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -781,9 +785,10 @@ __device__ __forceinline__ void store_px8(const ItemS &I, uint32_t y, uint32_t x
 //
 // ABL (diagnostic builds only, MCRAW_ABLATE): 0 = product; 1 = no global stores;
 // 2 = no unpack arithmetic; 3 (caller) = no payload loads.
-template <int ABL = 0, bool NT = false>
-__device__ __forceinline__ void item_decode(const ItemS &I, uint32_t tt, uint32_t r, uint32_t k, const uint8_t *s_pay,
-                                            const uint32_t *s_blk, const uint16_t *s_ref, const uint4 *s_tab)
+template <int ABL = 0, bool NT = false, bool POST = false>
+__device__ __forceinline__ void item_decode(const ItemS &I, const Post &post, uint32_t tt, uint32_t r, uint32_t k,
+                                            const uint8_t *s_pay, const uint32_t *s_blk, const uint16_t *s_ref,
+                                            const uint4 *s_tab)
 {
     const uint32_t tile = I.g * ITEM_TILES + tt;
     if (!I.valid || tile * 4u >= I.nblk) // uniform over the 16 lanes of a tile
@@ -834,8 +839,8 @@ __device__ __forceinline__ void item_decode(const ItemS &I, uint32_t tt, uint32_
     }
     const uint32_t x = 64u * tx + 8u * (2u * (k & 3u) + (k >> 2));
     const uint32_t y = 4u * ty + r;
-    store_px8<NT>(I, y, x, p0);
-    store_px8<NT>(I, y + 2u, x, p1);
+    store_px8<NT, POST>(I, post, y, x, p0);
+    store_px8<NT, POST>(I, post, y + 2u, x, p1);
 }
 
 // One WAVE per item, four independent waves per workgroup, no barrier on the data
@@ -843,7 +848,7 @@ __device__ __forceinline__ void item_decode(const ItemS &I, uint32_t tt, uint32_
 // offset), the wave stages its own span in its own LDS slice, then decodes its 16
 // tiles in four rounds of 64 lanes.  The only workgroup-wide event is the barrier
 // that publishes the shared term table.
-template <int ABL, bool NT>
+template <int ABL, bool NT, bool POST = false>
 __global__ __launch_bounds__(256) void k7_tiles(const Work7 W, uint32_t total)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_pay[4][PAY_LDS];
@@ -895,8 +900,8 @@ __global__ __launch_bounds__(256) void k7_tiles(const Work7 W, uint32_t total)
 
 #pragma unroll
     for (uint32_t q = 0; q < ITEM_TILES / 4u; q++)
-        item_decode<ABL, NT>(I, q * 4u + (lane >> 4), (lane >> 3) & 1u, lane & 7u, s_pay[wave], s_blk[wave], s_ref[wave],
-                             s_tab);
+        item_decode<ABL, NT, POST>(I, W.post, q * 4u + (lane >> 4), (lane >> 3) & 1u, lane & 7u, s_pay[wave], s_blk[wave],
+                                   s_ref[wave], s_tab);
 }
 
 // ------------------------------------------------------------------ launchers
@@ -957,7 +962,9 @@ void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st)
             return e ? std::atoi(e) : 0;
         }();
         const dim3 grid((total + 3) / 4);
-        if (abl == 1)
+        if (W.post.mode != 0u)
+            hipLaunchKernelGGL((k7_tiles<0, true, true>), grid, dim3(256), 0, st, W, total);
+        else if (abl == 1)
             hipLaunchKernelGGL((k7_tiles<1, true>), grid, dim3(256), 0, st, W, total);
         else if (abl == 2)
             hipLaunchKernelGGL((k7_tiles<2, true>), grid, dim3(256), 0, st, W, total);

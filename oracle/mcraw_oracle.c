@@ -238,6 +238,42 @@ size_t mcraw_oracle_len_used7(const uint8_t *in, size_t len)
     return used;
 }
 
+/* ---------------------------------------------------------------- post stage */
+
+size_t mcraw_oracle_post(uint8_t *out, const uint16_t *img, int width, int height,
+                         unsigned flags, const uint16_t black[4])
+{
+    const size_t row_bytes = (flags & 2u) ? ((size_t)width * 12 + 7) / 8 : (size_t)width * 2;
+    for (int y = 0; y < height; y++) {
+        uint8_t *row = out + (size_t)y * row_bytes;
+        if (flags & 2u)
+            memset(row, 0, row_bytes);
+        for (int x = 0; x < width; x++) {
+            unsigned v = img[(size_t)y * width + x];
+            if (flags & 1u) {
+                unsigned b = black[(y & 1) * 2 + (x & 1)];
+                v = v > b ? v - b : 0;
+            }
+            if (flags & 2u) {
+                if (v > 4095)
+                    v = 4095;
+                size_t bit = (size_t)x * 12; /* MSB-first: sample x occupies bits [12x, 12x+12) of the row */
+                if ((bit & 7) == 0) {
+                    row[bit >> 3] = (uint8_t)(v >> 4);
+                    row[(bit >> 3) + 1] |= (uint8_t)((v & 15) << 4);
+                } else {
+                    row[bit >> 3] |= (uint8_t)(v >> 8);
+                    row[(bit >> 3) + 1] = (uint8_t)(v & 255);
+                }
+            } else {
+                row[2 * x] = (uint8_t)(v & 255);
+                row[2 * x + 1] = (uint8_t)(v >> 8);
+            }
+        }
+    }
+    return row_bytes * (size_t)height;
+}
+
 /* ---------------------------------------------------------------- type 6 */
 
 /* RawData_Legacy.cpp:13-32 */

@@ -53,6 +53,15 @@ int mcraw_oracle_block6(uint16_t out[16], int bits, const uint8_t *in);
  * streams (SURVEY 8d "len_used"); 0 if malformed. */
 size_t mcraw_oracle_len_used7(const uint8_t *in, size_t len);
 
+/* The optional stage the product can fuse behind the decode (include/mcraw_hip.h,
+ * mcraw_ctx_set_post) -- there is no reference function for it; this is its definition, applied to
+ * a decoded mosaic: what a DNG writer is handed next (example.cpp:80-92: strip, BlackLevel,
+ * BitsPerSample).  flags bit 0: sample = max(sample - black[(row & 1) * 2 + (col & 1)], 0);
+ * bit 1: rows packed as 12-bit MSB-first strips of ceil(width * 12 / 8) bytes, samples saturating
+ * at 4095.  Without bit 1 the output is the uint16 little-endian mosaic.  Returns bytes written. */
+size_t mcraw_oracle_post(uint8_t *out, const uint16_t *img, int width, int height,
+                         unsigned flags, const uint16_t black[4]);
+
 /* Frame-parallel timing helper for bench.py's cpu_baseline: decodes
  * `nframes` buffers with `nthreads` pthreads (one frame per task), `reps`
  * passes, returns seconds of wall time for all passes, <0 on decode error. */

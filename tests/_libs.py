@@ -58,6 +58,8 @@ def oracle():
         lib.mcraw_oracle_block6.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         lib.mcraw_oracle_len_used7.restype = C.c_size_t
         lib.mcraw_oracle_len_used7.argtypes = [C.c_void_p, C.c_size_t]
+        lib.mcraw_oracle_post.restype = C.c_size_t
+        lib.mcraw_oracle_post.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint, C.c_void_p]
         lib.mcraw_oracle_time_batch.restype = C.c_double
         lib.mcraw_oracle_time_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                                 C.c_int, C.c_int, C.c_int]
@@ -179,6 +181,38 @@ def ref_decode7(buf, w, h, **kw):
 
 def ref_decode6(buf, w, h, **kw):
     return _decode(ref().mcraw_ref_decode6, buf, w, h, **kw)
+
+
+def post_row_bytes(w, pack12):
+    return (w * 12 + 7) // 8 if pack12 else w * 2
+
+
+def oracle_post(img, black=None, pack12=False):
+    """The post stage (mcraw_ctx_set_post) applied to a decoded mosaic by the oracle: bytes [h, row_bytes]."""
+    img = np.ascontiguousarray(img, dtype=np.uint16)
+    h, w = img.shape
+    out = np.zeros((h, post_row_bytes(w, pack12)), dtype=np.uint8)
+    bl = np.ascontiguousarray(black if black is not None else [0, 0, 0, 0], dtype=np.uint16)
+    n = oracle().mcraw_oracle_post(_ptr(out), _ptr(img), w, h, (1 if black is not None else 0) | (2 if pack12 else 0), _ptr(bl))
+    assert n == out.size
+    return out
+
+
+def post_np(img, black=None, pack12=False):
+    """Independent numpy statement of the same stage (checks the oracle's)."""
+    v = img.astype(np.int64)
+    h, w = v.shape
+    if black is not None:
+        b = np.asarray(black, dtype=np.int64).reshape(2, 2)
+        v = np.maximum(v - np.tile(b, ((h + 1) // 2, (w + 1) // 2))[:h, :w], 0)
+    if not pack12:
+        return v.astype("<u2").view(np.uint8).reshape(h, w * 2)
+    v = np.minimum(v, 4095)
+    bits = ((v[:, :, None] >> np.arange(11, -1, -1)) & 1).astype(np.uint8).reshape(h, w * 12)
+    pad = (-bits.shape[1]) % 8
+    if pad:
+        bits = np.concatenate([bits, np.zeros((h, pad), np.uint8)], axis=1)
+    return np.packbits(bits, axis=1)
 
 
 def natural_image_np(w, h, nbits, sigma, seed):

@@ -1,0 +1,105 @@
+"""Fused post-decode stage (mcraw_ctx_set_post) through the C ABI: decode + black levels / 12-bit
+strip rows on the GPU == oracle decode followed by the oracle's post stage, byte for byte."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import _libs as L
+import motioncam_decoder_amd as M
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(ctx, items, black, pack12, misalign=0, mem=M.MEM_DEVICE):
+    """items: (type, w, h, buf, img).  Returns the list of output byte arrays [h, row_bytes]."""
+    dev = torch.device("cuda:0")
+    ctx.set_post(black=black, pack12=pack12)
+    try:
+        keep, descs, outs = [], [], []
+        for typ, w, h, buf, img in items:
+            rb = L.post_row_bytes(w, pack12)
+            cap16 = (h * rb + 1) // 2
+            if mem == M.MEM_DEVICE:
+                t_in = torch.from_numpy(np.ascontiguousarray(buf)).to(dev)
+                t_out = torch.full((cap16 * 2 + 64,), 0xA5, dtype=torch.uint8, device=dev)
+                keep += [t_in, t_out]
+                descs.append((t_in.data_ptr(), t_in.numel(), w, h, typ, t_out.data_ptr() + misalign, cap16))
+                outs.append(t_out)
+            else:
+                a_in = np.ascontiguousarray(buf)
+                a_out = np.full(cap16 * 2 + 64, 0xA5, dtype=np.uint8)
+                keep += [a_in, a_out]
+                descs.append((a_in.ctypes.data, a_in.size, w, h, typ, a_out.ctypes.data + misalign, cap16))
+                outs.append(a_out)
+        written, status = ctx.decode_batch(M.Context.make_frames(descs), mem=mem)
+        torch.cuda.synchronize()
+        res = []
+        for (typ, w, h, buf, img), o, wr, st in zip(items, outs, written, status):
+            assert st == 0 and wr == w * h, (typ, w, h, st, wr)
+            a = o.cpu().numpy() if mem == M.MEM_DEVICE else o
+            rb = L.post_row_bytes(w, pack12)
+            res.append(a[misalign: misalign + h * rb].reshape(h, rb))
+            tail = a[misalign + h * rb: misalign + h * rb + 8]
+            assert (tail == 0xA5).all(), "wrote past the strip"
+        return res
+    finally:
+        ctx.set_post()
+
+
+def _items(shapes, seed):
+    rng = np.random.default_rng(seed)
+    items = []
+    for (w, h, nbits) in shapes:
+        img = rng.integers(0, 1 << nbits, size=(h, w), dtype=np.uint16)
+        img[: max(1, h // 3), : max(1, w // 2)] = 64 # a flat corner: empty blocks / 2-byte records
+        items.append((7, w, h, L.encode7(img), img))
+        items.append((6, w, h, L.encode6(img), img))
+    return items
+
+
+SHAPES = [(64, 4, 12), (256, 16, 12), (1000, 37, 12), (1001, 9, 10), (77, 6, 16), (1920, 64, 12), (4032, 24, 14)]
+
+
+@pytest.mark.parametrize("black,pack12", [([64, 64, 64, 64], False), (None, True), ([60, 64, 68, 4000], True)])
+def test_post_stage_matches_oracle(gpu_ctx, black, pack12):
+    items = _items(SHAPES, 11)
+    got = _run(gpu_ctx, items, black, pack12)
+    for (typ, w, h, buf, img), g in zip(items, got):
+        want = L.oracle_post(img, black, pack12)
+        assert np.array_equal(g, want), (typ, w, h, np.argwhere(g != want)[:3])
+
+
+def test_post_stage_unaligned_output_and_host_memory(gpu_ctx):
+    items = _items([(256, 16, 12), (1000, 21, 12)], 12)
+    for mem in (M.MEM_DEVICE, M.MEM_HOST):
+        got = _run(gpu_ctx, items, [64, 65, 66, 67], True, misalign=2, mem=mem)
+        for (typ, w, h, buf, img), g in zip(items, got):
+            assert np.array_equal(g, L.oracle_post(img, [64, 65, 66, 67], True)), (typ, w, h, mem)
+
+
+def test_post_stage_off_again_is_plain_mosaic(gpu_ctx):
+    items = _items([(256, 16, 12)], 13)
+    _run(gpu_ctx, items, [64, 64, 64, 64], True)
+    got = _run(gpu_ctx, items, None, False)
+    for (typ, w, h, buf, img), g in zip(items, got):
+        assert np.array_equal(g.view("<u2"), img)
+
+
+def test_post_capacity_is_counted_in_strip_bytes(gpu_ctx):
+    w, h = 256, 16
+    img = np.full((h, w), 100, np.uint16)
+    buf = L.encode7(img)
+    dev = torch.device("cuda:0")
+    t_in = torch.from_numpy(buf).to(dev)
+    t_out = torch.zeros(w * h * 2, dtype=torch.uint8, device=dev)
+    gpu_ctx.set_post(pack12=True)
+    try:
+        need16 = (h * L.post_row_bytes(w, True) + 1) // 2
+        for cap, want in ((need16 - 1, M.E_CAPACITY), (need16, 0)):
+            fr = M.Context.make_frames([(t_in.data_ptr(), t_in.numel(), w, h, 7, t_out.data_ptr(), cap)])
+            written, status = gpu_ctx.decode_batch(fr)
+            assert status[0] == want, (cap, status)
+    finally:
+        gpu_ctx.set_post()
