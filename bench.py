@@ -215,23 +215,28 @@ def cpu_baseline(L, wl, seconds):
                       "%.1f s on %d threads + %.1f s on 1 thread" % (n, wl.w, wl.h, 12, res["all_s"], cores, res["one_s"])}
 
 
-def pcie_inclusive(M, ctx, wl, nframes=48, reps=3):
+def pcie_inclusive(M, L, ctx, wl, nframes=48, reps=3, pack12=False):
     """End-to-end rate when the boundary hands over HOST buffers (never `value`): frames in pinned
     memory -> H2D -> decode -> D2H into pinned memory, sub-batches pipelined on the context's
-    streams (mcraw_decode_batch, MCRAW_MEM_HOST)."""
+    streams (mcraw_decode_batch, MCRAW_MEM_HOST).  pack12: with the fused 12-bit strip stage, which
+    sends 1.5 instead of 2 bytes per sample back over the link."""
     lib = M.load()
     d = len(wl.pairs)
     n = min(nframes, wl.frames)
+    row_bytes = L.post_row_bytes(wl.w, pack12)
+    out_bytes = wl.h * row_bytes
     ins, outs, descs = [], [], []
+    if pack12:
+        ctx.set_post(pack12=True)
     try:
         for i in range(n):
             buf = wl.pairs[i % d][1]
             pi = lib.mcraw_host_alloc(buf.size)
-            po = lib.mcraw_host_alloc(wl.out_stride)
+            po = lib.mcraw_host_alloc(out_bytes)
             ins.append(pi)
             outs.append(po)
             C.memmove(pi, buf.ctypes.data, buf.size)
-            descs.append((pi, buf.size, wl.w, wl.h, M.TYPE_BLOCK, po, wl.w * wl.h))
+            descs.append((pi, buf.size, wl.w, wl.h, M.TYPE_BLOCK, po, out_bytes // 2))
         frames = M.Context.make_frames(descs)
         ctx.decode_batch(frames, mem=M.MEM_HOST)  # warm-up: staging buffers get allocated
         t0 = time.perf_counter()
@@ -239,15 +244,55 @@ def pcie_inclusive(M, ctx, wl, nframes=48, reps=3):
             written, status = ctx.decode_batch(frames, mem=M.MEM_HOST)
         t = (time.perf_counter() - t0) / reps
         ok = all(s == 0 for s in status)
-        got = np.ctypeslib.as_array(C.cast(outs[0], C.POINTER(C.c_uint16)), shape=(wl.h, wl.w))
-        ok = ok and np.array_equal(got, wl.pairs[0][0])
+        got = np.ctypeslib.as_array(C.cast(outs[0], C.POINTER(C.c_uint8)), shape=(wl.h, row_bytes))
+        ok = ok and np.array_equal(got, L.oracle_post(wl.pairs[0][0], None, pack12))
         in_b = sum(wl.pairs[i % d][1].size for i in range(n))
         return {"frames": n, "mpix_s": round(n * wl.w * wl.h / t / 1e6, 1), "frames_per_s": round(n / t, 1),
-                "h2d_GBs": round(in_b / t / 1e9, 2), "d2h_GBs": round(n * wl.out_stride / t / 1e9, 2), "bit_exact": bool(ok),
-                "note": "pinned host buffers in and out, sub-batches pipelined on 4 streams; PCIe-bound"}
+                "h2d_GBs": round(in_b / t / 1e9, 2), "d2h_GBs": round(n * out_bytes / t / 1e9, 2), "bit_exact": bool(ok),
+                "note": "pinned host buffers in and out, sub-batches pipelined on 4 streams; PCIe-bound"
+                        + ("; 12-bit strips out (mcraw_ctx_set_post)" if pack12 else "")}
     finally:
+        ctx.set_post()
         for p in ins + outs:
             lib.mcraw_host_free(p)
+
+
+def post_stage(torch, ctx, M, L, wl, steps):
+    """The same batch with the fused post-decode stage: black levels subtracted and rows
+    written as 12-bit DNG strips -- 1.5 instead of 2 output bytes per sample.  Not the bench line."""
+    stream = torch.cuda.current_stream().cuda_stream
+    black = [256, 256, 256, 256]
+    ctx.set_post(black=black, pack12=True)
+    try:
+        for t in wl.t_outs[:1]:
+            t.zero_()
+        ctx.profile(only=("k7_tiles",))
+        for _ in range(2):
+            ctx.decode_batch(wl.descs, mem=M.MEM_DEVICE, stream=stream, want_status=False)
+        torch.cuda.synchronize()
+        ctx.kernel_ms("k7_tiles", reset=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ctx.decode_batch(wl.descs, mem=M.MEM_DEVICE, stream=stream, want_status=False)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        st = ctx.synchronize(wl.frames)
+        tile_ms, tile_n = ctx.kernel_ms("k7_tiles", reset=True)
+        rb = L.post_row_bytes(wl.w, True)
+        ok = all(s == 0 for s in st)
+        d = len(wl.pairs)
+        for i in sorted({0, wl.frames - 1}):
+            got = wl.t_out[i * wl.out_stride: i * wl.out_stride + wl.h * rb].cpu().numpy().reshape(wl.h, rb)
+            ok = ok and np.array_equal(got, L.oracle_post(wl.pairs[i % d][0], black, True))
+        out_b = wl.frames * wl.h * rb
+        ach = (wl.in_bytes + out_b) / (tile_ms / max(tile_n, 1) * 1e-3) / 1e9
+        return {"stage": "black levels %s subtracted, rows as 12-bit strips" % black, "ms_per_step": round(1e3 * el / steps, 4),
+                "mpix_s": round(wl.pixels * steps / el / 1e6, 1), "tiles_ms_per_launch": round(tile_ms / max(tile_n, 1), 4),
+                "algorithmic_bytes_per_launch": wl.in_bytes + out_b, "achieved_gbs": round(ach, 1),
+                "frac": round(ach / HBM_PEAK_GBS, 4), "bit_exact": bool(ok)}
+    finally:
+        ctx.set_post()
+        ctx.profile(True)
 
 
 def traffic_from_profile(workload_key):
@@ -359,7 +404,12 @@ def main():
                                 "frac": round(s2["achieved_gbs"] / HBM_PEAK_GBS, 4), "bit_exact": results[d]["ok"]}
         if world == 1 and not args.no_cpu:
             try:
-                out["pcie_inclusive"] = pcie_inclusive(M, ctx, wl)
+                out["post_stage"] = post_stage(torch, ctx, M, L, wl, max(2, args.steps // 2))
+            except Exception as e:
+                out["post_stage"] = {"error": repr(e)}
+            try:
+                out["pcie_inclusive"] = pcie_inclusive(M, L, ctx, wl)
+                out["pcie_inclusive_pack12"] = pcie_inclusive(M, L, ctx, wl, pack12=True)
             except Exception as e:
                 out["pcie_inclusive"] = {"error": repr(e)}
             try:

@@ -330,7 +330,29 @@ template <typename F> void parallelFor(size_t n, unsigned threads, F fn)
 void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<std::vector<uint8_t>> &outData,
                          std::vector<nlohmann::json> &outMetadata)
 {
+    loadFrames(timestamps, outData, outMetadata, FrameOutput());
+}
+
+void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<std::vector<uint8_t>> &outData,
+                         std::vector<nlohmann::json> &outMetadata, const FrameOutput &output)
+{
     Impl &I = *mImpl;
+    if (output.bitsPerSample != 16 && output.bitsPerSample != 12)
+        throw IOException("Unsupported bitsPerSample (16 or 12)");
+    mcraw_post post{};
+    if (output.subtractBlackLevel) {
+        const nlohmann::json &cm = getContainerMetadata();
+        const auto bl = cm.find("blackLevel"); // (no json::contains in the nlohmann the reference vendors)
+        if (!cm.is_object() || bl == cm.end() || !bl->is_array() || bl->size() != 4)
+            throw IOException("Container metadata has no blackLevel[4]");
+        post.flags |= MCRAW_POST_BLACK;
+        for (int i = 0; i < 4; i++) {
+            const double v = (*bl)[i].get<double>();
+            post.black[i] = static_cast<uint16_t>(std::min(65535.0, std::max(0.0, v + 0.5)));
+        }
+    }
+    if (output.bitsPerSample == 12)
+        post.flags |= MCRAW_POST_PACK12;
     const size_t n = timestamps.size();
     outData.resize(n);
     outMetadata.assign(n, nlohmann::json());
@@ -339,6 +361,7 @@ void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<s
     // locate every frame and parse its JSON (container errors come first, like in the reference)
     std::vector<FrameSpan> spans(n);
     std::vector<mcraw_frame> frames(n);
+    std::vector<size_t> outBytes(n); // bytes handed back per frame
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     for (size_t i = 0; i < n; i++) {
         spans[i] = I.locate(timestamps[i]);
@@ -358,7 +381,9 @@ void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<s
         f.height = height;
         f.type = type;
         f.reserved = 0;
-        f.out_capacity = static_cast<size_t>(width) * static_cast<size_t>(height);
+        const size_t rowBytes = output.bitsPerSample == 12 ? (static_cast<size_t>(width) * 12 + 7) / 8 : static_cast<size_t>(width) * 2;
+        outBytes[i] = rowBytes * static_cast<size_t>(height);
+        f.out_capacity = (outBytes[i] + 1) / 2; // counted in uint16 units
     }
 
     if (!I.ctx && mcraw_ctx_create(-1, &I.ctx) != 0) // no GPU: decoding fails, there is no CPU codec behind this class
@@ -428,13 +453,13 @@ void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<s
             parallelFor(c.count, hostThreads, [&](size_t k) {
                 const mcraw_frame &f = frames[c.first + k];
                 const uint8_t *src = reinterpret_cast<const uint8_t *>(f.out);
-                outData[c.first + k].assign(src, src + f.out_capacity * 2);
+                outData[c.first + k].assign(src, src + outBytes[c.first + k]);
             });
             return;
         }
         for (size_t k = 0; k < c.count; k++) { // few frames: slice every frame over the threads
             const mcraw_frame &f = frames[c.first + k];
-            const size_t bytes = f.out_capacity * 2;
+            const size_t bytes = outBytes[c.first + k];
             std::vector<uint8_t> &dst = outData[c.first + k];
             if (dst.size() != bytes)
                 dst.resize(bytes);
@@ -477,8 +502,14 @@ void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<s
             oo += up(frames[c.first + k].out_capacity * 2);
         }
         t0 = now();
-        if (mcraw_decode_batch(I.ctx, frames.data() + c.first, static_cast<int>(c.count), MCRAW_MEM_HOST, nullptr,
-                               written.data() + c.first, status.data() + c.first) != 0)
+        // the post stage is a property of this call, not of the context: set for the batch, cleared behind it
+        int rc = post.flags ? mcraw_ctx_set_post(I.ctx, &post) : 0;
+        if (rc == 0)
+            rc = mcraw_decode_batch(I.ctx, frames.data() + c.first, static_cast<int>(c.count), MCRAW_MEM_HOST, nullptr,
+                                    written.data() + c.first, status.data() + c.first);
+        if (post.flags)
+            (void)mcraw_ctx_set_post(I.ctx, nullptr);
+        if (rc != 0)
             throw IOException(std::string("GPU decode failed: ") + mcraw_last_error());
         tDecode += ms(t0, now());
         for (size_t k = c.first; k < c.first + c.count; k++)

@@ -65,6 +65,20 @@ public:
     void loadFrames(const std::vector<Timestamp> &timestamps, std::vector<std::vector<uint8_t>> &outData,
                     std::vector<nlohmann::json> &outMetadata);
 
+    // What loadFrames hands back per frame.  The defaults are loadFrame()'s output (uint16 LE mosaic,
+    // 2 * width * height bytes).  The other forms are produced by a stage fused into the GPU decode
+    // (mcraw_ctx_set_post) for the consumer example.cpp:55-139 stands for, a DNG writer:
+    //   subtractBlackLevel  sample = max(sample - blackLevel[(row & 1) * 2 + (col & 1)], 0), levels from the
+    //                       container metadata ("blackLevel", example.cpp:65) -- write BlackLevel 0 then;
+    //   bitsPerSample = 12  rows as 12-bit strips, ceil(width * 12 / 8) bytes each, MSB-first
+    //                       (SetBitsPerSample {12}, example.cpp:116-117), a quarter less to copy and store.
+    struct FrameOutput {
+        bool subtractBlackLevel = false;
+        int bitsPerSample = 16; // 16 or 12
+    };
+    void loadFrames(const std::vector<Timestamp> &timestamps, std::vector<std::vector<uint8_t>> &outData,
+                    std::vector<nlohmann::json> &outMetadata, const FrameOutput &output);
+
     int audioSampleRateHz() const;
     int numAudioChannels() const;
 

@@ -1,11 +1,13 @@
 // mcraw_export -- decode a .mcraw file on the GPU and dump what it holds.
 //
-//   mcraw_export <file.mcraw> [-n frames] [-o outdir] [--single] [--no-write]
+//   mcraw_export <file.mcraw> [-n frames] [-o outdir] [--single] [--no-write] [--black] [--bits 12]
 //
 // Writes outdir/frame_%06d.u16 (width*height uint16 LE, row-major Bayer mosaic) for the
 // first N frames (by timestamp) and outdir/audio.s16 (interleaved PCM), and prints one line
 // per frame with its geometry and a CRC-32 of the pixels.  Frames are decoded as one GPU
 // batch (Decoder::loadFrames); --single uses the per-frame loadFrame() path instead.
+// --black subtracts the container's black levels, --bits 12 writes frame_%06d.p12 (12-bit strip
+// rows) instead: both are done by the stage fused into the GPU decode (Decoder::FrameOutput).
 #include <motioncam/Decoder.hpp>
 
 #include <chrono>
@@ -54,6 +56,7 @@ int main(int argc, char **argv)
     std::string input = argv[1], outdir = ".";
     long limit = -1;
     bool single = false, nowrite = false;
+    motioncam::Decoder::FrameOutput output;
     for (int i = 2; i < argc; i++) {
         if (!std::strcmp(argv[i], "-n") && i + 1 < argc)
             limit = std::atol(argv[++i]);
@@ -63,6 +66,10 @@ int main(int argc, char **argv)
             single = true;
         else if (!std::strcmp(argv[i], "--no-write"))
             nowrite = true; // decode and checksum only (timing runs)
+        else if (!std::strcmp(argv[i], "--black"))
+            output.subtractBlackLevel = true;
+        else if (!std::strcmp(argv[i], "--bits") && i + 1 < argc)
+            output.bitsPerSample = std::atoi(argv[++i]);
     }
     try {
         motioncam::Decoder decoder(input);
@@ -91,14 +98,14 @@ int main(int argc, char **argv)
             for (size_t i = 0; i < frames.size(); i++)
                 decoder.loadFrame(frames[i], data[i], meta[i]);
         } else {
-            decoder.loadFrames(frames, data, meta);
+            decoder.loadFrames(frames, data, meta, output);
         }
         const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         std::cout << "decoded " << frames.size() << " frames in " << secs << " s (" << (secs > 0 ? frames.size() / secs : 0.0)
                   << " frames/s, file read + GPU decode + copy out)" << std::endl;
         for (size_t i = 0; i < frames.size(); i++) {
             char name[64];
-            std::snprintf(name, sizeof(name), "/frame_%06zu.u16", i);
+            std::snprintf(name, sizeof(name), output.bitsPerSample == 12 ? "/frame_%06zu.p12" : "/frame_%06zu.u16", i);
             if (!nowrite && !writeFile(outdir + name, data[i].data(), data[i].size()))
                 throw motioncam::IOException("Failed to write " + outdir + name);
             const int w = meta[i]["width"], h = meta[i]["height"], t = meta[i]["compressionType"];

@@ -62,6 +62,28 @@ def test_export_tool(container, mode, tmp_path):
     assert np.array_equal(pcm, np.concatenate([a[1] for a in audio]))
 
 
+def test_export_tool_fused_post_stage(container, tmp_path):
+    # Decoder::loadFrames with FrameOutput{subtractBlackLevel, bitsPerSample 12}: black levels from the
+    # container metadata (64 for every CFA position in this clip), rows as 12-bit strips
+    d, path, images, audio = container
+    if not os.path.exists(EXPORT):
+        from motioncam_decoder_amd import build
+        build.build_host()
+    r = _run([EXPORT, path, "-o", str(tmp_path), "--black", "--bits", "12"], str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    for i, ts in enumerate(sorted(images)):
+        img = images[ts]
+        want = L.oracle_post(img, [64, 64, 64, 64], True)
+        got = np.fromfile(str(tmp_path / ("frame_%06d.p12" % i)), dtype=np.uint8)
+        assert np.array_equal(got.reshape(want.shape), want), (i, ts)
+    r = _run([EXPORT, path, "-o", str(tmp_path), "--black"], str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    for i, ts in enumerate(sorted(images)):
+        got = np.fromfile(str(tmp_path / ("frame_%06d.u16" % i)), dtype=np.uint16)
+        want = np.maximum(images[ts].astype(np.int32) - 64, 0).astype(np.uint16)
+        assert np.array_equal(got.reshape(want.shape), want), (i, ts)
+
+
 @pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/example_dropin not built (needs /root/reference)")
 def test_reference_example_over_gpu_decode(container, tmp_path):
     d, path, images, audio = container
