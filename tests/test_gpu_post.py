@@ -103,3 +103,15 @@ def test_post_capacity_is_counted_in_strip_bytes(gpu_ctx):
             assert status[0] == want, (cap, status)
     finally:
         gpu_ctx.set_post()
+
+
+def test_unknown_post_flags_are_rejected(gpu_ctx):
+    p = M.Post()
+    p.flags = 4
+    assert gpu_ctx._lib.mcraw_ctx_set_post(gpu_ctx._h, C.byref(p)) != 0
+    assert b"post" in gpu_ctx._lib.mcraw_last_error()
+    # and the context still decodes plain mosaics
+    items = _items([(64, 4, 12)], 14)
+    got = _run(gpu_ctx, items, None, False)
+    for (typ, w, h, buf, img), g in zip(items, got):
+        assert np.array_equal(g.view("<u2"), img)
