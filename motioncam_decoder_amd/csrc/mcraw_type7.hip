@@ -135,16 +135,17 @@ __device__ __forceinline__ Unpacked unpack8(const uint8_t *__restrict__ base, ui
 // bytes}: where record i+1 starts is only known from the header of record i
 // (RawData.cpp:485-495).  A lone wave chasing ~2000 headers per stream costs ~0.3 ms,
 // so the chain is resolved in parallel with TRANSITION MAPS: record strides are even and
-// at most 130 bytes, hence a fixed 2 KiB chunk of the stream can only be entered at 65
+// at most 130 bytes, hence a fixed 1 KiB chunk of the stream can only be entered at 65
 // offsets ("phases" 0,2,..,128 past the chunk start).
 //
 //   k7_hdr      per stream: validate the frame header (RawData.cpp:547-554), find where the
 //               stream starts and how many chunks it can span; build the work list of k7_maps
-//   k7_maps     per chunk, per phase: walk the headers to the chunk end
+//   k7_maps     per chunk: table of record strides, then per phase a walk over it to the chunk end
 //               -> (exit phase into the next chunk, records started)
 //   k7_follow   per stream: follow the true phase through the chunk maps
 //               -> (entry phase, first record index) per chunk; work list of k7_records
-//   k7_records  per chunk: list its records from the true entry, unpack each one
+//   k7_records  per 4 chunks (a lane walks each from its true entry), or per chunk of tiny records
+//               (pointer doubling): list the records, unpack eight of them per pass
 //               -> bits[], refs[], byte length of every decode item
 //
 // k7_maps and k7_records are persistent grids looping over device-built work lists, so no
