@@ -144,16 +144,17 @@ struct Decoder::Impl {
     std::unique_ptr<Loader> loader;
 
     // pinned staging reused across loadFrames() calls
-    uint8_t *pinIn[2] = {nullptr, nullptr}, *pinOut[2] = {nullptr, nullptr};
-    size_t pinInCap[2] = {0, 0}, pinOutCap[2] = {0, 0};
+    static constexpr int kOutSlots = 4; // decoded chunks whose copy-out may still be running
+    uint8_t *pinIn[2] = {nullptr, nullptr}, *pinOut[kOutSlots] = {nullptr, nullptr, nullptr, nullptr};
+    size_t pinInCap[2] = {0, 0}, pinOutCap[kOutSlots] = {0, 0, 0, 0};
     mcraw_ctx *ctx = nullptr;
 
     ~Impl()
     {
-        for (int s = 0; s < 2; s++) {
+        for (int s = 0; s < 2; s++)
             mcraw_host_free(pinIn[s]);
+        for (int s = 0; s < kOutSlots; s++)
             mcraw_host_free(pinOut[s]);
-        }
         if (ctx)
             mcraw_ctx_destroy(ctx);
     }
@@ -425,8 +426,12 @@ void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<s
         maxOut = std::max(maxOut, c.outBytes);
     }
     const int nslots = chunks.size() > 1 ? 2 : 1;
-    for (int s = 0; s < nslots; s++) {
+    // a copy-out is one thread per frame (vector::assign faults its pages in as it copies), so several
+    // chunks' copy-outs have to be in flight to keep up with the GPU: one output slot each
+    const int noutslots = static_cast<int>(std::min<size_t>(Impl::kOutSlots, chunks.size()));
+    for (int s = 0; s < nslots; s++)
         grow(I.pinIn[s], I.pinInCap[s], maxIn);
+    for (int s = 0; s < noutslots; s++) {
         grow(I.pinOut[s], I.pinOutCap[s], maxOut);
     }
     const unsigned hostThreads = std::max(2u, std::min(8u, std::thread::hardware_concurrency() / 2));
@@ -482,8 +487,7 @@ void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<s
     std::vector<size_t> written(n);
     std::vector<int32_t> status(n);
     std::future<void> reading = std::async(std::launch::async, readChunk, size_t(0));
-    std::future<void> copying; // copy-out of the previous chunk
-    std::future<void> copying2; // ... and of the one before (it owns the output slot about to be reused)
+    std::vector<std::future<void>> copying(noutslots); // copy-out of the chunk that last used each output slot
     for (size_t ci = 0; ci < chunks.size(); ci++) {
         const Chunk &c = chunks[ci];
         auto t0 = now();
@@ -492,10 +496,10 @@ void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<s
         if (ci + 1 < chunks.size())
             reading = std::async(std::launch::async, readChunk, ci + 1);
         t0 = now();
-        if (copying2.valid())
-            copying2.get(); // chunk ci-2 used this output slot
+        if (copying[ci % noutslots].valid())
+            copying[ci % noutslots].get(); // chunk ci - noutslots used this output slot
         tWaitCopy += ms(t0, now());
-        uint8_t *obase = I.pinOut[ci % nslots];
+        uint8_t *obase = I.pinOut[ci % noutslots];
         size_t oo = 0;
         for (size_t k = 0; k < c.count; k++) {
             frames[c.first + k].out = reinterpret_cast<uint16_t *>(obase + oo);
@@ -516,14 +520,14 @@ void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<s
             if (status[k] != 0 || written[k] == 0)
                 throw IOException(frames[k].type == kTypeBlock ? "Failed to uncompress frame"
                                                                : "Failed to uncompress legacy frame");
-        copying2 = std::move(copying);
-        copying = std::async(std::launch::async, copyOut, ci);
+        copying[ci % noutslots] = std::async(std::launch::async, copyOut, ci);
     }
     const auto t1 = now();
-    if (copying2.valid())
-        copying2.get();
-    if (copying.valid())
-        copying.get();
+    for (size_t k = 0; k < copying.size(); k++) { // oldest first
+        std::future<void> &f = copying[(chunks.size() + k) % copying.size()];
+        if (f.valid())
+            f.get();
+    }
     if (trace)
         std::fprintf(stderr, "[mcraw] loadFrames n=%zu chunks=%zu total %.2f ms: wait-read %.2f, gpu batch %.2f, wait-copy %.2f, tail copy %.2f\n",
                      n, chunks.size(), ms(tStart, now()), tWaitRead, tDecode, tWaitCopy, ms(t1, now()));
