@@ -249,7 +249,7 @@ def pcie_inclusive(M, L, ctx, wl, nframes=48, reps=3, pack12=False):
         in_b = sum(wl.pairs[i % d][1].size for i in range(n))
         return {"frames": n, "mpix_s": round(n * wl.w * wl.h / t / 1e6, 1), "frames_per_s": round(n / t, 1),
                 "h2d_GBs": round(in_b / t / 1e9, 2), "d2h_GBs": round(n * out_bytes / t / 1e9, 2), "bit_exact": bool(ok),
-                "note": "pinned host buffers in and out, sub-batches pipelined on 4 streams; PCIe-bound"
+                "note": "pinned host buffers in and out; sub-batches flow through upload stream / kernels / download stream; PCIe-bound"
                         + ("; 12-bit strips out (mcraw_ctx_set_post)" if pack12 else "")}
     finally:
         ctx.set_post()
