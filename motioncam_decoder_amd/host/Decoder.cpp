@@ -338,6 +338,7 @@ void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<s
                          std::vector<nlohmann::json> &outMetadata, const FrameOutput &output)
 {
     Impl &I = *mImpl;
+    const auto tEnter = std::chrono::steady_clock::now();
     if (output.bitsPerSample != 16 && output.bitsPerSample != 12)
         throw IOException("Unsupported bitsPerSample (16 or 12)");
     mcraw_post post{};
@@ -529,8 +530,8 @@ void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<s
             f.get();
     }
     if (trace)
-        std::fprintf(stderr, "[mcraw] loadFrames n=%zu chunks=%zu total %.2f ms: wait-read %.2f, gpu batch %.2f, wait-copy %.2f, tail copy %.2f\n",
-                     n, chunks.size(), ms(tStart, now()), tWaitRead, tDecode, tWaitCopy, ms(t1, now()));
+        std::fprintf(stderr, "[mcraw] loadFrames n=%zu chunks=%zu setup %.2f ms (index, JSON, context, pinned staging), pipeline %.2f ms: wait-read %.2f, gpu batch %.2f, wait-copy %.2f, tail copy %.2f\n",
+                     n, chunks.size(), ms(tEnter, tStart), ms(tStart, now()), tWaitRead, tDecode, tWaitCopy, ms(t1, now()));
 }
 
 } // namespace motioncam
