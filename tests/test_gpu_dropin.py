@@ -104,3 +104,26 @@ def test_reference_example_over_gpu_decode(container, tmp_path):
         assert r.stdout == r2.stdout
         for name in sorted(os.listdir(str(b))):
             assert (a / name).read_bytes() == (b / name).read_bytes(), name
+
+
+SWAP = os.path.join(ROOT, "oracle", "_ref", "example_codec_swap")
+
+
+@pytest.mark.skipif(not (os.path.exists(SWAP) and os.path.exists(REFEX)),
+                    reason="oracle/_ref/example_codec_swap not built (needs /root/reference)")
+def test_reference_container_code_with_codec_swapped(container, tmp_path):
+    # the reference's example.cpp and lib/Decoder.cpp unchanged, only
+    # raw::Decode / raw::DecodeLegacy replaced by the C ABI (host/RawData.cpp) -- same files out
+    d, path, images, audio = container
+    a, b = tmp_path / "swap", tmp_path / "ref"
+    a.mkdir()
+    b.mkdir()
+    r = _run([SWAP, path], str(a))
+    assert r.returncode == 0, r.stderr + r.stdout
+    r2 = _run([REFEX, path], str(b))
+    assert r2.returncode == 0, r2.stderr
+    assert r.stdout == r2.stdout
+    names = sorted(os.listdir(str(b)))
+    assert len(names) == len(images) + 1
+    for name in names:
+        assert (a / name).read_bytes() == (b / name).read_bytes(), name
