@@ -99,3 +99,59 @@ def test_aliased_side_streams_are_replanned(gpu_ctx):
     written, status, outs = decode_batch_device(gpu_ctx, [(7, w, h, buf), (7, w, h, enc)])
     assert status == [0, 0] and written == [w * h, w * h]
     assert np.array_equal(outs[0], img) and np.array_equal(outs[1], img)
+
+
+def test_abi_edge_arguments(gpu_ctx):
+    """Every per-frame argument error is a status bit of that frame, not a crash and not a failed call;
+    an empty batch is a no-op; NULL where an array is required fails the call."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda:0")
+    w, h = 128, 8
+    img = L.natural_image_np(w, h, 12, 12.0, 5)
+    buf = L.encode7(img)
+    t_in = torch.zeros(buf.size + 64, dtype=torch.uint8, device=dev)
+    t_in[:buf.size].copy_(torch.from_numpy(buf))
+    t_in2 = torch.zeros(buf.size + 64, dtype=torch.uint8, device=dev)
+    t_in2[8:8 + buf.size].copy_(torch.from_numpy(buf))  # not 16-byte aligned
+    t_out = torch.zeros(w * h * 2 + 64, dtype=torch.uint8, device=dev)
+    t_out6 = torch.zeros(w * h * 2 + 64, dtype=torch.uint8, device=dev)
+    ip, ip_mis, op = t_in.data_ptr(), t_in2.data_ptr() + 8, t_out.data_ptr()
+    assert ip % 16 == 0
+    ret6, out6 = L.oracle_decode6(buf, w, h)  # a type-7 buffer read as a legacy stream: whatever the oracle says
+    cases = [
+        ((ip, buf.size, w, h, 7, op, w * h), 0),
+        ((ip_mis, buf.size, w, h, 7, op, w * h), M.E_ARGS),          # device input must be 16-byte aligned
+        ((ip, buf.size, w, h, 7, op + 1, w * h), M.E_ARGS),          # odd output address
+        ((ip, 0, w, h, 7, op, w * h), M.E_ARGS),                     # empty input
+        ((ip, buf.size, 0, h, 7, op, w * h), M.E_ARGS),
+        ((ip, buf.size, w, -3, 7, op, w * h), M.E_ARGS),
+        ((ip, buf.size, 1 << 20, 1 << 12, 7, op, w * h), M.E_ARGS),  # 2^32 samples
+        ((0, buf.size, w, h, 7, op, w * h), M.E_ARGS),
+        ((ip, buf.size, w, h, 7, 0, w * h), M.E_ARGS),
+        ((ip, buf.size, w, h, 7, op, w * h - 1), M.E_CAPACITY),
+        ((ip, buf.size, w, h, 6, t_out6.data_ptr(), w * h), None),
+        ((ip, buf.size, w, h, 7, op, w * h), 0),
+    ]
+    frames = M.Context.make_frames([c[0] for c in cases])
+    written, status = gpu_ctx.decode_batch(frames)
+    for i, (_, want) in enumerate(cases):
+        if want == 0:
+            assert status[i] == 0 and written[i] == w * h, (i, status[i])
+        elif want is None:
+            assert (status[i] == 0 and written[i] == ret6) if ret6 else (status[i] != 0 and written[i] == 0), (i, status[i], ret6)
+            if ret6:
+                assert np.array_equal(t_out6[: w * h * 2].cpu().numpy().view(np.uint16).reshape(h, w), out6)
+        else:
+            assert status[i] & want and written[i] == 0, (i, status[i], want)
+    torch.cuda.synchronize()
+    assert np.array_equal(t_out[: w * h * 2].cpu().numpy().view(np.uint16).reshape(h, w), img)
+    # empty batch
+    empty = M.Context.make_frames([])
+    assert gpu_ctx._lib.mcraw_decode_batch(gpu_ctx._h, empty, 0, M.MEM_DEVICE, None, None, None) == 0
+    # NULL frame array with n > 0, NULL context
+    assert gpu_ctx._lib.mcraw_decode_batch(gpu_ctx._h, None, 3, M.MEM_DEVICE, None, None, None) != 0
+    assert gpu_ctx._lib.mcraw_decode_batch(None, frames, len(cases), M.MEM_DEVICE, None, None, None) != 0
+    # the context is still good
+    written, status = gpu_ctx.decode_batch(M.Context.make_frames([cases[0][0]]))
+    assert status == [0] and written == [w * h]

@@ -53,3 +53,31 @@ def test_full_batch_order_and_repeat_invariance(gpu_ctx):
         assert (int(a1[0][i]), int(a1[1][i])) == ref[k], (i, k)
     for i, k in enumerate(order_b):                                             # order / neighbours do not matter
         assert (int(b[0][i]), int(b[1][i])) == ref[int(k)], (i, k)
+
+
+def test_frame_checksums_do_not_depend_on_the_gpu_count(gpu_ctx):
+    """BASELINE config 5: 7680x4320 frames sharded over 1, 2, 4, 8 ranks (frame i -> rank i mod world,
+    motioncam_decoder_amd/shard.py); the per-frame checksums of the job must be the same for every world
+    size.  One GPU plays the ranks one after another."""
+    import torch
+    import motioncam_decoder_amd as M
+    from motioncam_decoder_amd import shard
+    dev = torch.device("cuda:0")
+    w, h, total, distinct = 7680, 4320, 16, 4
+    imgs = [L.synth_image(w, h, 12, 1, 12.0, 5000 + i) for i in range(distinct)]
+    bufs = [torch.from_numpy(L.encode7(im)).to(dev) for im in imgs]
+    want = [shard.frame_checksum(imgs[i % distinct]) for i in range(total)]
+    for world in (1, 2, 4, 8):
+        got = {}
+        for rank in range(world):
+            mine = shard.shard_frames(total, rank, world)
+            t_out = torch.zeros(len(mine) * w * h * 2, dtype=torch.uint8, device=dev)
+            descs = [(bufs[g % distinct].data_ptr(), bufs[g % distinct].numel(), w, h, 7,
+                      t_out.data_ptr() + k * w * h * 2, w * h) for k, g in enumerate(mine)]
+            written, status = gpu_ctx.decode_batch(M.Context.make_frames(descs))
+            assert status == [0] * len(mine) and written == [w * h] * len(mine)
+            out = t_out.cpu().numpy().view(np.uint16).reshape(len(mine), h, w)
+            for k, g in enumerate(mine):
+                got[g] = shard.frame_checksum(out[k])
+            del t_out
+        assert [got[i] for i in range(total)] == want, world
