@@ -96,10 +96,10 @@ def test_baseline_config1_and_config2_full_size(gpu_ctx):
 
 def test_baseline_config4_mixed_batch(gpu_ctx):
     # 14-bit type 7 (U and Nat) interleaved with legacy frames incl. width % 32 != 0;
-    # every storage class forced at least once, reduced frame count for CI time
+    # every storage class forced at least once; 64 frames interleaved by frame index
     rng = np.random.default_rng(4000)
     items, expect = [], []
-    for i in range(16):
+    for i in range(64):
         if i % 2 == 0:
             w, h = ((1920, 1080), (4032, 3024))[(i // 2) % 2]
             img = L.synth_image(w, h, 14, (i // 4) % 2, 40.0, 4000 + i)
