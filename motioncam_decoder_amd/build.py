@@ -46,8 +46,9 @@ def build_hip(force=False):
     deps = srcs + [os.path.join(CSRC, f) for f in ("mcraw_plan.h", "mcraw_dev.h")] + [
         os.path.join(ROOT, "include", "mcraw_hip.h")]
     if force or _newer(out, deps):
+        diag = ["-DMCRAW_DIAG"] if os.environ.get("MCRAW_DIAG") else []  # timing-experiment kernels (tools/abl7.sh)
         _run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
-              "-Wall", "-Wno-unused-function", "-o", out] + srcs)
+              "-Wall", "-Wno-unused-function"] + diag + ["-o", out] + srcs)
     return out
 
 

@@ -784,7 +784,7 @@ __device__ __forceinline__ void store_px8(const ItemS &I, const Post &post, uint
 // then write one full 128-byte line per store instruction instead of two half-filled
 // ones (partial-line writes were the bottleneck of the first version).
 //
-// ABL (diagnostic builds only, MCRAW_ABLATE): 0 = product; 1 = no global stores;
+// ABL (builds with -DMCRAW_DIAG only, env MCRAW_ABLATE): 0 = product; 1 = no global stores;
 // 2 = no unpack arithmetic; 3 (caller) = no payload loads.
 template <int ABL = 0, bool NT = false, bool POST = false>
 __device__ __forceinline__ void item_decode(const ItemS &I, const Post &post, uint32_t tt, uint32_t r, uint32_t k,
@@ -934,38 +934,42 @@ void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st)
         hipLaunchKernelGGL(k7_maps, dim3(persistent_grid(0)), dim3(256), 0, st, W);
         hipLaunchKernelGGL(k7_follow, dim3(2 * n7), dim3(256), 0, st, W);
         break;
-    case MCRAW_K7_META:
-        {
-            static const int abl = []() {
-                const char *e = std::getenv("MCRAW_ABLATE_REC");
-                return e ? std::atoi(e) : 0;
-            }();
-            const dim3 g(persistent_grid(1));
-            if (abl == 1)
-                hipLaunchKernelGGL((k7_records<1, false>), g, dim3(64), 0, st, W);
-            else if (abl == 2)
-                hipLaunchKernelGGL((k7_records<2, false>), g, dim3(64), 0, st, W);
-            else if (abl == 3)
-                hipLaunchKernelGGL((k7_records<3, false>), g, dim3(64), 0, st, W);
-            else
-                hipLaunchKernelGGL((k7_records<0, false>), g, dim3(64), 0, st, W);
-            // chunks made of runs of tiny records (flat image regions): usually none
-            hipLaunchKernelGGL((k7_records<0, true>), dim3(2048), dim3(64), 0, st, W);
-        }
+    case MCRAW_K7_META: {
+        const dim3 g(persistent_grid(1));
+#ifdef MCRAW_DIAG // timing experiments (tools/abl7.sh builds with -DMCRAW_DIAG); not in the product library
+        static const int abl = []() {
+            const char *e = std::getenv("MCRAW_ABLATE_REC");
+            return e ? std::atoi(e) : 0;
+        }();
+        if (abl == 1)
+            hipLaunchKernelGGL((k7_records<1, false>), g, dim3(64), 0, st, W);
+        else if (abl == 2)
+            hipLaunchKernelGGL((k7_records<2, false>), g, dim3(64), 0, st, W);
+        else if (abl == 3)
+            hipLaunchKernelGGL((k7_records<3, false>), g, dim3(64), 0, st, W);
+        else
+#endif
+            hipLaunchKernelGGL((k7_records<0, false>), g, dim3(64), 0, st, W);
+        // chunks made of runs of tiny records (flat image regions): usually none
+        hipLaunchKernelGGL((k7_records<0, true>), dim3(2048), dim3(64), 0, st, W);
         break;
+    }
     case MCRAW_K7_SCAN:
         hipLaunchKernelGGL(k7_scan, dim3(n7), dim3(1024), 0, st, W);
         break;
     case MCRAW_K7_TILES: {
         const uint32_t total = W.Rmax * ITEM_SPLIT * n7;
-        static const int abl = []() { // diagnostic builds of the same kernel (see item_decode)
+        const dim3 grid((total + 3) / 4);
+        if (W.post.mode != 0u) {
+            hipLaunchKernelGGL((k7_tiles<0, true, true>), grid, dim3(256), 0, st, W, total);
+            break;
+        }
+#ifdef MCRAW_DIAG // timing experiments of the same kernel (see item_decode); not in the product library
+        static const int abl = []() {
             const char *e = std::getenv("MCRAW_ABLATE");
             return e ? std::atoi(e) : 0;
         }();
-        const dim3 grid((total + 3) / 4);
-        if (W.post.mode != 0u)
-            hipLaunchKernelGGL((k7_tiles<0, true, true>), grid, dim3(256), 0, st, W, total);
-        else if (abl == 1)
+        if (abl == 1)
             hipLaunchKernelGGL((k7_tiles<1, true>), grid, dim3(256), 0, st, W, total);
         else if (abl == 2)
             hipLaunchKernelGGL((k7_tiles<2, true>), grid, dim3(256), 0, st, W, total);
@@ -974,6 +978,7 @@ void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st)
         else if (abl == 4)
             hipLaunchKernelGGL((k7_tiles<0, false>), grid, dim3(256), 0, st, W, total);
         else
+#endif
             hipLaunchKernelGGL((k7_tiles<0, true>), grid, dim3(256), 0, st, W, total);
         break;
     }
