@@ -295,6 +295,36 @@ def post_stage(torch, ctx, M, L, wl, steps):
         ctx.profile(True)
 
 
+def legacy_leg(torch, ctx, M, L, dev, n=32, w=4000, h=3000, nbits=12, sigma=12.0, reps=10):
+    """The legacy (type 6) encoding on a BASELINE config 4 geometry (width % 32 != 0): not the bench line,
+    reported so that both codecs of the path are measured by the same program."""
+    imgs = [L.synth_image(w, h, nbits, 1, sigma, 6000 + i) for i in range(4)]
+    bufs = [L.encode6(im) for im in imgs]
+    tin = [torch.from_numpy(bufs[i % 4]).to(dev) for i in range(n)]
+    tout = torch.zeros(n * w * h * 2, dtype=torch.uint8, device=dev)
+    descs = [(tin[i].data_ptr(), tin[i].numel(), w, h, M.TYPE_LEGACY, tout.data_ptr() + i * w * h * 2, w * h) for i in range(n)]
+    frames = M.Context.make_frames(descs)
+    written, status = ctx.decode_batch(frames)
+    ok = all(s == 0 for s in status) and all(wr == w * h for wr in written)
+    for i in (0, n - 1):
+        got = tout[i * w * h * 2:(i + 1) * w * h * 2].cpu().numpy().view(np.uint16).reshape(h, w)
+        ok = ok and np.array_equal(got, imgs[i % 4])
+    ctx.profile(True)
+    for k in M.KERNELS:
+        ctx.kernel_ms(k, reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.decode_batch(frames, want_status=False)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / reps
+    kms = {k: round(ctx.kernel_ms(k, reset=True)[0] / reps, 4) for k in ("k6_maps", "k6_resolve", "k6_rows")}
+    byts = sum(bufs[i % 4].size for i in range(n)) + n * w * h * 2
+    return {"workload": "%d x %dx%d %d-bit type-6 frames, Nat" % (n, w, h, nbits), "ms_per_batch": round(t * 1e3, 4),
+            "mpix_s": round(n * w * h / t / 1e6, 1), "in_plus_out_GBs": round(byts / t / 1e9, 1),
+            "input_bpp": round(8.0 * bufs[0].size / (w * h), 2), "kernels_ms": kms, "bit_exact": bool(ok)}
+
+
 def traffic_from_profile(workload_key):
     """HBM bytes per k7_tiles launch from the committed rocprofv3 --pmc summary, if present."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
@@ -403,6 +433,10 @@ def main():
                                 "input_bpp": round(s2["bpp"], 2), "achieved_gbs": round(s2["achieved_gbs"], 1),
                                 "frac": round(s2["achieved_gbs"] / HBM_PEAK_GBS, 4), "bit_exact": results[d]["ok"]}
         if world == 1 and not args.no_cpu:
+            try:
+                out["legacy"] = legacy_leg(torch, ctx, M, L, dev)
+            except Exception as e:
+                out["legacy"] = {"error": repr(e)}
             try:
                 out["post_stage"] = post_stage(torch, ctx, M, L, wl, max(2, args.steps // 2))
             except Exception as e:
