@@ -215,7 +215,7 @@ def cpu_baseline(L, wl, seconds):
                       "%.1f s on %d threads + %.1f s on 1 thread" % (n, wl.w, wl.h, 12, res["all_s"], cores, res["one_s"])}
 
 
-def pcie_inclusive(M, L, ctx, wl, nframes=48, reps=3, pack12=False):
+def pcie_inclusive(M, L, ctx, wl, nframes=240, reps=2, pack12=False):
     """End-to-end rate when the boundary hands over HOST buffers (never `value`): frames in pinned
     memory -> H2D -> decode -> D2H into pinned memory, sub-batches pipelined on the context's
     streams (mcraw_decode_batch, MCRAW_MEM_HOST).  pack12: with the fused 12-bit strip stage, which
