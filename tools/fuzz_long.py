@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Extended mutation fuzzing of the HIP path against the oracle (same rule as tests/test_gpu_fuzz.py:
-whatever the oracle makes of a mutant, the GPU must agree).  FUZZ_SECONDS (default 120), FUZZ_SEED."""
+whatever the oracle makes of a mutant, the GPU must agree).  FUZZ_SECONDS (default 120), FUZZ_SEED;
+FUZZ_POST=1 runs every round with the fused post stage on (random black levels, 12-bit strips on or off)
+and compares with the oracle's post stage applied to the oracle's decode."""
 import os
 import sys
 import time
@@ -23,7 +25,13 @@ def main():
     ctx = M.Context(0)
     t0 = time.time()
     rounds = frames = decoded = 0
+    use_post = bool(os.environ.get("FUZZ_POST"))
     while time.time() - t0 < secs:
+        black, pack12 = None, False
+        if use_post:
+            black = [int(x) for x in rng.integers(0, 5000, 4)] if rng.random() < 0.7 else None
+            pack12 = bool(rng.random() < 0.6) or black is None
+            ctx.set_post(black=black, pack12=pack12)
         typ = 7 if rng.random() < 0.6 else 6
         w = int(rng.choice([64, 77, 200, 256, 640, 1000, 1920, 4032]))
         h = int(rng.choice([4, 12, 30, 64, 270, 1080])) if w < 3000 else int(rng.choice([8, 64, 256]))
@@ -51,7 +59,12 @@ def main():
             else:
                 assert status[i] == 0 and written[i] == ret, (seed, rounds, i, typ, w, h, status[i], written[i], ret)
                 rows = ret // w
-                assert np.array_equal(outs[i][:rows], want[:rows]), (seed, rounds, i, typ, w, h)
+                if use_post:
+                    rb = L.post_row_bytes(w, pack12)
+                    got = outs[i].reshape(-1).view(np.uint8)[: rows * rb].reshape(rows, rb)
+                    assert np.array_equal(got, L.oracle_post(want[:rows], black, pack12)), (seed, rounds, i, typ, w, h, black, pack12)
+                else:
+                    assert np.array_equal(outs[i][:rows], want[:rows]), (seed, rounds, i, typ, w, h)
                 decoded += 1
         frames += len(bufs)
         rounds += 1
