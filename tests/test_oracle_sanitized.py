@@ -38,6 +38,18 @@ for name in z["names"]:
         out = np.zeros((h, w), np.uint16)
         fn(out.ctypes.data, w, h, b.ctypes.data, b.size)
         n += 1
+# the post stage on exact-size buffers (odd widths: the last byte of a 12-bit row is half padding)
+lib.mcraw_oracle_post.restype = C.c_size_t
+lib.mcraw_oracle_post.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint, C.c_void_p]
+black = np.array([64, 65, 66, 4000], np.uint16)
+for (w, h) in ((1, 1), (2, 3), (13, 5), (64, 4), (101, 7)):
+    img = rng.integers(0, 65536, size=(h, w), dtype=np.uint16)
+    for flags in (0, 1, 2, 3):
+        rb = (w * 12 + 7) // 8 if flags & 2 else 2 * w
+        out = np.zeros(h * rb, np.uint8)
+        assert lib.mcraw_oracle_post(out.ctypes.data, img.ctypes.data, w, h, flags, black.ctypes.data) == out.size
+        assert np.array_equal(out.reshape(h, rb), L.post_np(img, black if flags & 1 else None, bool(flags & 2)))
+        n += 1
 print("sanitized ok", n)
 '''
 
