@@ -57,3 +57,36 @@ def test_product_does_not_link_oracle():
     for f in os.listdir(os.path.join(ROOT, "motioncam_decoder_amd", "csrc")):
         src = open(os.path.join(ROOT, "motioncam_decoder_amd", "csrc", f)).read()
         assert "oracle" not in src.lower(), f
+
+
+def _build_c_probe(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "abi_probe")
+    lib_dir = os.path.dirname(M.lib_path())
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c", "abi_probe.c"), "-L" + lib_dir, "-lmcraw_hip",
+                    "-Wl,-rpath," + lib_dir, "-o", exe], check=True)
+    return exe
+
+
+def test_header_is_plain_c_and_links_from_c(lib, tmp_path):
+    # include/mcraw_hip.h compiles as C99 with -pedantic -Werror; a C program links the library and, on a
+    # machine without a GPU, every call fails cleanly (no CPU fallback)
+    import subprocess
+    import torch
+    exe = _build_c_probe(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the decode leg runs in test_c_program_decodes")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ctx=no" in r.stdout and "decode7 returned 0" in r.stdout and "no CPU fallback" in r.stdout
+
+
+@pytest.mark.gpu
+def test_c_program_decodes(lib, tmp_path):
+    import subprocess
+    exe = _build_c_probe(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "ctx=yes" in r.stdout and "decode7 returned 256 first=0" in r.stdout
+    assert "set_post rc=0" in r.stdout and "set_post(NULL) rc=0" in r.stdout
