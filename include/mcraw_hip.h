@@ -87,6 +87,17 @@ size_t mcraw_decode6(uint16_t *output, int width, int height, const uint8_t *inp
 int mcraw_decode_batch(mcraw_ctx *ctx, const mcraw_frame *frames, int nframes, int mem,
                        void *stream, size_t *written, int32_t *status);
 
+/* Asynchronous host-memory batches (MCRAW_MEM_HOST semantics; buffers should be pinned): the call
+ * returns when the batch is queued, so the next one can be submitted while this one is still moving
+ * over PCIe -- the upload / kernel / download lanes then run back to back ACROSS batches, which a
+ * sequence of synchronous mcraw_decode_batch calls cannot do.  `frames` is copied; the in / out buffers
+ * must stay valid until mcraw_ticket_wait has returned for the ticket.  mcraw_ticket_wait blocks for that
+ * batch only, fills `written` / `status` (either may be NULL) and releases the ticket.  Wait for every
+ * ticket before mcraw_ctx_destroy.  Returns 0 or a negative value. */
+typedef struct mcraw_ticket mcraw_ticket;
+int mcraw_decode_batch_async(mcraw_ctx *ctx, const mcraw_frame *frames, int nframes, mcraw_ticket **ticket);
+int mcraw_ticket_wait(mcraw_ticket *ticket, size_t *written, int32_t *status);
+
 /* Wait for everything submitted on the context; fetch the statuses of the
  * last batch (status may be NULL).  Returns 0 or negative. */
 int mcraw_ctx_synchronize(mcraw_ctx *ctx, int32_t *status, int nframes);

@@ -30,7 +30,7 @@ KERNELS = {"k7_walk": 0, "k7_meta": 1, "k7_scan": 2, "k7_tiles": 3, "k6_maps": 4
 ABI_SYMBOLS = [
     "mcraw_ctx_create", "mcraw_ctx_destroy", "mcraw_last_error", "mcraw_decode7", "mcraw_decode6",
     "mcraw_decode_batch", "mcraw_ctx_synchronize", "mcraw_ctx_profile", "mcraw_ctx_kernel_ms",
-    "mcraw_host_alloc", "mcraw_host_free", "mcraw_ctx_set_post",
+    "mcraw_host_alloc", "mcraw_host_free", "mcraw_ctx_set_post", "mcraw_decode_batch_async", "mcraw_ticket_wait",
 ]
 
 POST_BLACK, POST_PACK12 = 1, 2
@@ -107,6 +107,10 @@ def load():
     lib.mcraw_host_alloc.argtypes = [C.c_size_t]
     lib.mcraw_host_free.restype = None
     lib.mcraw_host_free.argtypes = [C.c_void_p]
+    lib.mcraw_decode_batch_async.restype = C.c_int
+    lib.mcraw_decode_batch_async.argtypes = [C.c_void_p, C.POINTER(Frame), C.c_int, C.POINTER(C.c_void_p)]
+    lib.mcraw_ticket_wait.restype = C.c_int
+    lib.mcraw_ticket_wait.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
     lib.mcraw_ctx_set_post.restype = C.c_int
     lib.mcraw_ctx_set_post.argtypes = [C.c_void_p, C.POINTER(Post)]
     _lib = lib
@@ -159,6 +163,24 @@ class Context:
         if want_status:
             return list(written), list(status)
         return None
+
+    def decode_batch_async(self, frames):
+        """Host-memory batch, queued: returns a ticket for wait()."""
+        t = C.c_void_p()
+        rc = self._lib.mcraw_decode_batch_async(self._h, frames, len(frames), C.byref(t))
+        if rc != 0:
+            raise McrawError("mcraw_decode_batch_async failed (%d): %s" % (rc, self._lib.mcraw_last_error().decode()))
+        return (t, len(frames))
+
+    def wait(self, ticket):
+        """Blocks for that batch; returns (written, status)."""
+        t, n = ticket
+        written = (C.c_size_t * max(n, 1))()
+        status = (C.c_int32 * max(n, 1))()
+        rc = self._lib.mcraw_ticket_wait(t, written, status)
+        if rc != 0:
+            raise McrawError("mcraw_ticket_wait failed (%d): %s" % (rc, self._lib.mcraw_last_error().decode()))
+        return list(written)[:n], list(status)[:n]
 
     def synchronize(self, nframes=0):
         status = (C.c_int32 * max(nframes, 1))()

@@ -29,6 +29,8 @@ void launch_k6_rows(const Plan6 *plans, const uint32_t *item_base, int nframes, 
 
 using namespace mcraw;
 
+struct mcraw_ticket;
+
 namespace {
 
 thread_local std::string g_err;
@@ -46,7 +48,7 @@ int fail(hipError_t e, const char *what)
             return fail(e_, #expr);                                                                                    \
     } while (0)
 
-constexpr int NSLOT = 4;
+constexpr int NSLOT = 16;
 constexpr size_t ALIGN = 256;
 
 inline size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -68,10 +70,19 @@ struct Slot {
     std::vector<int> order;
     std::vector<int32_t> host_status;
     hipEvent_t done = nullptr;
+    ::mcraw_ticket *owner = nullptr; // host-memory batch whose statuses still sit in this slot's arena
+    int owner_part = -1;
     hipEvent_t uploaded = nullptr; // host-memory pipeline: inputs of the sub-batch are in HBM
     hipEvent_t decoded = nullptr;  // ... its kernels have run
     hipStream_t stream = nullptr; // the slot's own stream (host-memory pipeline: the kernels of a sub-batch)
     bool busy = false;
+};
+
+// One sub-batch of a host-memory batch, riding in a slot.
+struct Part {
+    int slot, first, count;
+    size_t status_off;
+    bool drained;
 };
 
 struct KStat {
@@ -81,6 +92,15 @@ struct KStat {
 };
 
 } // namespace
+
+// An asynchronous host-memory batch (mcraw_decode_batch_async / mcraw_ticket_wait).
+struct mcraw_ticket {
+    mcraw_ctx *c = nullptr;
+    std::vector<mcraw_frame> frames;
+    std::vector<int32_t> status;
+    std::vector<Part> parts;
+    uint32_t post_mode = 0; // output layout the batch was submitted with
+};
 
 struct mcraw_ctx {
     int device = 0;
@@ -390,13 +410,37 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     return 0;
 }
 
+int fetch_status(mcraw_ctx *c, Slot &s, size_t status_off, int n, hipStream_t st, int32_t *status);
+
+// Bring the statuses of one sub-batch home (they live in its slot's arena) and wait for its downloads:
+// the slot is free afterwards.
+int drain_part(mcraw_ticket *t, int idx)
+{
+    Part &p = t->parts[idx];
+    if (p.drained)
+        return 0;
+    Slot &s = t->c->slots[p.slot];
+    if (int rc = fetch_status(t->c, s, p.status_off, p.count, s.stream, t->status.data() + p.first))
+        return rc;
+    HIP_TRY(hipEventSynchronize(s.done)); // its downloads, queued on the download stream
+    s.busy = false;
+    s.owner = nullptr;
+    p.drained = true;
+    return 0;
+}
+
 int acquire_slot(mcraw_ctx *c, Slot **out)
 {
     Slot &s = c->slots[c->next_slot];
     c->next_slot = (c->next_slot + 1) % NSLOT;
     if (s.busy) {
-        HIP_TRY(hipEventSynchronize(s.done));
-        s.busy = false;
+        if (s.owner) { // an asynchronous batch still keeps its statuses here
+            if (int rc = drain_part(s.owner, s.owner_part))
+                return rc;
+        } else {
+            HIP_TRY(hipEventSynchronize(s.done));
+            s.busy = false;
+        }
     }
     *out = &s;
     return 0;
@@ -505,16 +549,15 @@ int decode_device(mcraw_ctx *c, const mcraw_frame *frames, int n, hipStream_t st
 // one execute (BASELINE config 3: "pinned H2D + decode overlapped on HIP streams").  With the copies
 // of a sub-batch on its slot's own stream (first version) the engines idled between sub-batches:
 // 2 150 instead of 2 630 UHD frames/s.
-int decode_host(mcraw_ctx *c, const mcraw_frame *frames, int n, size_t *written, int32_t *status_out)
+// Queue a host-memory batch (ticket->frames): returns when the last sub-batch is submitted.
+int host_submit(mcraw_ticket *t)
 {
+    mcraw_ctx *c = t->c;
+    const mcraw_frame *frames = t->frames.data();
+    const int n = static_cast<int>(t->frames.size());
     constexpr size_t SUB_BYTES = 96ull << 20; // compressed + decoded bytes per sub-batch (64-160 MB measure within 3 %)
-    struct Pending {
-        Slot *s;
-        int first, count;
-        size_t status_off;
-    };
-    std::vector<Pending> pend;
-    std::vector<int32_t> status(n, 0);
+    t->status.assign(n, 0);
+    t->post_mode = c->post.mode;
     int first = 0;
     while (first < n) {
         size_t bytes = 0;
@@ -578,24 +621,35 @@ int decode_host(mcraw_ctx *c, const mcraw_frame *frames, int n, size_t *written,
         }
         HIP_TRY(hipEventRecord(s.done, c->d2h));
         s.busy = true;
-        pend.push_back({sp, first, count, status_off});
-        // more sub-batches than slots: drain the oldest before its slot is reused
-        if (pend.size() >= static_cast<size_t>(NSLOT)) {
-            Pending &p = pend.front();
-            if (int rc = fetch_status(c, *p.s, p.status_off, p.count, p.s->stream, status.data() + p.first))
-                return rc;
-            HIP_TRY(hipEventSynchronize(p.s->done)); // its downloads, queued on the download stream
-            p.s->busy = false;
-            pend.erase(pend.begin());
-        }
+        // the slot keeps this sub-batch's statuses until they are drained into the ticket: by
+        // mcraw_ticket_wait, or earlier by acquire_slot when the ring comes round (more sub-batches in
+        // flight than slots)
+        s.owner = t;
+        s.owner_part = static_cast<int>(t->parts.size());
+        t->parts.push_back({static_cast<int>(sp - c->slots), first, count, status_off, false});
         first += count;
     }
-    for (Pending &p : pend) {
-        if (int rc = fetch_status(c, *p.s, p.status_off, p.count, p.s->stream, status.data() + p.first))
+    return 0;
+}
+
+// Wait for a host-memory batch and resolve its statuses.
+int host_finish(mcraw_ticket *t, size_t *written, int32_t *status_out)
+{
+    mcraw_ctx *c = t->c;
+    const mcraw_frame *frames = t->frames.data();
+    const int n = static_cast<int>(t->frames.size());
+    std::vector<int32_t> &status = t->status;
+    for (size_t k = 0; k < t->parts.size(); k++)
+        if (int rc = drain_part(t, static_cast<int>(k)))
             return rc;
-        HIP_TRY(hipEventSynchronize(p.s->done));
-        p.s->busy = false;
-    }
+    const Post post_now = c->post;
+    c->post.mode = t->post_mode; // a re-planned frame is written in the layout the batch was submitted with
+    struct RestorePost {
+        mcraw_ctx *c;
+        Post p;
+        ~RestorePost() { c->post = p; }
+    } restore{c, post_now};
+    (void)restore;
 
     // geometry mismatches: the header is readable on the host here
     for (int i = 0; i < n; i++) {
@@ -636,6 +690,29 @@ int decode_host(mcraw_ctx *c, const mcraw_frame *frames, int n, size_t *written,
             written[i] = written_of(frames[i], status[i], encH);
     }
     return 0;
+}
+
+// A ticket that goes away (finished, or failed half way) must not be pointed at by a slot.
+void forget_ticket(mcraw_ticket *t)
+{
+    for (Slot &s : t->c->slots)
+        if (s.owner == t) {
+            s.owner = nullptr; // the slot stays busy until its `done` event: acquire_slot waits for it
+            s.owner_part = -1;
+        }
+}
+
+// Synchronous host-memory batch.
+int decode_host(mcraw_ctx *c, const mcraw_frame *frames, int n, size_t *written, int32_t *status_out)
+{
+    mcraw_ticket t;
+    t.c = c;
+    t.frames.assign(frames, frames + n);
+    int rc = host_submit(&t);
+    if (rc == 0)
+        rc = host_finish(&t, written, status_out);
+    forget_ticket(&t);
+    return rc;
 }
 
 mcraw_ctx *g_default = nullptr;
@@ -771,6 +848,44 @@ int mcraw_decode_batch(mcraw_ctx *c, const mcraw_frame *frames, int nframes, int
     return -1;
 }
 
+int mcraw_decode_batch_async(mcraw_ctx *c, const mcraw_frame *frames, int nframes, mcraw_ticket **ticket)
+{
+    if (ticket)
+        *ticket = nullptr;
+    if (!c || !ticket || (!frames && nframes > 0) || nframes < 0) {
+        g_err = "mcraw_decode_batch_async: bad arguments";
+        return -1;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    mcraw_ticket *t = new mcraw_ticket();
+    t->c = c;
+    if (nframes)
+        t->frames.assign(frames, frames + nframes);
+    if (int rc = host_submit(t)) {
+        forget_ticket(t);
+        delete t;
+        return rc;
+    }
+    *ticket = t;
+    return 0;
+}
+
+int mcraw_ticket_wait(mcraw_ticket *t, size_t *written, int32_t *status)
+{
+    if (!t)
+        return -1;
+    mcraw_ctx *c = t->c;
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        rc = hipSetDevice(c->device) == hipSuccess ? host_finish(t, written, status) : -static_cast<int>(hipErrorInvalidDevice);
+        forget_ticket(t);
+    }
+    delete t;
+    return rc;
+}
+
 int mcraw_ctx_synchronize(mcraw_ctx *c, int32_t *status, int nframes)
 {
     if (!c)
@@ -779,6 +894,11 @@ int mcraw_ctx_synchronize(mcraw_ctx *c, int32_t *status, int nframes)
     HIP_TRY(hipSetDevice(c->device));
     for (Slot &s : c->slots)
         if (s.busy) {
+            if (s.owner) { // an asynchronous host-memory batch keeps its statuses: file them in its ticket
+                if (int rc = drain_part(s.owner, s.owner_part))
+                    return rc;
+                continue;
+            }
             HIP_TRY(hipEventSynchronize(s.done));
             s.busy = false;
         }

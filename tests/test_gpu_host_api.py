@@ -96,3 +96,58 @@ def test_concurrent_host_threads(gpu_ctx, golden):
     for t in threads:
         t.join(timeout=300)
     assert not errors, errors[:5]
+
+
+def test_async_tickets_keep_several_batches_in_flight(gpu_ctx):
+    # three host-memory batches queued back to back (together far more sub-batches than the context has
+    # slots, so statuses of early parts are filed into their tickets when the slot ring comes round),
+    # waited for out of order; one batch carries a truncated frame and a legacy frame
+    w, h = 4032, 3024
+    imgs = [L.synth_image(w, h, 12, 1, 12.0, 8000 + i) for i in range(3)]
+    bufs7 = [L.encode7(im) for im in imgs]
+    small = L.natural_image_np(800, 600, 12, 12.0, 9)
+    buf6 = L.encode6(small)
+    trunc = bufs7[0][: bufs7[0].size // 2].copy()
+    batches, keep = [], []
+    for b in range(3):
+        items = [(7, w, h, bufs7[(b + k) % 3], imgs[(b + k) % 3]) for k in range(9)]
+        if b == 1:
+            items.insert(4, (7, w, h, trunc, None))
+            items.append((6, 800, 600, buf6, small))
+        descs, outs = [], []
+        for typ, ww, hh, buf, img in items:
+            out = np.full((hh, ww), 0xA5A5, np.uint16)
+            outs.append(out)
+            descs.append((buf.ctypes.data, buf.size, ww, hh, typ, out.ctypes.data, ww * hh))
+        batches.append((items, outs, M.Context.make_frames(descs)))
+    tickets = [gpu_ctx.decode_batch_async(fr) for (_, _, fr) in batches]
+    for b in (1, 0, 2):
+        items, outs, _ = batches[b]
+        written, status = gpu_ctx.wait(tickets[b])
+        for i, (typ, ww, hh, buf, img) in enumerate(items):
+            if img is None:
+                assert status[i] != 0 and written[i] == 0, (b, i, status[i])  # cut in half: side-stream offsets past len
+            else:
+                assert status[i] == 0 and written[i] == ww * hh, (b, i, status[i])
+                assert np.array_equal(outs[i], img), (b, i)
+    # the synchronous entry still works beside it, and so does an empty asynchronous batch
+    out = np.zeros((600, 800), np.uint16)
+    fr = M.Context.make_frames([(buf6.ctypes.data, buf6.size, 800, 600, 6, out.ctypes.data, 800 * 600)])
+    written, status = gpu_ctx.decode_batch(fr, mem=M.MEM_HOST)
+    assert status == [0] and np.array_equal(out, small)
+    assert gpu_ctx.wait(gpu_ctx.decode_batch_async(M.Context.make_frames([]))) == ([], [])
+
+
+def test_async_ticket_survives_context_synchronize(gpu_ctx):
+    # mcraw_ctx_synchronize in between must not lose the statuses of a queued batch
+    img = L.natural_image_np(1920, 1080, 12, 12.0, 21)
+    buf = L.encode7(img)
+    bad = buf[:1000].copy()
+    outs = [np.zeros((1080, 1920), np.uint16) for _ in range(2)]
+    fr = M.Context.make_frames([(buf.ctypes.data, buf.size, 1920, 1080, 7, outs[0].ctypes.data, 1920 * 1080),
+                                (bad.ctypes.data, bad.size, 1920, 1080, 7, outs[1].ctypes.data, 1920 * 1080)])
+    t = gpu_ctx.decode_batch_async(fr)
+    gpu_ctx.synchronize()
+    written, status = gpu_ctx.wait(t)
+    assert status[0] == 0 and written[0] == 1920 * 1080 and np.array_equal(outs[0], img)
+    assert status[1] != 0 and written[1] == 0
