@@ -48,7 +48,8 @@ int fail(hipError_t e, const char *what)
             return fail(e_, #expr);                                                                                    \
     } while (0)
 
-constexpr int NSLOT = 16;
+constexpr int NSLOT = 16; // host-memory sub-batches in flight (two batches of five, with room)
+constexpr int NDSLOT = 4; // device-memory batches the host may run ahead by
 constexpr size_t ALIGN = 256;
 
 inline size_t up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -106,8 +107,10 @@ struct mcraw_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t h2d = nullptr, d2h = nullptr; // host-memory pipeline: one stream per copy direction
-    Slot slots[NSLOT];
+    Slot slots[NSLOT];   // host-memory pipeline
     int next_slot = 0;
+    Slot dslots[NDSLOT]; // device-memory batches (tables + workspace only)
+    int next_dslot = 0;
     uint32_t profile = 0; // bit id: bracket launches of kernel id with events
     Post post{0, 0, 0};   // fused post-decode stage of the batches to come (mcraw_ctx_set_post)
     KStat kstat[MCRAW_K_COUNT];
@@ -429,10 +432,13 @@ int drain_part(mcraw_ticket *t, int idx)
     return 0;
 }
 
-int acquire_slot(mcraw_ctx *c, Slot **out)
+int acquire_slot(mcraw_ctx *c, Slot **out, bool device_batch = false)
 {
-    Slot &s = c->slots[c->next_slot];
-    c->next_slot = (c->next_slot + 1) % NSLOT;
+    Slot &s = device_batch ? c->dslots[c->next_dslot] : c->slots[c->next_slot];
+    if (device_batch)
+        c->next_dslot = (c->next_dslot + 1) % NDSLOT;
+    else
+        c->next_slot = (c->next_slot + 1) % NSLOT;
     if (s.busy) {
         if (s.owner) { // an asynchronous batch still keeps its statuses here
             if (int rc = drain_part(s.owner, s.owner_part))
@@ -481,7 +487,7 @@ size_t written_of(const mcraw_frame &f, int32_t status, uint32_t encH)
 int decode_device(mcraw_ctx *c, const mcraw_frame *frames, int n, hipStream_t st, size_t *written, int32_t *status_out)
 {
     Slot *sp = nullptr;
-    if (int rc = acquire_slot(c, &sp))
+    if (int rc = acquire_slot(c, &sp, true))
         return rc;
     Slot &s = *sp;
     size_t status_off = 0;
@@ -489,7 +495,7 @@ int decode_device(mcraw_ctx *c, const mcraw_frame *frames, int n, hipStream_t st
         return rc;
     HIP_TRY(hipEventRecord(s.done, st));
     s.busy = true;
-    c->last_slot = static_cast<int>(sp - c->slots);
+    c->last_slot = static_cast<int>(sp - c->dslots);
     c->last_n = n;
     c->last_status_off = status_off;
     if (!written && !status_out)
@@ -519,7 +525,7 @@ int decode_device(mcraw_ctx *c, const mcraw_frame *frames, int n, hipStream_t st
             rg[k] = {hdr[0], hdr[1], 1u};
         }
         Slot *s2 = nullptr;
-        if (int rc = acquire_slot(c, &s2))
+        if (int rc = acquire_slot(c, &s2, true))
             return rc;
         size_t off2 = 0;
         if (int rc = submit(c, *s2, rf.data(), static_cast<int>(rf.size()), &rg, nullptr, nullptr, st, &off2))
@@ -792,6 +798,8 @@ int mcraw_ctx_create(int device, mcraw_ctx **out)
         HIP_TRY(hipEventCreateWithFlags(&s.decoded, hipEventDisableTiming));
         HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     }
+    for (Slot &s : c->dslots)
+        HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     *out = c;
     return 0;
 }
@@ -802,7 +810,7 @@ void mcraw_ctx_destroy(mcraw_ctx *c)
         return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    for (Slot &s : c->slots) {
+    auto release = [](Slot &s) {
         if (s.pinned.p) (void)hipHostFree(s.pinned.p);
         if (s.status_host.p) (void)hipHostFree(s.status_host.p);
         if (s.arena.p) (void)hipFree(s.arena.p);
@@ -812,7 +820,11 @@ void mcraw_ctx_destroy(mcraw_ctx *c)
         if (s.uploaded) (void)hipEventDestroy(s.uploaded);
         if (s.decoded) (void)hipEventDestroy(s.decoded);
         if (s.stream) (void)hipStreamDestroy(s.stream);
-    }
+    };
+    for (Slot &s : c->slots)
+        release(s);
+    for (Slot &s : c->dslots)
+        release(s);
     for (KStat &k : c->kstat)
         for (auto &p : k.pending) {
             (void)hipEventDestroy(p.first);
@@ -902,8 +914,13 @@ int mcraw_ctx_synchronize(mcraw_ctx *c, int32_t *status, int nframes)
             HIP_TRY(hipEventSynchronize(s.done));
             s.busy = false;
         }
+    for (Slot &s : c->dslots)
+        if (s.busy) {
+            HIP_TRY(hipEventSynchronize(s.done));
+            s.busy = false;
+        }
     if (status && c->last_slot >= 0) {
-        Slot &s = c->slots[c->last_slot];
+        Slot &s = c->dslots[c->last_slot];
         int n = std::min(nframes, c->last_n);
         if (int rc = fetch_status(c, s, c->last_status_off, n, c->stream, status))
             return rc;
