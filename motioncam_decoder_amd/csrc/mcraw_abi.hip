@@ -100,7 +100,7 @@ struct mcraw_ticket {
     std::vector<mcraw_frame> frames;
     std::vector<int32_t> status;
     std::vector<Part> parts;
-    uint32_t post_mode = 0; // output layout the batch was submitted with
+    Post post{0, 0, 0}; // post stage the batch was submitted with
 };
 
 struct mcraw_ctx {
@@ -563,7 +563,7 @@ int host_submit(mcraw_ticket *t)
     const int n = static_cast<int>(t->frames.size());
     constexpr size_t SUB_BYTES = 96ull << 20; // compressed + decoded bytes per sub-batch (64-160 MB measure within 3 %)
     t->status.assign(n, 0);
-    t->post_mode = c->post.mode;
+    t->post = c->post;
     int first = 0;
     while (first < n) {
         size_t bytes = 0;
@@ -649,7 +649,7 @@ int host_finish(mcraw_ticket *t, size_t *written, int32_t *status_out)
         if (int rc = drain_part(t, static_cast<int>(k)))
             return rc;
     const Post post_now = c->post;
-    c->post.mode = t->post_mode; // a re-planned frame is written in the layout the batch was submitted with
+    c->post = t->post; // a re-planned frame gets the post stage the batch was submitted with
     struct RestorePost {
         mcraw_ctx *c;
         Post p;
