@@ -155,3 +155,39 @@ def test_abi_edge_arguments(gpu_ctx):
     # the context is still good
     written, status = gpu_ctx.decode_batch(M.Context.make_frames([cases[0][0]]))
     assert status == [0] and written == [w * h]
+
+
+def test_replanned_frames_in_host_memory_batches(gpu_ctx):
+    # the re-plan path of the host-memory pipeline (synchronous and ticketed), with and without the
+    # post stage: a frame coded larger than ceil64(w) x ceil4(h), between two ordinary frames
+    big = L.natural_image_np(320, 24, 12, 12.0, 11)
+    odd = L.encode7(big)                       # encW=320, encH=24, decoded into a 200x16 window
+    plain = L.natural_image_np(256, 16, 12, 12.0, 12)
+    pbuf = L.encode7(plain)
+    window = big[:16, :200]
+    for black, pack12 in ((None, False), ([64, 65, 66, 67], True)):
+        for use_ticket in (False, True):
+            items = [(pbuf, 256, 16, plain), (odd, 200, 16, window), (pbuf, 256, 16, plain)]
+            outs, descs = [], []
+            for buf, w, h, img in items:
+                rb = L.post_row_bytes(w, pack12)
+                o = np.full(h * rb + 16, 0xA5, np.uint8)
+                outs.append(o)
+                descs.append((buf.ctypes.data, buf.size, w, h, 7, o.ctypes.data, (h * rb + 1) // 2))
+            frames = M.Context.make_frames(descs)
+            gpu_ctx.set_post(black=black, pack12=pack12)
+            try:
+                if use_ticket:
+                    t = gpu_ctx.decode_batch_async(frames)
+                    gpu_ctx.set_post()  # the ticket keeps the stage it was submitted with
+                    written, status = gpu_ctx.wait(t)
+                else:
+                    written, status = gpu_ctx.decode_batch(frames, mem=M.MEM_HOST)
+            finally:
+                gpu_ctx.set_post()
+            for (buf, w, h, img), o, wr, st in zip(items, outs, written, status):
+                assert st == 0 and wr == w * h, (black, pack12, use_ticket, st, wr)
+                rb = L.post_row_bytes(w, pack12)
+                want = L.oracle_post(img, black, pack12)
+                assert np.array_equal(o[: h * rb].reshape(h, rb), want), (black, pack12, use_ticket, w, h)
+                assert (o[h * rb:] == 0xA5).all()
