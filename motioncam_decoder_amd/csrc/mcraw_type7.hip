@@ -27,10 +27,10 @@ namespace mcraw {
 // byte-domain terms ((P[p][j] >> s) & (2^n - 1)) << l, plus (Decode10 only) a
 // 2-bit term that lands in bits 8..9.  Lane j of the reference's 8-wide SIMD
 // is byte j of an 8-byte plane; sample index = 8*k + j.  One row per
-// (class, k): {term0, term1, term2, term_hi}, a term = p*8 | s<<8 | n<<16 | l<<24.
+// (class, k): {term0, term1, term2, term_hi}, a term = p*8 | s<<8 | (2^n - 1)<<16 | l<<24.
 // Rows follow lib/RawData.cpp: Decode1 :112-136, Decode2 :138-162, Decode3 :164-199,
 // Decode4 :201-223, Decode5 :225-262, Decode6 :264-304, Decode8 :306-326, Decode10 :328-374.
-#define TM(p, s, n, l) ((uint32_t)((p) * 8) | ((uint32_t)(s) << 8) | ((uint32_t)(n) << 16) | ((uint32_t)(l) << 24))
+#define TM(p, s, n, l) ((uint32_t)((p) * 8) | ((uint32_t)(s) << 8) | ((uint32_t)((1u << (n)) - 1u) << 16) | ((uint32_t)(l) << 24))
 #define Z 0u
 #define ROW1(k) {TM(0, k, 1, 0), Z, Z, Z}
 #define ROW2(k) {TM((k) >> 2, 2 * ((k)&3), 2, 0), Z, Z, Z}
@@ -63,7 +63,8 @@ __constant__ uint32_t c_tab7[9 * 8][4] = {
 
 __device__ __forceinline__ uint32_t term_off(uint32_t t) { return t & 0xffu; }
 __device__ __forceinline__ uint32_t term_shr(uint32_t t) { return (t >> 8) & 31u; }
-__device__ __forceinline__ uint32_t term_bits(uint32_t t) { return (t >> 16) & 31u; }
+// the field mask 2^n - 1 of the term in every byte lane (one v_perm_b32; a multiply by 0x01010101 is quarter rate)
+__device__ __forceinline__ uint32_t term_mask(uint32_t t) { return __builtin_amdgcn_perm(t, t, 0x02020202u); }
 __device__ __forceinline__ uint32_t term_shl(uint32_t t) { return (t >> 24) & 31u; }
 
 // ------------------------------------------------------------------ block unpack
@@ -109,7 +110,7 @@ __device__ __forceinline__ Unpacked unpack8(const uint8_t *__restrict__ base, ui
         if (!ALIGNED8 && t > 0 && !__any(tm != 0u))
             continue;
         const uint2 p = lds_read8<ALIGNED8>(base, blk + term_off(tm));
-        const uint32_t m = ((1u << term_bits(tm)) - 1u) * 0x01010101u;
+        const uint32_t m = term_mask(tm);
         lo |= ((p.x >> term_shr(tm)) & m) << term_shl(tm);
         hi |= ((p.y >> term_shr(tm)) & m) << term_shl(tm);
     }
@@ -117,7 +118,7 @@ __device__ __forceinline__ Unpacked unpack8(const uint8_t *__restrict__ base, ui
     uint32_t lo8 = 0, hi8 = 0;
     if (ALIGNED8 || __any(th != 0u)) {
         const uint2 ph = lds_read8<ALIGNED8>(base, blk + term_off(th));
-        const uint32_t mh = ((1u << term_bits(th)) - 1u) * 0x01010101u;
+        const uint32_t mh = term_mask(th);
         lo8 = (ph.x >> term_shr(th)) & mh;
         hi8 = (ph.y >> term_shr(th)) & mh;
     }
