@@ -49,6 +49,12 @@ __device__ __forceinline__ uint4 ld_b128(__amdgpu_buffer_rsrc_t r, uint32_t off)
     return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
 
+// The same load marked non-temporal (read once, streaming).
+__device__ __forceinline__ uint4 ld_b128_nt(__amdgpu_buffer_rsrc_t r, uint32_t off)
+{
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 2));
+}
+
 // Largest f with base[f] <= item (base has n+1 ascending entries, base[0] = 0).
 __device__ __forceinline__ int find_frame(uint32_t item, const uint32_t *__restrict__ base, int n)
 {

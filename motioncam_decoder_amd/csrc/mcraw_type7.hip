@@ -879,7 +879,7 @@ __global__ __launch_bounds__(256) void k7_tiles(const Work7 W, uint32_t total)
     for (uint32_t c = 0; c < NV; c++) {
         v[c] = make_uint4(0, 0, 0, 0);
         if (ABL != 3 && lane + 64u * c < I.n16)
-            v[c] = ld_b128(rs, I.base16 + (lane + 64u * c) * 16u);
+            v[c] = ld_b128_nt(rs, I.base16 + (lane + 64u * c) * 16u);
     }
     uint32_t b = 0, r = 0;
     if (I.valid && lane < ITEM_BLOCKS && I.g * ITEM_BLOCKS + lane < I.nblk) {
