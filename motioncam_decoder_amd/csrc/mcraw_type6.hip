@@ -264,13 +264,16 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
     __shared__ __attribute__((aligned(4))) uint16_t s_pos[4][ROWS_CAP + 2]; // record r of a round at [r - wlo], wlo even
     __shared__ uint32_t s_ent[4 * ROWS_CH];
 
-    const int f = find_frame(blockIdx.x, item_base, nframes);
+    // workgroups run over the batch BACKWARDS: k6_maps has just streamed the whole input through the
+    // Infinity Cache front to back, so its tail -- what a backward pass touches first -- is still there
+    const uint32_t bid = gridDim.x - 1u - blockIdx.x;
+    const int f = find_frame(bid, item_base, nframes);
     const Plan6 *P = plans + f;
     if (*P->status != 0)
         return; // whole workgroup
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t nchunks = P->nchunks, nrec = P->nrec, len = P->len;
-    const uint32_t c0 = ((blockIdx.x - item_base[f]) * 4u + wave) * ROWS_CH;
+    const uint32_t c0 = ((bid - item_base[f]) * 4u + wave) * ROWS_CH;
     const bool have = c0 < nchunks;
     // entries of my chunks (lane j) and of the chunk after them (lane ROWS_CH)
     uint32_t e = DEAD;
