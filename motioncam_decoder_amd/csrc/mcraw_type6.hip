@@ -400,11 +400,13 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
     const bool walker = lane < ROWS_CH && (e & 255u) != DEAD && c0 + lane < nchunks;
     // the last walking lane carries on past its chunk for the partner of an even last record
     const bool lastw = walker && (lane + 1u == ROWS_CH || c0 + lane + 1u >= nchunks);
+    // a walker keeps its place from round to round (restarting at the chunk entry every round made a
+    // run of 2-byte records cost rounds x 512 steps per lane)
+    uint32_t pos = 2u * (e & 255u), idx = e >> 8;
     for (uint32_t base = 0; base < N; base += ROWS_CAP) {
         const uint32_t wlo = R0 + base, whi = min(R1, wlo + ROWS_CAP); // records listed this round (both even)
         if (K6_ABL != 3 && walker) {
             const uint32_t off = lane * CHUNK6;
-            uint32_t pos = 2u * (e & 255u), idx = e >> 8;
             while (idx < whi && (pos < CHUNK6 || (lastw && idx < R1))) {
                 const uint32_t nx = pos + 2u + len6_of(static_cast<uint32_t>(bytes[off + pos]) >> 4);
                 if (cs0 + off + nx >= len)
