@@ -408,6 +408,21 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
         if (K6_ABL != 3 && walker) {
             const uint32_t off = lane * CHUNK6;
             while (idx < whi && (pos < CHUNK6 || (lastw && idx < R1))) {
+                // Runs of 2-byte records (flat or clipped image regions) are what makes a wave land here:
+                // eight of them fill an aligned 16-byte line whose even bytes all have a zero high
+                // nibble -- one LDS read then lists eight records instead of one.
+                const uint32_t a = off + pos;
+                if ((a & 15u) == 0u && pos + 16u <= CHUNK6 && idx >= wlo && idx + 8u <= whi && cs0 + a + 16u < len) {
+                    const uint4 q = *reinterpret_cast<const uint4 *>(bytes + a);
+                    if (((q.x | q.y | q.z | q.w) & 0x00F000F0u) == 0u) {
+#pragma unroll
+                        for (uint32_t k = 0; k < 8u; k++)
+                            s_pos[wave][idx - wlo + k] = static_cast<uint16_t>(a + 2u * k);
+                        pos += 16u;
+                        idx += 8u;
+                        continue;
+                    }
+                }
                 const uint32_t nx = pos + 2u + len6_of(static_cast<uint32_t>(bytes[off + pos]) >> 4);
                 if (cs0 + off + nx >= len)
                     break; // k6_frame has already failed the frame if records are missing
