@@ -288,6 +288,40 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     }
     const int n7 = static_cast<int>(B.p7.size()), n6 = static_cast<int>(B.p6.size());
 
+    // Type-7 plans in order of decreasing size, cut into size classes: the unpack kernel is launched
+    // once per class with that class's group count, so a batch that mixes small and large frames does
+    // not spend the largest frame's grid on every frame (BASELINE config 4 mixes 2 MP and 12 MP frames).
+    uint32_t nclasses = 0, class_first[Work7::MAX_CLASSES + 1] = {0}, class_groups[Work7::MAX_CLASSES] = {0};
+    if (n7) {
+        std::vector<int> perm(n7);
+        for (int k = 0; k < n7; k++)
+            perm[k] = k;
+        std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return B.p7[a].ngroups > B.p7[b].ngroups; });
+        bool sorted = true;
+        for (int k = 0; k < n7; k++)
+            sorted = sorted && perm[k] == k;
+        if (!sorted) {
+            std::vector<Plan7> p7(n7);
+            std::vector<int> idx7(n7);
+            for (int k = 0; k < n7; k++) {
+                p7[k] = B.p7[perm[k]];
+                idx7[k] = B.idx7[perm[k]];
+            }
+            B.p7.swap(p7);
+            B.idx7.swap(idx7);
+        }
+        for (int k = 0; k < n7; k++) {
+            const uint32_t g = B.p7[k].ngroups;
+            // a frame joins the current class while it wastes at most a fifth of the class's grid
+            if (nclasses == 0 || (g * 5u < class_groups[nclasses - 1] * 4u && nclasses < static_cast<uint32_t>(Work7::MAX_CLASSES))) {
+                class_first[nclasses] = static_cast<uint32_t>(k);
+                class_groups[nclasses] = g;
+                nclasses++;
+            }
+        }
+        class_first[nclasses] = static_cast<uint32_t>(n7);
+    }
+
     // ---- lay out the upload image and the workspace ------------------------
     Layout L;
     size_t off = 0;
@@ -388,6 +422,11 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         W.Rmax = static_cast<uint32_t>(Rmax);
         W.n7 = n7;
         W.post = c->post;
+        W.nclasses = nclasses;
+        for (uint32_t k = 0; k <= nclasses; k++)
+            W.class_first[k] = class_first[k];
+        for (uint32_t k = 0; k < nclasses; k++)
+            W.class_groups[k] = class_groups[k];
         for (uint32_t stage : {MCRAW_K7_WALK, MCRAW_K7_META, MCRAW_K7_SCAN, MCRAW_K7_TILES}) {
             KTimer t(c, static_cast<int>(stage), st);
             launch_k7(W, stage, st);

@@ -80,6 +80,13 @@ struct Work7 {
     uint32_t nch;        // side-stream chunks planned per stream (covers Rmax records of 130 bytes)
     int32_t n7;
     Post post;           // fused post-decode stage (mode 0: none)
+    // k7_tiles is launched once per SIZE CLASS of the batch (plans are sorted by ngroups, descending):
+    // frames [class_first[k], class_first[k+1]) get class_groups[k] decode groups each, so a batch that
+    // mixes small and large frames does not pay the largest frame's grid for every frame
+    static constexpr int MAX_CLASSES = 8;
+    uint32_t nclasses;
+    uint32_t class_first[MAX_CLASSES + 1];
+    uint32_t class_groups[MAX_CLASSES];
 };
 
 // Per-frame plan of the legacy ("type 6") encoding.

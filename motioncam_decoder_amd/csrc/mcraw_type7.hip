@@ -723,12 +723,14 @@ struct ItemS {
     size_t meta;         // index of the group's first entry in W.bits / W.refs
 };
 
-__device__ __forceinline__ ItemS item_scalars(const Work7 &W, uint32_t item)
+__device__ __forceinline__ ItemS item_scalars(const Work7 &W, uint32_t item, uint32_t first_frame, uint32_t class_groups)
 {
     ItemS I;
-    const uint32_t per = W.Rmax * ITEM_SPLIT; // items planned per frame
-    const uint32_t f = item / per;
-    const uint32_t g = item - f * per;
+    const uint32_t per = W.Rmax * ITEM_SPLIT;         // items of the uniform-stride workspace per frame
+    const uint32_t cper = class_groups * ITEM_SPLIT;  // items this launch spends on each frame of its size class
+    const uint32_t fc = item / cper;
+    const uint32_t f = first_frame + fc;
+    const uint32_t g = item - fc * cper;
     const Plan7 *P = W.plans + f;
     const uint32_t *grp = W.grp_off + static_cast<size_t>(f) * (per + 1u) + g;
     const uint32_t start = grp[0], end = grp[1];
@@ -851,7 +853,7 @@ __device__ __forceinline__ void item_decode(const ItemS &I, const Post &post, ui
 // tiles in four rounds of 64 lanes.  The only workgroup-wide event is the barrier
 // that publishes the shared term table.
 template <int ABL, bool NT, bool POST = false>
-__global__ __launch_bounds__(256) void k7_tiles(const Work7 W, uint32_t total)
+__global__ __launch_bounds__(256) void k7_tiles(const Work7 W, uint32_t total, uint32_t first_frame, uint32_t class_groups)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_pay[4][PAY_LDS];
     __shared__ uint4 s_tab[72];
@@ -869,7 +871,7 @@ __global__ __launch_bounds__(256) void k7_tiles(const Work7 W, uint32_t total)
     I.valid = 0;
     I.n16 = 0;
     if (item < total)
-        I = item_scalars(W, item);
+        I = item_scalars(W, item, first_frame, class_groups);
 
     // span -> registers: 16-byte chunks lane, lane+64, ... (ITEM_SPAN + alignment head)
     constexpr uint32_t NV = (PAY_CHUNKS + 63u) / 64u;
@@ -959,28 +961,35 @@ void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st)
         hipLaunchKernelGGL(k7_scan, dim3(n7), dim3(1024), 0, st, W);
         break;
     case MCRAW_K7_TILES: {
-        const uint32_t total = W.Rmax * ITEM_SPLIT * n7;
-        const dim3 grid((total + 3) / 4);
-        if (W.post.mode != 0u) {
-            hipLaunchKernelGGL((k7_tiles<0, true, true>), grid, dim3(256), 0, st, W, total);
-            break;
-        }
 #ifdef MCRAW_DIAG // timing experiments of the same kernel (see item_decode); not in the product library
         static const int abl = []() {
             const char *e = std::getenv("MCRAW_ABLATE");
             return e ? std::atoi(e) : 0;
         }();
-        if (abl == 1)
-            hipLaunchKernelGGL((k7_tiles<1, true>), grid, dim3(256), 0, st, W, total);
-        else if (abl == 2)
-            hipLaunchKernelGGL((k7_tiles<2, true>), grid, dim3(256), 0, st, W, total);
-        else if (abl == 3)
-            hipLaunchKernelGGL((k7_tiles<3, true>), grid, dim3(256), 0, st, W, total);
-        else if (abl == 4)
-            hipLaunchKernelGGL((k7_tiles<0, false>), grid, dim3(256), 0, st, W, total);
-        else
 #endif
-            hipLaunchKernelGGL((k7_tiles<0, true>), grid, dim3(256), 0, st, W, total);
+        for (uint32_t k = 0; k < W.nclasses; k++) { // one launch per size class (a homogeneous batch has one)
+            const uint32_t first = W.class_first[k], count = W.class_first[k + 1] - first, groups = W.class_groups[k];
+            const uint32_t total = groups * ITEM_SPLIT * count;
+            if (total == 0u)
+                continue;
+            const dim3 grid((total + 3) / 4);
+            if (W.post.mode != 0u) {
+                hipLaunchKernelGGL((k7_tiles<0, true, true>), grid, dim3(256), 0, st, W, total, first, groups);
+                continue;
+            }
+#ifdef MCRAW_DIAG
+            if (abl == 1)
+                hipLaunchKernelGGL((k7_tiles<1, true>), grid, dim3(256), 0, st, W, total, first, groups);
+            else if (abl == 2)
+                hipLaunchKernelGGL((k7_tiles<2, true>), grid, dim3(256), 0, st, W, total, first, groups);
+            else if (abl == 3)
+                hipLaunchKernelGGL((k7_tiles<3, true>), grid, dim3(256), 0, st, W, total, first, groups);
+            else if (abl == 4)
+                hipLaunchKernelGGL((k7_tiles<0, false>), grid, dim3(256), 0, st, W, total, first, groups);
+            else
+#endif
+                hipLaunchKernelGGL((k7_tiles<0, true>), grid, dim3(256), 0, st, W, total, first, groups);
+        }
         break;
     }
     }

@@ -215,6 +215,31 @@ def test_rows_wider_than_24_bits(gpu_ctx):
     _check(gpu_ctx, items, expect)
 
 
+def test_batch_of_many_different_sizes(gpu_ctx):
+    # more distinct frame sizes than the unpack kernel has size classes (8), in random order: the plans
+    # are sorted into classes for the launches, statuses and outputs must still land on the caller's frames
+    rng = np.random.default_rng(1212)
+    sizes = [(64 * k, 4 * (k + 1)) for k in range(1, 13)] + [(1000, 37), (77, 6)]
+    items, expect = [], []
+    for i in rng.permutation(len(sizes) * 3):
+        w, h = sizes[int(i) % len(sizes)]
+        img = rng.integers(0, 1 << int(rng.integers(1, 15)), size=(h, w), dtype=np.uint16)
+        bad = int(i) % 7 == 3
+        buf = L.encode7(img)
+        if bad:
+            buf = buf[: buf.size - 5].copy()  # the refs stream loses its tail
+        ret, out = L.oracle_decode7(buf, w, h)
+        items.append((7, w, h, buf))
+        expect.append((ret, out))
+    from _gpu import decode_batch_device
+    written, status, outs = decode_batch_device(gpu_ctx, items)
+    for i, ((t, w, h, b), (ret, img)) in enumerate(zip(items, expect)):
+        if ret == 0:
+            assert status[i] != 0 and written[i] == 0, (i, w, h, status[i])
+        else:
+            assert status[i] == 0 and written[i] == ret and np.array_equal(outs[i], img), (i, w, h, status[i])
+
+
 def test_many_small_frames_one_batch(gpu_ctx):
     # 1200 frames of assorted small geometries, both encodings interleaved: exercises the batch
     # indexing (uniform-stride workspace sized by the largest frame, work lists, status mapping)
