@@ -157,7 +157,11 @@ __device__ __forceinline__ void post_store8(uint16_t *out, const Post &post, uin
                 __builtin_nontemporal_store(v, reinterpret_cast<u32x3 *>(dst));
             else
                 *reinterpret_cast<u32x3 *>(dst) = v;
-        } else { // cropped or unaligned row: bytes; an odd last sample owns the high nibble of its second byte
+        } else if (n == 8u) { // a strip row off the dword grid: one unaligned 12-byte store
+            typedef uint32_t u32x3_u __attribute__((ext_vector_type(3), aligned(1)));
+            const u32x3_u v = {o[0], o[1], o[2]};
+            *reinterpret_cast<u32x3_u *>(dst) = v;
+        } else { // the cropped end of a row: bytes; an odd last sample owns the high nibble of its second byte
             const uint32_t nb = (n * 12u + 7u) >> 3;
 #pragma unroll
             for (uint32_t i = 0; i < 12u; i++)
@@ -178,6 +182,10 @@ __device__ __forceinline__ void post_store8(uint16_t *out, const Post &post, uin
             __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst));
         else
             *reinterpret_cast<u32x4 *>(dst) = v;
+    } else if (n == 8u) { // rows off the 16-byte grid: one unaligned 16-byte store
+        typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(2)));
+        const u32x4_u v = {p[0], p[1], p[2], p[3]};
+        *reinterpret_cast<u32x4_u *>(dst) = v;
     } else {
 #pragma unroll
         for (uint32_t i = 0; i < 8u; i++)

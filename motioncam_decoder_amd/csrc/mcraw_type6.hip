@@ -361,6 +361,10 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
             } else if (fast && x + 8u <= width) {
                 const u32x4 v = {o[0], o[1], o[2], o[3]};
                 __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(px));
+            } else if (x + 8u <= width) { // rows off the 16-byte grid: still one (unaligned) 16-byte store
+                typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(2)));
+                const u32x4_u v = {o[0], o[1], o[2], o[3]};
+                *reinterpret_cast<u32x4_u *>(px) = v;
             } else {
 #pragma unroll
                 for (uint32_t j = 0; j < 8u; j++) // padded columns are cropped (RawData_Legacy.cpp:490)
