@@ -44,8 +44,10 @@ typedef struct mcraw_ctx mcraw_ctx;
  * DecodeLegacy (lib/include/motioncam/RawData.hpp:25-37) plus the explicit
  * output capacity the reference lacks. */
 typedef struct mcraw_frame {
-    const uint8_t *in;   /* compressed frame buffer (BUFFER item payload); with     */
-                         /*   MCRAW_MEM_DEVICE it must be 16-byte aligned           */
+    const uint8_t *in;   /* compressed frame buffer (BUFFER item payload), any      */
+                         /*   byte alignment -- e.g. a payload inside a .mcraw file */
+                         /*   image resident in HBM; with MCRAW_MEM_DEVICE up to 3  */
+                         /*   bytes behind in + len may be read (never used)        */
     size_t len;          /* its length in bytes                                    */
     int32_t width;       /* frame JSON "width"   (lib/Decoder.cpp:216)             */
     int32_t height;      /* frame JSON "height"  (lib/Decoder.cpp:217)             */

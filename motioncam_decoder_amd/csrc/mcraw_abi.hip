@@ -224,7 +224,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         uint16_t *out = dev_out ? dev_out[i] : f.out;
         if (!in || !out || f.width <= 0 || f.height <= 0 || f.len == 0 || f.len >= (1ull << 32) ||
             (f.type != MCRAW_TYPE_BLOCK && f.type != MCRAW_TYPE_LEGACY) ||
-            reinterpret_cast<uintptr_t>(in) % 16 != 0 || reinterpret_cast<uintptr_t>(out) % 2 != 0 ||
+            reinterpret_cast<uintptr_t>(out) % 2 != 0 ||
             static_cast<uint64_t>(f.width) * static_cast<uint64_t>(f.height) >= (1ull << 31)) {
             status[i] = MCRAW_E_ARGS;
             continue;

@@ -256,3 +256,40 @@ def test_many_small_frames_one_batch(gpu_ctx):
         items.append((t, w, h, buf))
         expect.append((w * h, img))
     _check(gpu_ctx, items, expect)
+
+
+def test_frames_decoded_in_place_from_a_file_image_in_hbm(gpu_ctx, tmp_path):
+    # the whole .mcraw file is uploaded once; every frame is decoded from where its BUFFER payload sits
+    # in that image (arbitrary byte alignment -- container items are packed back to back)
+    import struct
+    import torch
+    import motioncam_decoder_amd as M
+    rng = np.random.default_rng(99)
+    specs = [(1000 + i, (7, 6)[i % 2], (640, 1000, 200, 1920)[i % 4], (480, 37, 12, 64)[i % 4]) for i in range(12)]
+    frames, images = [], {}
+    for ts, typ, w, h in specs:
+        img = rng.integers(0, 1 << int(rng.integers(4, 15)), size=(h, w), dtype=np.uint16)
+        frames.append((ts, typ, w, h, L.encode7(img) if typ == 7 else L.encode6(img)))
+        images[ts] = img
+    path = L.write_mcraw(str(tmp_path / "clip.mcraw"), frames)
+    raw = np.fromfile(path, dtype=np.uint8)
+    # walk the items (8-byte header: type u32, size u32; BUFFER = 2), note the payload offsets
+    off, payloads = 8, []
+    while off + 8 <= raw.size:
+        t, size = struct.unpack_from("<II", raw, off)
+        if t == 2:
+            payloads.append((off + 8, size))
+        off += 8 + size
+    assert len(payloads) == len(specs) and any(p % 16 for p, _ in payloads) and any(p % 2 for p, _ in payloads if True)
+    dev = torch.device("cuda:0")
+    image = torch.from_numpy(raw).to(dev)
+    outs, descs = [], []
+    for (ts, typ, w, h), (p, size) in zip(specs, payloads):
+        o = torch.zeros(w * h * 2, dtype=torch.uint8, device=dev)
+        outs.append(o)
+        descs.append((image.data_ptr() + p, size, w, h, typ, o.data_ptr(), w * h))
+    written, status = gpu_ctx.decode_batch(M.Context.make_frames(descs))
+    torch.cuda.synchronize()
+    for (ts, typ, w, h), o, wr, st in zip(specs, outs, written, status):
+        assert st == 0 and wr == w * h, (ts, typ, st)
+        assert np.array_equal(o.cpu().numpy().view(np.uint16).reshape(h, w), images[ts]), ts
