@@ -26,8 +26,10 @@ __device__ __forceinline__ uint32_t cls7_of(uint32_t b)
 // Bounds-checked byte-buffer descriptor over one frame buffer: reads past
 // `len` return 0 instead of faulting (corrupt offsets cannot leave the frame).
 // The range check of a raw buffer works on whole dwords, so the record count is
-// `len` rounded up to 4: the last 1-3 bytes of an odd-sized frame stay readable
-// (the dword that holds them lies inside the 4-byte aligned allocation).
+// `len` rounded up to 4: the last 1-3 bytes of an odd-sized frame stay readable.
+// Up to 3 bytes behind the frame can be fetched that way (never used): inside a
+// device allocation, which is page-granular, they always exist -- documented in
+// include/mcraw_hip.h.  The base may have any byte alignment.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t frame_rsrc(const uint8_t *in, uint32_t len)
 {
     // descriptor inputs must be provably wave-uniform (no waterfall loops)
