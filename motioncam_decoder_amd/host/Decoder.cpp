@@ -145,13 +145,14 @@ struct Decoder::Impl {
 
     // pinned staging reused across loadFrames() calls
     static constexpr int kOutSlots = 4; // decoded chunks whose copy-out may still be running
-    uint8_t *pinIn[2] = {nullptr, nullptr}, *pinOut[kOutSlots] = {nullptr, nullptr, nullptr, nullptr};
-    size_t pinInCap[2] = {0, 0}, pinOutCap[kOutSlots] = {0, 0, 0, 0};
+    static constexpr int kInSlots = 3;  // (loadFramesInto) chunk being read, chunk queued, chunk finishing on the GPU
+    uint8_t *pinIn[kInSlots] = {nullptr, nullptr, nullptr}, *pinOut[kOutSlots] = {nullptr, nullptr, nullptr, nullptr};
+    size_t pinInCap[kInSlots] = {0, 0, 0}, pinOutCap[kOutSlots] = {0, 0, 0, 0};
     mcraw_ctx *ctx = nullptr;
 
     ~Impl()
     {
-        for (int s = 0; s < 2; s++)
+        for (int s = 0; s < kInSlots; s++)
             mcraw_host_free(pinIn[s]);
         for (int s = 0; s < kOutSlots; s++)
             mcraw_host_free(pinOut[s]);
@@ -337,7 +338,45 @@ void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<s
 void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<std::vector<uint8_t>> &outData,
                          std::vector<nlohmann::json> &outMetadata, const FrameOutput &output)
 {
+    loadFramesImpl(timestamps, &outData, nullptr, outMetadata, output);
+}
+
+void Decoder::loadFramesInto(const std::vector<Timestamp> &timestamps, const std::vector<uint8_t *> &outBuffers,
+                             std::vector<nlohmann::json> &outMetadata, const FrameOutput &output)
+{
+    if (outBuffers.size() != timestamps.size())
+        throw IOException("loadFramesInto: one buffer per timestamp");
+    for (uint8_t *p : outBuffers)
+        if (!p || reinterpret_cast<uintptr_t>(p) % 2 != 0)
+            throw IOException("loadFramesInto: buffers must be non-null and 2-byte aligned");
+    loadFramesImpl(timestamps, nullptr, &outBuffers, outMetadata, output);
+}
+
+void Decoder::loadFrameMetadata(const Timestamp timestamp, nlohmann::json &outMetadata)
+{
     Impl &I = *mImpl;
+    const FrameSpan span = I.locate(timestamp); // throws "Frame not found" like loadFrame
+    outMetadata = readJson(I.reader, span.json, span.jsonSize);
+}
+
+size_t Decoder::frameBytes(int width, int height, const FrameOutput &output)
+{
+    if (width <= 0 || height <= 0)
+        return 0;
+    const size_t rowBytes = output.bitsPerSample == 12 ? (static_cast<size_t>(width) * 12 + 7) / 8 : static_cast<size_t>(width) * 2;
+    return rowBytes * static_cast<size_t>(height);
+}
+
+// outData (vectors, filled through pinned output slots and copy-out threads) or outBuffers (the
+// caller's memory, written by the GPU pipeline directly).
+void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vector<std::vector<uint8_t>> *outDataPtr,
+                             const std::vector<uint8_t *> *outBuffers, std::vector<nlohmann::json> &outMetadata,
+                             const FrameOutput &output)
+{
+    Impl &I = *mImpl;
+    std::vector<std::vector<uint8_t>> noVectors;
+    std::vector<std::vector<uint8_t>> &outData = outDataPtr ? *outDataPtr : noVectors;
+    const bool direct = outBuffers != nullptr;
     const auto tEnter = std::chrono::steady_clock::now();
     if (output.bitsPerSample != 16 && output.bitsPerSample != 12)
         throw IOException("Unsupported bitsPerSample (16 or 12)");
@@ -356,7 +395,8 @@ void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<s
     if (output.bitsPerSample == 12)
         post.flags |= MCRAW_POST_PACK12;
     const size_t n = timestamps.size();
-    outData.resize(n);
+    if (!direct)
+        outData.resize(n);
     outMetadata.assign(n, nlohmann::json());
     if (n == 0)
         return;
@@ -426,15 +466,15 @@ void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<s
         maxIn = std::max(maxIn, c.inBytes);
         maxOut = std::max(maxOut, c.outBytes);
     }
-    const int nslots = chunks.size() > 1 ? 2 : 1;
+    // with the caller's buffers as destination the GPU stage is asynchronous (below): one more input slot
+    const int nslots = static_cast<int>(std::min<size_t>(direct ? Impl::kInSlots : 2, chunks.size()));
     // a copy-out is one thread per frame (vector::assign faults its pages in as it copies), so several
     // chunks' copy-outs have to be in flight to keep up with the GPU: one output slot each
     const int noutslots = static_cast<int>(std::min<size_t>(Impl::kOutSlots, chunks.size()));
     for (int s = 0; s < nslots; s++)
         grow(I.pinIn[s], I.pinInCap[s], maxIn);
-    for (int s = 0; s < noutslots; s++) {
+    for (int s = 0; s < noutslots && !direct; s++)
         grow(I.pinOut[s], I.pinOutCap[s], maxOut);
-    }
     const unsigned hostThreads = std::max(2u, std::min(8u, std::thread::hardware_concurrency() / 2));
 
     auto readChunk = [&](size_t ci) { // file -> pinned input slot
@@ -489,6 +529,32 @@ void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<s
     std::vector<int32_t> status(n);
     std::future<void> reading = std::async(std::launch::async, readChunk, size_t(0));
     std::vector<std::future<void>> copying(noutslots); // copy-out of the chunk that last used each output slot
+    auto checkChunk = [&](size_t ci) {
+        const Chunk &c = chunks[ci];
+        for (size_t k = c.first; k < c.first + c.count; k++)
+            if (status[k] != 0 || written[k] == 0)
+                throw IOException(frames[k].type == kTypeBlock ? "Failed to uncompress frame"
+                                                               : "Failed to uncompress legacy frame");
+    };
+    struct Queued { // loadFramesInto: the chunk whose ticket is still open
+        mcraw_ticket *ticket = nullptr;
+        size_t ci = 0;
+        ~Queued()
+        {
+            if (ticket) // an exception is on its way out: the batch still writes into the caller's buffers
+                (void)mcraw_ticket_wait(ticket, nullptr, nullptr);
+        }
+    } queued;
+    auto finishQueued = [&]() {
+        if (!queued.ticket)
+            return;
+        const Chunk &c = chunks[queued.ci];
+        mcraw_ticket *t = queued.ticket;
+        queued.ticket = nullptr;
+        if (mcraw_ticket_wait(t, written.data() + c.first, status.data() + c.first) != 0)
+            throw IOException(std::string("GPU decode failed: ") + mcraw_last_error());
+        checkChunk(queued.ci);
+    };
     for (size_t ci = 0; ci < chunks.size(); ci++) {
         const Chunk &c = chunks[ci];
         auto t0 = now();
@@ -500,28 +566,41 @@ void Decoder::loadFrames(const std::vector<Timestamp> &timestamps, std::vector<s
         if (copying[ci % noutslots].valid())
             copying[ci % noutslots].get(); // chunk ci - noutslots used this output slot
         tWaitCopy += ms(t0, now());
-        uint8_t *obase = I.pinOut[ci % noutslots];
+        uint8_t *obase = direct ? nullptr : I.pinOut[ci % noutslots];
         size_t oo = 0;
         for (size_t k = 0; k < c.count; k++) {
-            frames[c.first + k].out = reinterpret_cast<uint16_t *>(obase + oo);
+            frames[c.first + k].out = reinterpret_cast<uint16_t *>(direct ? (*outBuffers)[c.first + k] : obase + oo);
             oo += up(frames[c.first + k].out_capacity * 2);
         }
         t0 = now();
         // the post stage is a property of this call, not of the context: set for the batch, cleared behind it
         int rc = post.flags ? mcraw_ctx_set_post(I.ctx, &post) : 0;
-        if (rc == 0)
-            rc = mcraw_decode_batch(I.ctx, frames.data() + c.first, static_cast<int>(c.count), MCRAW_MEM_HOST, nullptr,
-                                    written.data() + c.first, status.data() + c.first);
+        mcraw_ticket *ticket = nullptr;
+        if (rc == 0) {
+            if (direct) // queued BEHIND chunk ci-1, which is waited for below: the PCIe lanes never drain
+                rc = mcraw_decode_batch_async(I.ctx, frames.data() + c.first, static_cast<int>(c.count), &ticket);
+            else
+                rc = mcraw_decode_batch(I.ctx, frames.data() + c.first, static_cast<int>(c.count), MCRAW_MEM_HOST, nullptr,
+                                        written.data() + c.first, status.data() + c.first);
+        }
         if (post.flags)
             (void)mcraw_ctx_set_post(I.ctx, nullptr);
         if (rc != 0)
             throw IOException(std::string("GPU decode failed: ") + mcraw_last_error());
+        if (direct) {
+            finishQueued(); // chunk ci-1
+            queued.ticket = ticket;
+            queued.ci = ci;
+        } else {
+            checkChunk(ci);
+            copying[ci % noutslots] = std::async(std::launch::async, copyOut, ci);
+        }
         tDecode += ms(t0, now());
-        for (size_t k = c.first; k < c.first + c.count; k++)
-            if (status[k] != 0 || written[k] == 0)
-                throw IOException(frames[k].type == kTypeBlock ? "Failed to uncompress frame"
-                                                               : "Failed to uncompress legacy frame");
-        copying[ci % noutslots] = std::async(std::launch::async, copyOut, ci);
+    }
+    {
+        const auto t0 = now();
+        finishQueued();
+        tDecode += ms(t0, now());
     }
     const auto t1 = now();
     for (size_t k = 0; k < copying.size(); k++) { // oldest first

@@ -73,11 +73,23 @@ public:
     //   bitsPerSample = 12  rows as 12-bit strips, ceil(width * 12 / 8) bytes each, MSB-first
     //                       (SetBitsPerSample {12}, example.cpp:116-117), a quarter less to copy and store.
     struct FrameOutput {
-        bool subtractBlackLevel = false;
-        int bitsPerSample = 16; // 16 or 12
+        bool subtractBlackLevel;
+        int bitsPerSample; // 16 or 12
+        FrameOutput() : subtractBlackLevel(false), bitsPerSample(16) {}
     };
     void loadFrames(const std::vector<Timestamp> &timestamps, std::vector<std::vector<uint8_t>> &outData,
                     std::vector<nlohmann::json> &outMetadata, const FrameOutput &output);
+
+    // JSON of one frame without decoding it (width, height, compressionType ...: what sizes a buffer).
+    void loadFrameMetadata(const Timestamp timestamp, nlohmann::json &outMetadata);
+
+    // The same batch into memory the caller owns: frame i is written to outBuffers[i], which must hold
+    // frameBytes(width, height, output) bytes.  The GPU pipeline downloads straight into these buffers (no
+    // staging copy, no std::vector to fault in), so pinned memory is the fast choice: mcraw_host_alloc() /
+    // hipHostMalloc -- pageable memory works, through the HIP runtime's own staging.
+    void loadFramesInto(const std::vector<Timestamp> &timestamps, const std::vector<uint8_t *> &outBuffers,
+                        std::vector<nlohmann::json> &outMetadata, const FrameOutput &output = FrameOutput());
+    static size_t frameBytes(int width, int height, const FrameOutput &output = FrameOutput());
 
     int audioSampleRateHz() const;
     int numAudioChannels() const;
@@ -87,6 +99,9 @@ public:
     AudioChunkLoader &loadAudio() const;
 
 private:
+    void loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vector<std::vector<uint8_t>> *outData,
+                        const std::vector<uint8_t *> *outBuffers, std::vector<nlohmann::json> &outMetadata,
+                        const FrameOutput &output);
     struct Impl;
     std::unique_ptr<Impl> mImpl;
 };

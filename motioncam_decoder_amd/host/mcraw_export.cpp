@@ -1,6 +1,6 @@
 // mcraw_export -- decode a .mcraw file on the GPU and dump what it holds.
 //
-//   mcraw_export <file.mcraw> [-n frames] [-o outdir] [--single] [--no-write] [--black] [--bits 12]
+//   mcraw_export <file.mcraw> [-n frames] [-o outdir] [--single] [--no-write] [--black] [--bits 12] [--pinned]
 //
 // Writes outdir/frame_%06d.u16 (width*height uint16 LE, row-major Bayer mosaic) for the
 // first N frames (by timestamp) and outdir/audio.s16 (interleaved PCM), and prints one line
@@ -8,7 +8,10 @@
 // batch (Decoder::loadFrames); --single uses the per-frame loadFrame() path instead.
 // --black subtracts the container's black levels, --bits 12 writes frame_%06d.p12 (12-bit strip
 // rows) instead: both are done by the stage fused into the GPU decode (Decoder::FrameOutput).
+// --pinned decodes into pinned buffers this tool allocates (Decoder::loadFramesInto: no copy-out stage).
 #include <motioncam/Decoder.hpp>
+
+#include "mcraw_hip.h" // mcraw_host_alloc / mcraw_host_free for --pinned
 
 #include <chrono>
 #include <cstdio>
@@ -55,7 +58,7 @@ int main(int argc, char **argv)
     }
     std::string input = argv[1], outdir = ".";
     long limit = -1;
-    bool single = false, nowrite = false;
+    bool single = false, nowrite = false, pinned = false;
     motioncam::Decoder::FrameOutput output;
     for (int i = 2; i < argc; i++) {
         if (!std::strcmp(argv[i], "-n") && i + 1 < argc)
@@ -66,6 +69,8 @@ int main(int argc, char **argv)
             single = true;
         else if (!std::strcmp(argv[i], "--no-write"))
             nowrite = true; // decode and checksum only (timing runs)
+        else if (!std::strcmp(argv[i], "--pinned"))
+            pinned = true;
         else if (!std::strcmp(argv[i], "--black"))
             output.subtractBlackLevel = true;
         else if (!std::strcmp(argv[i], "--bits") && i + 1 < argc)
@@ -97,6 +102,29 @@ int main(int argc, char **argv)
             meta.resize(frames.size());
             for (size_t i = 0; i < frames.size(); i++)
                 decoder.loadFrame(frames[i], data[i], meta[i]);
+        } else if (pinned) {
+            // geometry of every frame first (metadata only), then one pinned buffer per frame
+            std::vector<uint8_t *> bufs(frames.size(), nullptr);
+            std::vector<size_t> sizes(frames.size(), 0);
+            for (size_t i = 0; i < frames.size(); i++) {
+                nlohmann::json m;
+                decoder.loadFrameMetadata(frames[i], m);
+                sizes[i] = motioncam::Decoder::frameBytes(m["width"], m["height"], output);
+                bufs[i] = static_cast<uint8_t *>(mcraw_host_alloc(sizes[i]));
+                if (!bufs[i])
+                    throw motioncam::IOException("Failed to allocate pinned memory");
+            }
+            const auto t1 = std::chrono::steady_clock::now();
+            decoder.loadFramesInto(frames, bufs, meta, output);
+            const auto t2 = std::chrono::steady_clock::now();
+            std::cout << "pinned: allocation " << std::chrono::duration<double>(t1 - t0).count() << " s, loadFramesInto "
+                      << std::chrono::duration<double>(t2 - t1).count() << " s ("
+                      << frames.size() / std::chrono::duration<double>(t2 - t1).count() << " frames/s)" << std::endl;
+            data.resize(frames.size());
+            for (size_t i = 0; i < frames.size(); i++) { // (outside the decode: only for the checksums / files below)
+                data[i].assign(bufs[i], bufs[i] + sizes[i]);
+                mcraw_host_free(bufs[i]);
+            }
         } else {
             decoder.loadFrames(frames, data, meta, output);
         }

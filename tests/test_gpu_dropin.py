@@ -106,6 +106,27 @@ def test_reference_example_over_gpu_decode(container, tmp_path):
             assert (a / name).read_bytes() == (b / name).read_bytes(), name
 
 
+def test_export_tool_into_caller_buffers(container, tmp_path):
+    # Decoder::loadFramesInto: the GPU pipeline downloads straight into (pinned) buffers of the caller;
+    # same bytes as the vector form, also with the post stage
+    d, path, images, audio = container
+    if not os.path.exists(EXPORT):
+        from motioncam_decoder_amd import build
+        build.build_host()
+    r = _run([EXPORT, path, "-o", str(tmp_path), "--pinned"], str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    assert "loadFramesInto" in r.stdout
+    for i, ts in enumerate(sorted(images)):
+        got = np.fromfile(str(tmp_path / ("frame_%06d.u16" % i)), dtype=np.uint16)
+        assert np.array_equal(got.reshape(images[ts].shape), images[ts]), (i, ts)
+    r = _run([EXPORT, path, "-o", str(tmp_path), "--pinned", "--black", "--bits", "12"], str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    for i, ts in enumerate(sorted(images)):
+        want = L.oracle_post(images[ts], [64, 64, 64, 64], True)
+        got = np.fromfile(str(tmp_path / ("frame_%06d.p12" % i)), dtype=np.uint8)
+        assert np.array_equal(got.reshape(want.shape), want), (i, ts)
+
+
 SWAP = os.path.join(ROOT, "oracle", "_ref", "example_codec_swap")
 
 
