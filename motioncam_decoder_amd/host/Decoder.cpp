@@ -194,6 +194,10 @@ void Decoder::Impl::open()
         throw IOException("Corrupted file");
     if (index.rows < 0)
         throw IOException("Invalid index");
+    // a corrupted count must not turn into a multi-gigabyte allocation: the rows have to lie inside the file
+    if (index.rowsPosition < 0 || index.rowsPosition > fileSize ||
+        static_cast<uint64_t>(index.rows) > static_cast<uint64_t>(fileSize - index.rowsPosition) / sizeof(Locator))
+        throw IOException("Invalid index");
 
     std::vector<Locator> offsets(static_cast<size_t>(index.rows));
     if (!offsets.empty())
@@ -220,8 +224,9 @@ void Decoder::Impl::open()
             } else if (item.kind == Kind::PCM_TABLE) {
                 const PcmTable ai = readPod<PcmTable>(reader, pos);
                 pos += static_cast<int64_t>(sizeof(PcmTable));
-                if (ai.rows < 0)
-                    break;
+                if (ai.rows < 0 || pos > fileSize ||
+                    static_cast<uint64_t>(ai.rows) > static_cast<uint64_t>(fileSize - pos) / sizeof(Locator))
+                    break; // not an audio table this file can hold
                 audioOffsets.resize(static_cast<size_t>(ai.rows));
                 if (!audioOffsets.empty())
                     reader.readAt(pos, audioOffsets.data(), audioOffsets.size() * sizeof(Locator));
@@ -276,9 +281,9 @@ const std::vector<Timestamp> &Decoder::getFrames() const { return mImpl->frames;
 
 const nlohmann::json &Decoder::getContainerMetadata() const { return mImpl->metadata; }
 
-int Decoder::audioSampleRateHz() const { return mImpl->metadata["extraData"]["audioSampleRate"]; }
+int Decoder::audioSampleRateHz() const { return mImpl->metadata.at("extraData").at("audioSampleRate"); } // throws when absent
 
-int Decoder::numAudioChannels() const { return mImpl->metadata["extraData"]["audioChannels"]; }
+int Decoder::numAudioChannels() const { return mImpl->metadata.at("extraData").at("audioChannels"); }
 
 void Decoder::loadAudio(std::vector<AudioChunk> &outAudioChunks)
 {

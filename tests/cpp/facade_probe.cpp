@@ -15,7 +15,7 @@ int main(int argc, char **argv)
         for (auto t : frames)
             std::cout << " " << t;
         std::cout << "\n";
-        std::cout << "camera " << d.getContainerMetadata()["sensorArrangment"].get<std::string>() << " "
+        std::cout << "camera " << d.getContainerMetadata().at("sensorArrangment").get<std::string>() << " "
                   << d.audioSampleRateHz() << " " << d.numAudioChannels() << "\n";
         std::vector<motioncam::AudioChunk> chunks;
         d.loadAudio(chunks);
