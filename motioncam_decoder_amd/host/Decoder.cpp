@@ -83,6 +83,8 @@ template <typename T> T readPod(const FileReader &r, int64_t offset)
 
 nlohmann::json readJson(const FileReader &r, int64_t offset, uint32_t size)
 {
+    if (offset < 0 || offset + static_cast<int64_t>(size) > r.size()) // before allocating `size` bytes
+        throw IOException("Invalid metadata");
     std::string text(size, '\0');
     if (size)
         r.readAt(offset, &text[0], size);
@@ -258,6 +260,8 @@ FrameSpan Decoder::Impl::locate(Timestamp ts) const
         throw IOException("Invalid metadata");
     s.json = metaPos + static_cast<int64_t>(sizeof(Chunk));
     s.jsonSize = meta.bytes;
+    if (s.json + static_cast<int64_t>(s.jsonSize) > reader.size()) // (the payload is inside the file: its JSON item was read behind it)
+        throw IOException("Invalid metadata");
     return s;
 }
 
