@@ -424,6 +424,13 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
             throw IOException("Invalid compression type");
         if (width <= 0 || height <= 0)
             throw IOException("Failed to uncompress frame");
+        // before any staging is sized by them: dimensions the payload cannot possibly hold (a corrupt JSON).
+        // A type-7 frame carries two 2-byte side-stream records per 64 blocks of 64 samples, a legacy
+        // frame one 2-byte record per 16 samples at the very least.
+        const uint64_t px = static_cast<uint64_t>(width) * static_cast<uint64_t>(height);
+        const uint64_t least = type == kTypeBlock ? px / 1024 : px / 8;
+        if (px >= (1ull << 31) || spans[i].payloadSize < least)
+            throw IOException(type == kTypeBlock ? "Failed to uncompress frame" : "Failed to uncompress legacy frame");
         mcraw_frame &f = frames[i];
         f.in = nullptr;
         f.out = nullptr;
