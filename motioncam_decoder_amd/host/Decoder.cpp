@@ -106,6 +106,8 @@ bool loadAudioChunkAt(const FileReader &r, const Locator &o, AudioChunk &out)
         return false;
     if (item.kind != Kind::PCM)
         throw IOException("Invalid audio data");
+    if (o.position < 0 || o.position + static_cast<int64_t>(sizeof(Chunk)) + static_cast<int64_t>(item.bytes) > r.size())
+        throw IOException("Invalid audio data"); // before sizing a vector by a corrupt length
     std::vector<int16_t> samples((static_cast<size_t>(item.bytes) + 1) / 2);
     r.readAt(o.position + static_cast<int64_t>(sizeof(Chunk)), samples.data(), item.bytes);
     // newer files follow the samples with their capture time; older ones do not
