@@ -248,7 +248,11 @@ __device__ __forceinline__ void quad6(const uint8_t *__restrict__ bytes, uint32_
 //
 // (A wave-uniform walk of ONE chunk per wave spent 64 lanes on a scalar chain and made this kernel
 // issue-bound; more chunks per wave spread the walk over more lanes but cost LDS, and 4 measured best.)
-constexpr uint32_t ROWS_CAP = 128u * ROWS_CH; // records listed per round (typical: ~70 per chunk; worst case 512 -> 4 rounds)
+// The list holds one entry per record PAIR -- the position of the even record; the odd one starts where
+// the even one ends, which the unpacking lane knows from the even record's header -- so a round covers
+// 1024 records in 1 KiB of LDS: all data but runs of 2-byte records stays on the single-round path
+// (4-byte records, 1-bit residuals of a nearly flat frame, are 1024 per wave).
+constexpr uint32_t ROWS_CAP = 256u * ROWS_CH; // records per round (typical: ~70 per chunk; worst case 512 per chunk -> 2 rounds)
 static_assert(ROWS_CAP <= 1024u && ROWS_CAP % 2u == 0u, "the division-free row arithmetic in k6_rows assumes at most 512 pairs per round");
 
 #ifndef K6_ABL
@@ -261,7 +265,11 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
 {
     constexpr uint32_t STAGE = ROWS_CH * CHUNK6 + 64 + 16; // + the reach of a record that starts 32 bytes past the chunks
     __shared__ __attribute__((aligned(16))) uint8_t s_bytes[4][STAGE];
-    __shared__ __attribute__((aligned(4))) uint16_t s_pos[4][ROWS_CAP + 2]; // record r of a round at [r - wlo], wlo even
+    // the list of a round, one of two layouts: every record r at [r - wlo] (up to ROWS_CAP / 2 records: the
+    // common case, one LDS read gives both records of a pair), or one entry per PAIR at [(r - wlo) / 2]
+    // holding the even record only (up to ROWS_CAP records; the unpacking lane finds the odd one behind it)
+    __shared__ __attribute__((aligned(4))) uint16_t s_pos[4][ROWS_CAP / 2 + 2];
+    __shared__ uint32_t s_pairmode[4];
     __shared__ uint32_t s_ent[4 * ROWS_CH];
 
     // workgroups run over the batch BACKWARDS: k6_maps has just streamed the whole input through the
@@ -305,6 +313,9 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
     // lean: every chunk of this wave runs to its end, the next entry bounds the last one, no record can
     // reach `len`, and the records fit one round of the list
     const bool lean = live && inner && N <= ROWS_CAP && cs0 + STAGE < len;
+    const bool pairmode = N > ROWS_CAP / 2u; // which list layout this wave's single round uses
+    if (lane == 0)
+        s_pairmode[wave] = pairmode ? 1u : 0u;
     // When that holds for all four waves (everywhere but at the ends of a frame and in runs of tiny
     // records), ONE wave walks the 16 chunks of the workgroup, a lane each: a walk keeps a wave busy for
     // ~70 dependent steps whatever the number of walking lanes, so four waves walking four chunks each
@@ -323,9 +334,10 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
     const uint32_t m20 = widerow ? 0u : ((1u << 20) + ppr - 1u) / ppr;
 
     // Unpack the pairs of records [wlo, whi) (both even) listed in s_pos[wave]: four lanes per pair
-    auto unpack_round = [&](uint32_t wlo, uint32_t whi) {
+    auto unpack_round = [&](uint32_t wlo, uint32_t whi, bool by_pair) {
         const uint32_t pair0 = wlo >> 1;
-        const uint32_t *s_pos32 = reinterpret_cast<const uint32_t *>(s_pos[wave]);
+        const uint16_t *pairs = s_pos[wave];
+        const uint32_t *both = reinterpret_cast<const uint32_t *>(s_pos[wave]);
         const uint32_t y0 = pair0 / ppr, r0 = pair0 - y0 * ppr; // wave-uniform
         const uint32_t row0 = y0 * width;
         const uint32_t ntask = 2u * (whi - wlo);
@@ -335,10 +347,18 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
             // one task: 8 pixels (even columns from record A, odd columns from record B, uint16 wrap
             // on the reference add) and where they go
             const uint32_t q = t >> 2, qt = t & 3u;
-            const uint32_t ro2 = s_pos32[q];
+            uint32_t roa, rob;
+            if (by_pair) { // the odd-column record starts where the even-column one ends (RawData_Legacy.cpp:377-442)
+                roa = pairs[q];
+                rob = roa + 2u + len6_of(static_cast<uint32_t>(bytes[roa]) >> 4);
+            } else {
+                const uint32_t ro2 = both[q];
+                roa = ro2 & 0xffffu;
+                rob = ro2 >> 16;
+            }
             uint32_t va[4], vb[4], refa, refb;
-            quad6(bytes, ro2 & 0xffffu, qt, va, &refa);
-            quad6(bytes, ro2 >> 16, qt, vb, &refb);
+            quad6(bytes, roa, qt, va, &refa);
+            quad6(bytes, rob, qt, vb, &refb);
             const uint32_t n = r0 + q;
             const uint32_t dy = widerow ? (n >= ppr ? 1u : 0u) : __umul24(n, m20) >> 20;
             const uint32_t x = (n - __umul24(dy, ppr)) * 32u + 8u * qt; // RawData_Legacy.cpp:479-486
@@ -380,48 +400,59 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
             const uint32_t ej = s_ent[lane], first = ((s_ent[w * ROWS_CH] >> 8) + 1u) & ~1u;
             const uint8_t *base = s_bytes[w];
             const uint8_t *p = base + j * CHUNK6 + 2u * (ej & 255u), *const pe = base + (j + 1u) * CHUNK6;
-            uint16_t *lp = s_pos[w] + static_cast<int32_t>((ej >> 8) - first); // wave w's first record sits at [-1] when it is odd:
-            if ((ej >> 8) < first) {                     // it belongs to the previous wave's last pair
-                p += 2u + len6_of(static_cast<uint32_t>(*p) >> 4);
-                lp++;
+            uint32_t idx = ej >> 8;
+            if (s_pairmode[w]) {
+                // an odd first record belongs to the previous wave's last pair: never listed
+                while (p < pe) { // the stride decode, and a store for every second record
+                    const uint32_t hb = static_cast<uint32_t>(*p) >> 4;
+                    if ((idx & 1u) == 0u)
+                        s_pos[w][(idx - first) >> 1] = static_cast<uint16_t>(p - base);
+                    idx++;
+                    p += 2u + len6_of(hb);
+                }
+            } else {
+                uint16_t *lp = s_pos[w] + static_cast<int32_t>(idx - first); // [-1] for an odd first record:
+                if (idx < first) {                                             // skipped, see above
+                    p += 2u + len6_of(static_cast<uint32_t>(*p) >> 4);
+                    lp++;
+                }
+                while (p < pe) { // nothing but the stride decode in the loop
+                    const uint32_t hb = static_cast<uint32_t>(*p) >> 4;
+                    *lp++ = static_cast<uint16_t>(p - base);
+                    p += 2u + len6_of(hb);
+                }
+                // the walk of a wave's last chunk stops on the next wave's first record: the partner of my
+                // last record when my range ends on an even one (lp is then at an odd list index)
+                if (j == ROWS_CH - 1u && ((lp - s_pos[w]) & 1))
+                    *lp = static_cast<uint16_t>(p - base);
             }
-            while (p < pe) { // nothing but the stride decode in the loop
-                const uint32_t hb = static_cast<uint32_t>(*p) >> 4;
-                *lp++ = static_cast<uint16_t>(p - base);
-                p += 2u + len6_of(hb);
-            }
-            // the walk of a wave's last chunk stops on the next wave's first record: the partner of my
-            // last record when my range ends on an even one (lp is then at an odd list index)
-            if (j == ROWS_CH - 1u && ((lp - s_pos[w]) & 1))
-                *lp = static_cast<uint16_t>(p - base);
         }
         __syncthreads();
-        unpack_round(R0, R1);
+        unpack_round(R0, R1, pairmode);
         return;
     }
     if (!live)
         return;
     const bool walker = lane < ROWS_CH && (e & 255u) != DEAD && c0 + lane < nchunks;
-    // the last walking lane carries on past its chunk for the partner of an even last record
-    const bool lastw = walker && (lane + 1u == ROWS_CH || c0 + lane + 1u >= nchunks);
     // a walker keeps its place from round to round (restarting at the chunk entry every round made a
     // run of 2-byte records cost rounds x 512 steps per lane)
     uint32_t pos = 2u * (e & 255u), idx = e >> 8;
     for (uint32_t base = 0; base < N; base += ROWS_CAP) {
-        const uint32_t wlo = R0 + base, whi = min(R1, wlo + ROWS_CAP); // records listed this round (both even)
+        const uint32_t wlo = R0 + base, whi = min(R1, wlo + ROWS_CAP); // records of this round (both even)
         if (K6_ABL != 3 && walker) {
             const uint32_t off = lane * CHUNK6;
-            while (idx < whi && (pos < CHUNK6 || (lastw && idx < R1))) {
+            while (idx < whi && pos < CHUNK6) {
                 // Runs of 2-byte records (flat or clipped image regions) are what makes a wave land here:
                 // eight of them fill an aligned 16-byte line whose even bytes all have a zero high
-                // nibble -- one LDS read then lists eight records instead of one.
+                // nibble -- one LDS read then lists four pairs instead of one record.
                 const uint32_t a = off + pos;
-                if ((a & 15u) == 0u && pos + 16u <= CHUNK6 && idx >= wlo && idx + 8u <= whi && cs0 + a + 16u < len) {
+                if ((a & 15u) == 0u && (idx & 1u) == 0u && pos + 16u <= CHUNK6 && idx >= wlo && idx + 8u <= whi &&
+                    cs0 + a + 16u < len) {
                     const uint4 q = *reinterpret_cast<const uint4 *>(bytes + a);
                     if (((q.x | q.y | q.z | q.w) & 0x00F000F0u) == 0u) {
 #pragma unroll
-                        for (uint32_t k = 0; k < 8u; k++)
-                            s_pos[wave][idx - wlo + k] = static_cast<uint16_t>(a + 2u * k);
+                        for (uint32_t k = 0; k < 4u; k++)
+                            s_pos[wave][((idx - wlo) >> 1) + k] = static_cast<uint16_t>(a + 4u * k);
                         pos += 16u;
                         idx += 8u;
                         continue;
@@ -430,15 +461,15 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
                 const uint32_t nx = pos + 2u + len6_of(static_cast<uint32_t>(bytes[off + pos]) >> 4);
                 if (cs0 + off + nx >= len)
                     break; // k6_frame has already failed the frame if records are missing
-                if (idx >= wlo)
-                    s_pos[wave][idx - wlo] = static_cast<uint16_t>(off + pos);
+                if (idx >= wlo && (idx & 1u) == 0u)
+                    s_pos[wave][(idx - wlo) >> 1] = static_cast<uint16_t>(off + pos);
                 pos = nx;
                 idx++;
             }
         }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
-        unpack_round(wlo, whi);
+        unpack_round(wlo, whi, true);
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier(); // the list is rewritten by the next round
     }
