@@ -620,34 +620,61 @@ int host_submit(mcraw_ticket *t)
             return rc;
         Slot &s = *sp;
         hipStream_t st = s.stream;
-        size_t in_bytes = 0, out_bytes = 0;
-        for (int i = 0; i < count; i++) {
-            const mcraw_frame &f = frames[first + i];
-            in_bytes += up(f.len, ALIGN);
-            if (f.width > 0 && f.height > 0)
-                out_bytes += up(static_cast<size_t>(f.width) * f.height * 2, ALIGN);
-        }
-        if (int rc = ensure(s.dev_in, in_bytes + ALIGN, false))
-            return rc;
-        if (int rc = ensure(s.dev_out, out_bytes + ALIGN, false))
-            return rc;
-        std::vector<const uint8_t *> din(count);
-        std::vector<uint16_t *> dout(count);
+        // Device staging mirrors the host layout wherever frames are neighbours in host memory (inputs: up
+        // to 256 bytes apart; outputs: exactly adjacent, a copy must not touch bytes between two buffers):
+        // such a run moves with ONE copy per direction -- a copy call costs about 6 us, which is what a
+        // stream of small frames would otherwise be bound by.  Offsets keep the host address modulo 256.
+        struct Run {
+            uintptr_t host;
+            size_t bytes, dev;
+        };
+        std::vector<Run> rin, rout;
+        std::vector<size_t> in_off(count, SIZE_MAX), out_off(count, SIZE_MAX), out_len(count, 0);
         size_t io = 0, oo = 0;
         for (int i = 0; i < count; i++) {
             const mcraw_frame &f = frames[first + i];
-            din[i] = static_cast<uint8_t *>(s.dev_in.p) + io;
-            dout[i] = reinterpret_cast<uint16_t *>(static_cast<uint8_t *>(s.dev_out.p) + oo);
-            if (f.in && f.len)
-                HIP_TRY(hipMemcpyAsync(const_cast<uint8_t *>(din[i]), f.in, f.len, hipMemcpyHostToDevice, c->h2d));
-            else
-                din[i] = nullptr;
-            io += up(f.len, ALIGN);
-            if (f.width > 0 && f.height > 0)
-                oo += up(static_cast<size_t>(f.width) * f.height * 2, ALIGN);
-            if (!f.out)
-                dout[i] = nullptr;
+            if (f.in && f.len) {
+                const uintptr_t a = reinterpret_cast<uintptr_t>(f.in);
+                if (!rin.empty() && a >= rin.back().host + rin.back().bytes && a - (rin.back().host + rin.back().bytes) <= 256) {
+                    in_off[i] = rin.back().dev + (a - rin.back().host);
+                    rin.back().bytes = a + f.len - rin.back().host;
+                } else {
+                    const size_t dev = up(io, ALIGN) + (a & (ALIGN - 1));
+                    rin.push_back({a, f.len, dev});
+                    in_off[i] = dev;
+                }
+                io = rin.back().dev + rin.back().bytes;
+            }
+            if (f.out && f.in && f.len && f.width > 0 && f.height > 0) { // (a frame without input is rejected: its buffer stays untouched)
+                const uintptr_t a = reinterpret_cast<uintptr_t>(f.out);
+                out_len[i] = std::min(f.out_capacity * 2, static_cast<size_t>(f.height) * post_row_bytes(static_cast<uint32_t>(f.width), c->post.mode));
+                // the kernels may write a whole frame even when the caller's capacity is smaller (that frame then
+                // fails with MCRAW_E_CAPACITY before any kernel runs): reserve the full size on the device
+                const size_t full = std::max(out_len[i], static_cast<size_t>(f.width) * f.height * 2);
+                if (!rout.empty() && a == rout.back().host + rout.back().bytes && full == out_len[i]) {
+                    out_off[i] = rout.back().dev + rout.back().bytes;
+                    rout.back().bytes += out_len[i];
+                } else {
+                    const size_t dev = up(oo, ALIGN) + (a & (ALIGN - 1));
+                    rout.push_back({a, out_len[i], dev});
+                    out_off[i] = dev;
+                }
+                oo = std::max(oo, out_off[i] + full);
+            }
         }
+        if (int rc = ensure(s.dev_in, io + ALIGN, false))
+            return rc;
+        if (int rc = ensure(s.dev_out, oo + ALIGN, false))
+            return rc;
+        std::vector<const uint8_t *> din(count);
+        std::vector<uint16_t *> dout(count);
+        for (int i = 0; i < count; i++) {
+            din[i] = in_off[i] != SIZE_MAX ? static_cast<uint8_t *>(s.dev_in.p) + in_off[i] : nullptr;
+            dout[i] = out_off[i] != SIZE_MAX ? reinterpret_cast<uint16_t *>(static_cast<uint8_t *>(s.dev_out.p) + out_off[i]) : nullptr;
+        }
+        for (const Run &r : rin)
+            HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(s.dev_in.p) + r.dev, reinterpret_cast<const void *>(r.host), r.bytes,
+                                   hipMemcpyHostToDevice, c->h2d));
         // three lanes: all uploads queue on one stream, all downloads on another (each copy engine then
         // runs back to back over the sub-batches), the kernels of a sub-batch on its slot's stream between
         HIP_TRY(hipEventRecord(s.uploaded, c->h2d));
@@ -657,13 +684,9 @@ int host_submit(mcraw_ticket *t)
             return rc;
         HIP_TRY(hipEventRecord(s.decoded, st));
         HIP_TRY(hipStreamWaitEvent(c->d2h, s.decoded, 0));
-        for (int i = 0; i < count; i++) {
-            const mcraw_frame &f = frames[first + i];
-            if (!dout[i] || !din[i] || f.width <= 0 || f.height <= 0)
-                continue;
-            size_t nbytes = std::min(f.out_capacity * 2, static_cast<size_t>(f.height) * post_row_bytes(static_cast<uint32_t>(f.width), c->post.mode));
-            HIP_TRY(hipMemcpyAsync(f.out, dout[i], nbytes, hipMemcpyDeviceToHost, c->d2h));
-        }
+        for (const Run &r : rout)
+            HIP_TRY(hipMemcpyAsync(reinterpret_cast<void *>(r.host), static_cast<uint8_t *>(s.dev_out.p) + r.dev, r.bytes,
+                                   hipMemcpyDeviceToHost, c->d2h));
         HIP_TRY(hipEventRecord(s.done, c->d2h));
         s.busy = true;
         // the slot keeps this sub-batch's statuses until they are drained into the ticket: by
