@@ -65,9 +65,12 @@ def main():
                 else:
                     wr, st = ctx.wait(ctx.decode_batch_async(fr))
                 assert all(s == 0 for s in st)
-                if not pack12:
-                    typ, w, h, _, _, img = picks[-1]
-                    assert np.array_equal(outs[-1].view(np.uint16).reshape(h, w), img)
+                for (typ, w, h, _, _, img), o in zip(picks, outs):  # every frame: the copies of neighbours are merged
+                    if pack12:
+                        rb = L.post_row_bytes(w, True)
+                        assert np.array_equal(o[: h * rb].reshape(h, rb), L.oracle_post(img, [64, 64, 64, 64], True))
+                    else:
+                        assert np.array_equal(o.view(np.uint16).reshape(h, w), img)
         finally:
             if pack12:
                 ctx.set_post()
