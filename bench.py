@@ -6,7 +6,7 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one pass of the decode path (mcraw_decode_batch through the C ABI,
-kernels k7_hdr/maps/follow -> k7_records -> k7_scan -> k7_tiles) over one batch of synthetic
+kernels k7_side -> k7_tiles) over one batch of synthetic
 frames that are already resident in HBM.  Workload = BASELINE.json config 3:
 240 frames of 3840x2160 12-bit, current (type 7) encoding, per GPU.  Frames
 shard by index, no collective on the data path (weak scaling: every rank decodes
@@ -135,7 +135,7 @@ def run_timed(torch, dist_mod, ctx, M, wl, steps, warmup, world):
         ctx.decode_batch(wl.desc_sets[i % nset], mem=M.MEM_DEVICE, stream=streams[i % nset].cuda_stream, want_status=False)
     torch.cuda.synchronize()
     # untimed: a few steps on one stream with every kernel bracketed by events, for the per-kernel breakdown
-    names = ("k7_walk", "k7_meta", "k7_scan", "k7_tiles")
+    names = ("k7_side", "k7_tiles")
     ctx.profile(True)
     for i in range(4):
         if i == 1: # the first step after the synchronise runs on an idle, down-clocked GPU

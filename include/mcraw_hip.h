@@ -107,9 +107,8 @@ int mcraw_ctx_synchronize(mcraw_ctx *ctx, int32_t *status, int nframes);
 /* ---- measurement -------------------------------------------------------- */
 
 /* Kernel ids for mcraw_ctx_kernel_ms. */
-#define MCRAW_K7_WALK    0 /* side-stream chain resolve           */
-#define MCRAW_K7_META    1 /* side-stream record decode           */
-#define MCRAW_K7_SCAN    2 /* payload offset scan                 */
+#define MCRAW_K7_SIDE    0 /* side streams: chain, records, payload offsets (one launch) */
+                           /* ids 1 and 2 are retired (former separate chain kernels)  */
 #define MCRAW_K7_TILES   3 /* tile decode (the roofline kernel)   */
 #define MCRAW_K6_MAPS    4 /* legacy: per-chunk transition maps   */
 #define MCRAW_K6_RESOLVE 5 /* legacy: map composition             */

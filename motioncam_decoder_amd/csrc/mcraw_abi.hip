@@ -70,6 +70,7 @@ struct Slot {
     // frame indices and `host_status` holds what the host decided on its own (bad arguments).
     std::vector<int> order;
     std::vector<int32_t> host_status;
+    int n7 = 0; // type-7 frames of the batch in this slot (their coded heights follow the statuses)
     hipEvent_t done = nullptr;
     ::mcraw_ticket *owner = nullptr; // host-memory batch whose statuses still sit in this slot's arena
     int owner_part = -1;
@@ -77,6 +78,13 @@ struct Slot {
     hipEvent_t decoded = nullptr;  // ... its kernels have run
     hipStream_t stream = nullptr; // the slot's own stream (host-memory pipeline: the kernels of a sub-batch)
     bool busy = false;
+    // A device-memory batch submitted without a status request: what is needed to plan frames again
+    // whose header asks for more workspace than they were given (mcraw_ctx_synchronize, or the
+    // next use of the slot, does that before the batch is forgotten).
+    std::vector<mcraw_frame> frames;
+    size_t status_off = 0;
+    Post post{0, 0, 0};
+    bool unresolved = false;
 };
 
 // One sub-batch of a host-memory batch, riding in a slot.
@@ -99,6 +107,7 @@ struct mcraw_ticket {
     mcraw_ctx *c = nullptr;
     std::vector<mcraw_frame> frames;
     std::vector<int32_t> status;
+    std::vector<uint32_t> encH; // coded heights (type-7 frames)
     std::vector<Part> parts;
     Post post{0, 0, 0}; // post stage the batch was submitted with
 };
@@ -111,6 +120,8 @@ struct mcraw_ctx {
     int next_slot = 0;
     Slot dslots[NDSLOT]; // device-memory batches (tables + workspace only)
     int next_dslot = 0;
+    Slot rslot;          // frames planned a second time (always drained before the call returns)
+    hipStream_t aux = nullptr; // deferred second plans of batches whose caller stream is not known any more
     uint32_t profile = 0; // bit id: bracket launches of kernel id with events
     Post post{0, 0, 0};   // fused post-decode stage of the batches to come (mcraw_ctx_set_post)
     KStat kstat[MCRAW_K_COUNT];
@@ -118,7 +129,7 @@ struct mcraw_ctx {
     // last device-memory batch, for mcraw_ctx_synchronize
     int last_slot = -1;
     int last_n = 0;
-    size_t last_status_off = 0;
+    std::vector<int32_t> last_status; // its statuses once resolved
     std::mutex mu;
 };
 
@@ -130,18 +141,14 @@ int ensure(Buf &b, size_t bytes, bool pinned)
         return 0;
     size_t want = std::max(bytes, b.cap + b.cap / 2);
     want = up(want, 1 << 20);
-    if (b.p) {
-        if (pinned)
-            HIP_TRY(hipHostFree(b.p));
-        else
-            HIP_TRY(hipFree(b.p));
-        b.p = nullptr;
-        b.cap = 0;
-    }
+    void *np = nullptr; // the old buffer stays valid until the new one exists
     if (pinned)
-        HIP_TRY(hipHostMalloc(&b.p, want, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&np, want, hipHostMallocDefault));
     else
-        HIP_TRY(hipMalloc(&b.p, want));
+        HIP_TRY(hipMalloc(&np, want));
+    if (b.p)
+        (void)(pinned ? hipHostFree(b.p) : hipFree(b.p));
+    b.p = np;
     b.cap = want;
     return 0;
 }
@@ -185,7 +192,6 @@ struct KTimer { // brackets one launch with events on the launch stream
 // Geometry the host plans a type-7 frame with unless the header says otherwise.
 struct Geom7 {
     uint32_t encW, encH;
-    uint32_t full_extent;
 };
 
 struct Batch {
@@ -204,8 +210,7 @@ inline size_t carve(size_t &off, size_t bytes)
 }
 
 struct Layout { // byte offsets inside the slot arena / upload image
-    size_t status = 0;                                   // int32[n]
-    size_t counters = 0;                                 // u32[4] work-list lengths, start at 0
+    size_t status = 0;                                   // int32[n + 1 + n7]
     size_t plans7 = 0;                                   // Plan7[n7]
     size_t plans6 = 0, map_base = 0, super_base = 0, row_base = 0;
     size_t upload_bytes = 0;                             // tables end here, workspace follows
@@ -238,26 +243,25 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
             p.out = out;
             p.len = static_cast<uint32_t>(f.len);
             p.width = f.width;
-            if (geom_override) {
-                p.encW = (*geom_override)[i].encW;
-                p.encH = (*geom_override)[i].encH;
-                p.full_extent = (*geom_override)[i].full_extent;
-            } else {
-                p.encW = static_cast<uint32_t>(up(f.width, 64));
-                p.encH = static_cast<uint32_t>(up(f.height, 4));
+            // coded geometry the frame gets workspace and grid for: the header's where the host has
+            // seen it, else what an encoder makes of width x height (RawData.cpp reads it from the
+            // header only, :545-554; k7_side does the same and reports a frame that needs more)
+            uint32_t encW = static_cast<uint32_t>(up(f.width, 64)), encH = static_cast<uint32_t>(up(f.height, 4));
+            if (geom_override && (*geom_override)[i].encW) {
+                encW = (*geom_override)[i].encW;
+                encH = (*geom_override)[i].encH;
             }
-            p.rows = static_cast<int32_t>(std::min<uint32_t>(static_cast<uint32_t>(f.height), p.encH));
-            if (static_cast<uint64_t>(p.encW) * p.encH >= (1ull << 31)) {
+            if (static_cast<uint64_t>(encW) * encH >= (1ull << 31) || (encW & 63u) || (encH & 3u)) {
                 status[i] = MCRAW_E_HEADER;
                 continue;
             }
-            if (f.out_capacity * 2 < static_cast<size_t>(p.rows) * post_row_bytes(static_cast<uint32_t>(f.width), pmode)) {
+            const uint32_t rows = std::min<uint32_t>(static_cast<uint32_t>(f.height), encH);
+            if (f.out_capacity * 2 < static_cast<size_t>(rows) * post_row_bytes(static_cast<uint32_t>(f.width), pmode)) {
                 status[i] = MCRAW_E_CAPACITY;
                 continue;
             }
-            p.tilesX = p.encW / 64;
-            p.nblk = 4 * p.tilesX * (p.encH / 4);
-            p.ngroups = (p.nblk + GROUP_BLOCKS - 1) / GROUP_BLOCKS;
+            p.height = f.height;
+            p.ngroups = (4 * (encW / 64) * (encH / 4) + GROUP_BLOCKS - 1) / GROUP_BLOCKS;
             p.fast_store = fast ? 1u : 0u;
             B.p7.push_back(p);
             B.idx7.push_back(i);
@@ -325,8 +329,8 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     // ---- lay out the upload image and the workspace ------------------------
     Layout L;
     size_t off = 0;
-    L.status = carve(off, sizeof(int32_t) * (n7 + n6 + 1));
-    L.counters = carve(off, sizeof(uint32_t) * 4);
+    const size_t nstatus = static_cast<size_t>(n7) + n6 + 1;
+    L.status = carve(off, sizeof(int32_t) * (nstatus + n7)); // statuses, then the coded height of every type-7 frame
     L.plans7 = carve(off, sizeof(Plan7) * n7);
     L.plans6 = carve(off, sizeof(Plan6) * n6);
     L.map_base = carve(off, sizeof(uint32_t) * (n6 + 1));
@@ -339,16 +343,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     size_t Rmax = 0;
     for (const Plan7 &p : B.p7)
         Rmax = std::max<size_t>(Rmax, p.ngroups);
-    // a stream of R records is at most R * 130 bytes long; never more chunks than the frame has bytes
-    size_t nch = 1;
-    for (const Plan7 &p : B.p7)
-        nch = std::max(nch, std::min<size_t>((static_cast<size_t>(p.ngroups) * 130 + CH7 - 1) / CH7 + 1,
-                                             (static_cast<size_t>(p.len) + CH7 - 1) / CH7));
-    const size_t w_cmap7 = carve(off, sizeof(uint32_t) * PH7 * nch * 2 * n7);
-    const size_t w_centry7 = carve(off, sizeof(uint32_t) * nch * 2 * n7);
-    const size_t w_sinfo = carve(off, sizeof(uint4) * 2 * n7);
-    const size_t w_lmaps = carve(off, sizeof(uint4) * 2 * n7 * ((nch + 2) / 3));
-    const size_t w_lrecs = carve(off, sizeof(uint4) * 2 * n7 * nch);
+    const size_t w_geo = carve(off, sizeof(uint4) * n7);
     const size_t w_bits = carve(off, Rmax * 64 * n7);
     const size_t w_refs = carve(off, Rmax * 64 * sizeof(uint16_t) * n7);
     const size_t w_grp = carve(off, sizeof(uint32_t) * (Rmax * ITEM_SPLIT + 1) * n7);
@@ -369,9 +364,9 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     uint8_t *dev = static_cast<uint8_t *>(s.arena.p);
     uint8_t *img = static_cast<uint8_t *>(s.pinned.p);
 
-    std::memset(img + L.status, 0, sizeof(int32_t) * (n7 + n6 + 1));
-    std::memset(img + L.counters, 0, sizeof(uint32_t) * 4);
+    std::memset(img + L.status, 0, sizeof(int32_t) * (nstatus + n7));
     s.host_status = status;
+    s.n7 = n7;
     s.order = B.idx7;
     s.order.insert(s.order.end(), B.idx6.begin(), B.idx6.end());
     if (n7)
@@ -408,14 +403,8 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         Work7 W{};
         W.plans = reinterpret_cast<const Plan7 *>(dev + L.plans7);
         W.status = reinterpret_cast<int32_t *>(dev + L.status);
-        W.cmap = reinterpret_cast<uint32_t *>(dev + w_cmap7);
-        W.centry = reinterpret_cast<uint32_t *>(dev + w_centry7);
-        W.nch = static_cast<uint32_t>(nch);
-        W.sinfo = reinterpret_cast<uint4 *>(dev + w_sinfo);
-        W.list_maps = reinterpret_cast<uint4 *>(dev + w_lmaps);
-        W.list_recs = reinterpret_cast<uint4 *>(dev + w_lrecs);
-        W.counters = reinterpret_cast<uint32_t *>(dev + L.counters);
-        W.list_cap = static_cast<uint32_t>(2 * static_cast<size_t>(n7) * nch);
+        W.geo = reinterpret_cast<uint4 *>(dev + w_geo);
+        W.nstatus = static_cast<uint32_t>(nstatus);
         W.bits = dev + w_bits;
         W.refs = reinterpret_cast<uint16_t *>(dev + w_refs);
         W.grp_off = reinterpret_cast<uint32_t *>(dev + w_grp);
@@ -427,7 +416,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
             W.class_first[k] = class_first[k];
         for (uint32_t k = 0; k < nclasses; k++)
             W.class_groups[k] = class_groups[k];
-        for (uint32_t stage : {MCRAW_K7_WALK, MCRAW_K7_META, MCRAW_K7_SCAN, MCRAW_K7_TILES}) {
+        for (uint32_t stage : {MCRAW_K7_SIDE, MCRAW_K7_TILES}) {
             KTimer t(c, static_cast<int>(stage), st);
             launch_k7(W, stage, st);
         }
@@ -452,7 +441,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     return 0;
 }
 
-int fetch_status(mcraw_ctx *c, Slot &s, size_t status_off, int n, hipStream_t st, int32_t *status);
+int fetch_status(mcraw_ctx *c, Slot &s, size_t status_off, int n, hipStream_t st, int32_t *status, uint32_t *encH = nullptr);
 
 // Bring the statuses of one sub-batch home (they live in its slot's arena) and wait for its downloads:
 // the slot is free afterwards.
@@ -462,13 +451,38 @@ int drain_part(mcraw_ticket *t, int idx)
     if (p.drained)
         return 0;
     Slot &s = t->c->slots[p.slot];
-    if (int rc = fetch_status(t->c, s, p.status_off, p.count, s.stream, t->status.data() + p.first))
+    if (int rc = fetch_status(t->c, s, p.status_off, p.count, s.stream, t->status.data() + p.first, t->encH.data() + p.first))
         return rc;
     HIP_TRY(hipEventSynchronize(s.done)); // its downloads, queued on the download stream
     s.busy = false;
     s.owner = nullptr;
     p.drained = true;
     return 0;
+}
+
+int resolve_device(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, hipStream_t st, int32_t *status, uint32_t *encH);
+
+// A finished device-memory batch that nobody asked the statuses of: frames whose header wants more than
+// the plan gave them are decoded now (second plan on the context's own stream).
+int settle_slot(mcraw_ctx *c, Slot &s, std::vector<int32_t> *keep)
+{
+    HIP_TRY(hipEventSynchronize(s.done));
+    int rc = 0;
+    if (s.unresolved) {
+        const int n = static_cast<int>(s.frames.size());
+        std::vector<int32_t> status(n);
+        std::vector<uint32_t> encH(n, 0);
+        const Post now = c->post;
+        c->post = s.post; // a frame planned again gets the post stage its batch was submitted with
+        rc = resolve_device(c, s, s.frames.data(), n, c->aux, status.data(), encH.data());
+        c->post = now;
+        if (keep)
+            keep->swap(status);
+        s.unresolved = false;
+        s.frames.clear();
+    }
+    s.busy = false;
+    return rc;
 }
 
 int acquire_slot(mcraw_ctx *c, Slot **out, bool device_batch = false)
@@ -482,6 +496,12 @@ int acquire_slot(mcraw_ctx *c, Slot **out, bool device_batch = false)
         if (s.owner) { // an asynchronous batch still keeps its statuses here
             if (int rc = drain_part(s.owner, s.owner_part))
                 return rc;
+        } else if (device_batch) {
+            const bool last = c->last_slot == static_cast<int>(&s - c->dslots);
+            if (int rc = settle_slot(c, s, last ? &c->last_status : nullptr))
+                return rc;
+            if (last)
+                c->last_slot = -1; // its statuses are kept in last_status
         } else {
             HIP_TRY(hipEventSynchronize(s.done));
             s.busy = false;
@@ -491,14 +511,16 @@ int acquire_slot(mcraw_ctx *c, Slot **out, bool device_batch = false)
     return 0;
 }
 
-// Fetch statuses of a finished-or-running batch (synchronises on the stream).
-int fetch_status(mcraw_ctx *c, Slot &s, size_t status_off, int n, hipStream_t st, int32_t *status)
+// Fetch statuses of a finished-or-running batch (synchronises on the stream); `encH`: the coded
+// height of every type-7 frame, from its header (rows written = min(height, encH), RawData.cpp:571, :611).
+int fetch_status(mcraw_ctx *c, Slot &s, size_t status_off, int n, hipStream_t st, int32_t *status, uint32_t *encH)
 {
     const int ndev = static_cast<int>(s.order.size());
-    if (int rc = ensure(s.status_host, sizeof(int32_t) * std::max(ndev, 1), true))
+    const size_t words = static_cast<size_t>(ndev) + 1 + s.n7; // statuses, one spare word, coded heights
+    if (int rc = ensure(s.status_host, sizeof(int32_t) * words, true))
         return rc;
     if (ndev)
-        HIP_TRY(hipMemcpyAsync(s.status_host.p, static_cast<uint8_t *>(s.arena.p) + status_off, sizeof(int32_t) * ndev,
+        HIP_TRY(hipMemcpyAsync(s.status_host.p, static_cast<uint8_t *>(s.arena.p) + status_off, sizeof(int32_t) * words,
                                hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const int32_t *dev = static_cast<const int32_t *>(s.status_host.p);
@@ -507,6 +529,10 @@ int fetch_status(mcraw_ctx *c, Slot &s, size_t status_off, int n, hipStream_t st
     for (int j = 0; j < ndev; j++)
         if (s.order[j] < n)
             status[s.order[j]] |= dev[j];
+    if (encH)
+        for (int j = 0; j < s.n7; j++)
+            if (s.order[j] < n)
+                encH[s.order[j]] = static_cast<uint32_t>(dev[ndev + 1 + j]);
     (void)c;
     return 0;
 }
@@ -520,65 +546,80 @@ size_t written_of(const mcraw_frame &f, int32_t status, uint32_t encH)
     return static_cast<size_t>(f.width) * static_cast<size_t>(f.height); // RawData_Legacy.cpp:494
 }
 
-// Decode a batch whose buffers are in HBM; optionally resolve statuses
-// (synchronising) and re-plan frames whose header geometry differs from the
-// host's assumption.
+// Statuses a caller sees carry no internal bits.
+inline int32_t public_status(int32_t st)
+{
+    return (st & E_GEOMETRY) ? ((st & ~E_GEOMETRY) | MCRAW_E_HEADER) : st;
+}
+
+// Statuses (and coded heights) of the device-memory batch in slot `s`, synchronising on `st`.  Frames
+// whose header describes more blocks than they were planned with (the caller's width x height is a
+// window of a larger coded frame: RawData.cpp takes the geometry from the header alone, :545-554)
+// are planned again from the real header and decoded on `st` before this returns.
+int resolve_device(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, hipStream_t st, int32_t *status, uint32_t *encH)
+{
+    if (int rc = fetch_status(c, s, s.status_off, n, st, status, encH))
+        return rc;
+    std::vector<int> redo;
+    for (int i = 0; i < n; i++)
+        if (status[i] & E_GEOMETRY)
+            redo.push_back(i);
+    if (!redo.empty()) {
+        std::vector<mcraw_frame> rf(redo.size());
+        std::vector<Geom7> rg(redo.size());
+        std::vector<uint32_t> hdr(4 * redo.size(), 0u);
+        for (size_t k = 0; k < redo.size(); k++) {
+            rf[k] = frames[redo[k]];
+            HIP_TRY(hipMemcpyAsync(&hdr[4 * k], rf[k].in, 16, hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+        for (size_t k = 0; k < redo.size(); k++)
+            rg[k] = {hdr[4 * k], hdr[4 * k + 1]};
+        Slot &s2 = c->rslot;
+        if (int rc = submit(c, s2, rf.data(), static_cast<int>(rf.size()), &rg, nullptr, nullptr, st, &s2.status_off))
+            return rc;
+        std::vector<int32_t> st2(rf.size());
+        std::vector<uint32_t> eh2(rf.size(), 0u);
+        if (int rc = fetch_status(c, s2, s2.status_off, static_cast<int>(rf.size()), st, st2.data(), eh2.data()))
+            return rc;
+        for (size_t k = 0; k < redo.size(); k++) {
+            status[redo[k]] = st2[k];
+            encH[redo[k]] = eh2[k];
+        }
+    }
+    for (int i = 0; i < n; i++)
+        status[i] = public_status(status[i]);
+    return 0;
+}
+
+// Decode a batch whose buffers are in HBM.  With `written` / `status_out` the call synchronises and
+// resolves everything; without, frames that need a second plan get it in mcraw_ctx_synchronize (or when
+// the slot comes round again).
 int decode_device(mcraw_ctx *c, const mcraw_frame *frames, int n, hipStream_t st, size_t *written, int32_t *status_out)
 {
     Slot *sp = nullptr;
     if (int rc = acquire_slot(c, &sp, true))
         return rc;
     Slot &s = *sp;
-    size_t status_off = 0;
-    if (int rc = submit(c, s, frames, n, nullptr, nullptr, nullptr, st, &status_off))
+    if (int rc = submit(c, s, frames, n, nullptr, nullptr, nullptr, st, &s.status_off))
         return rc;
     HIP_TRY(hipEventRecord(s.done, st));
     s.busy = true;
     c->last_slot = static_cast<int>(sp - c->dslots);
     c->last_n = n;
-    c->last_status_off = status_off;
-    if (!written && !status_out)
+    c->last_status.clear();
+    if (!written && !status_out) {
+        s.frames.assign(frames, frames + n);
+        s.post = c->post;
+        s.unresolved = true;
         return 0;
-
-    std::vector<int32_t> status(n);
-    if (int rc = fetch_status(c, s, status_off, n, st, status.data()))
-        return rc;
-    std::vector<uint32_t> encH(n);
-    for (int i = 0; i < n; i++)
-        encH[i] = static_cast<uint32_t>(up(std::max(frames[i].height, 1), 4));
-
-    // frames coded with a geometry other than ceil64(w) x ceil4(h): read the
-    // real header and run them again with it
-    std::vector<int> redo;
-    for (int i = 0; i < n; i++)
-        if (status[i] == E_GEOMETRY || status[i] == E_LAYOUT)
-            redo.push_back(i);
-    if (!redo.empty()) {
-        std::vector<mcraw_frame> rf(redo.size());
-        std::vector<Geom7> rg(redo.size());
-        for (size_t k = 0; k < redo.size(); k++) {
-            rf[k] = frames[redo[k]];
-            uint32_t hdr[4] = {0, 0, 0, 0};
-            HIP_TRY(hipMemcpyAsync(hdr, rf[k].in, 16, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            rg[k] = {hdr[0], hdr[1], 1u};
-        }
-        Slot *s2 = nullptr;
-        if (int rc = acquire_slot(c, &s2, true))
-            return rc;
-        size_t off2 = 0;
-        if (int rc = submit(c, *s2, rf.data(), static_cast<int>(rf.size()), &rg, nullptr, nullptr, st, &off2))
-            return rc;
-        HIP_TRY(hipEventRecord(s2->done, st));
-        s2->busy = true;
-        std::vector<int32_t> st2(rf.size());
-        if (int rc = fetch_status(c, *s2, off2, static_cast<int>(rf.size()), st, st2.data()))
-            return rc;
-        for (size_t k = 0; k < redo.size(); k++) {
-            status[redo[k]] = (st2[k] & (E_GEOMETRY | E_LAYOUT)) ? MCRAW_E_HEADER : st2[k];
-            encH[redo[k]] = rg[k].encH;
-        }
     }
+    s.unresolved = false;
+    std::vector<int32_t> status(n);
+    std::vector<uint32_t> encH(n, 0u);
+    if (int rc = resolve_device(c, s, frames, n, st, status.data(), encH.data()))
+        return rc;
+    c->last_status = status;
     for (int i = 0; i < n; i++) {
         if (status_out)
             status_out[i] = status[i];
@@ -588,12 +629,162 @@ int decode_device(mcraw_ctx *c, const mcraw_frame *frames, int n, hipStream_t st
     return 0;
 }
 
+// What submit() rejects on the host before any device work (MCRAW_E_ARGS).
+inline bool frame_args_ok(const mcraw_frame &f, const void *in, const void *out)
+{
+    return in && out && f.width > 0 && f.height > 0 && f.len != 0 && f.len < (1ull << 32) &&
+           (f.type == MCRAW_TYPE_BLOCK || f.type == MCRAW_TYPE_LEGACY) && reinterpret_cast<uintptr_t>(out) % 2 == 0 &&
+           static_cast<uint64_t>(f.width) * static_cast<uint64_t>(f.height) < (1ull << 31);
+}
+
+// Coded geometry from the 16-byte frame header (RawData.cpp:500-524) when the host can read it; zeros
+// (= plan from width x height) when it is not a header a frame could decode with (:547-554).
+inline Geom7 header_geometry(const mcraw_frame &f)
+{
+    Geom7 g{0u, 0u};
+    if (f.type != MCRAW_TYPE_BLOCK || !f.in || f.len < 16 || f.width <= 0)
+        return g;
+    uint32_t h[2];
+    std::memcpy(h, f.in, 8);
+    if (h[0] == 0u || h[1] == 0u || (h[0] & 63u) || (h[1] & 3u) || h[0] < static_cast<uint32_t>(f.width) ||
+        static_cast<uint64_t>(h[0]) * h[1] >= (1ull << 31))
+        return g;
+    g.encW = h[0];
+    g.encH = h[1];
+    return g;
+}
+
 // Host-memory batch, cut into sub-batches that flow through three lanes: every upload on one stream,
 // the kernels of a sub-batch on its slot's stream, every download on a third stream, chained by
 // events -- so each copy engine runs back to back over the sub-batches while the kernels of the next
 // one execute (BASELINE config 3: "pinned H2D + decode overlapped on HIP streams").  With the copies
 // of a sub-batch on its slot's own stream (first version) the engines idled between sub-batches:
 // 2 150 instead of 2 630 UHD frames/s.
+// The frame headers are in host memory here, so every frame is planned from its real geometry.
+int host_submit_part(mcraw_ticket *t, int first, int count)
+{
+    mcraw_ctx *c = t->c;
+    const mcraw_frame *frames = t->frames.data();
+    Slot *sp = nullptr;
+    if (int rc = acquire_slot(c, &sp))
+        return rc;
+    Slot &s = *sp;
+    hipStream_t st = s.stream;
+    // Device staging mirrors the host layout wherever frames are neighbours in host memory (inputs: up
+    // to 256 bytes apart; outputs: exactly adjacent, a copy must not touch bytes between two buffers):
+    // such a run moves with ONE copy per direction -- a copy call costs about 6 us, which is what a
+    // stream of small frames would otherwise be bound by.  Offsets keep the host address modulo 256.
+    // Neighbours are assumed to belong to one allocation (the usual case: slices of one pinned buffer);
+    // where the runtime refuses a merged copy (hipErrorInvalidValue: it spans two allocations) the run
+    // is copied frame by frame instead.
+    struct Run {
+        uintptr_t host;
+        size_t bytes, dev;
+        int first, last; // frames of the run (sub-batch indices)
+    };
+    std::vector<Run> rin, rout;
+    std::vector<size_t> in_off(count, SIZE_MAX), out_off(count, SIZE_MAX), out_len(count, 0);
+    std::vector<Geom7> geom(count);
+    size_t io = 0, oo = 0;
+    uintptr_t lay_host_end = 0;
+    size_t lay_dev_end = 0;
+    bool lay_ok = false;
+    for (int i = 0; i < count; i++) {
+        const mcraw_frame &f = frames[first + i];
+        geom[i] = header_geometry(f);
+        if (!frame_args_ok(f, f.in, f.out))
+            continue; // rejected by submit() with MCRAW_E_ARGS: nothing is staged, nothing is copied
+        const uintptr_t a = reinterpret_cast<uintptr_t>(f.in);
+        if (!rin.empty() && a >= rin.back().host + rin.back().bytes && a - (rin.back().host + rin.back().bytes) <= 256) {
+            in_off[i] = rin.back().dev + (a - rin.back().host);
+            rin.back().bytes = a + f.len - rin.back().host;
+            rin.back().last = i;
+        } else {
+            const size_t dev = up(io, ALIGN) + (a & (ALIGN - 1));
+            rin.push_back({a, f.len, dev, i, i});
+            in_off[i] = dev;
+        }
+        io = rin.back().dev + rin.back().bytes;
+        out_len[i] = std::min(f.out_capacity * 2, static_cast<size_t>(f.height) * post_row_bytes(static_cast<uint32_t>(f.width), c->post.mode));
+        // the kernels may write a whole frame even when the caller's capacity is smaller (that frame then
+        // fails with MCRAW_E_CAPACITY before any kernel runs): reserve the full size on the device
+        const size_t full = std::max(out_len[i], static_cast<size_t>(f.width) * f.height * 2);
+        const uintptr_t ao = reinterpret_cast<uintptr_t>(f.out);
+        if (lay_ok && ao == lay_host_end)
+            out_off[i] = lay_dev_end; // adjacent in host memory: adjacent in the staging too
+        else
+            out_off[i] = up(oo, ALIGN) + (ao & (ALIGN - 1));
+        lay_ok = full == out_len[i]; // nothing behind this frame's bytes in the staging
+        lay_host_end = ao + out_len[i];
+        lay_dev_end = out_off[i] + out_len[i];
+        oo = std::max(oo, out_off[i] + full);
+    }
+    if (int rc = ensure(s.dev_in, io + ALIGN, false))
+        return rc;
+    if (int rc = ensure(s.dev_out, oo + ALIGN, false))
+        return rc;
+    std::vector<const uint8_t *> din(count);
+    std::vector<uint16_t *> dout(count);
+    for (int i = 0; i < count; i++) {
+        din[i] = in_off[i] != SIZE_MAX ? static_cast<uint8_t *>(s.dev_in.p) + in_off[i] : nullptr;
+        dout[i] = out_off[i] != SIZE_MAX ? reinterpret_cast<uint16_t *>(static_cast<uint8_t *>(s.dev_out.p) + out_off[i]) : nullptr;
+    }
+    for (const Run &r : rin) {
+        hipError_t e = hipMemcpyAsync(static_cast<uint8_t *>(s.dev_in.p) + r.dev, reinterpret_cast<const void *>(r.host), r.bytes,
+                                      hipMemcpyHostToDevice, c->h2d);
+        if (e == hipErrorInvalidValue && r.last > r.first) {
+            (void)hipGetLastError();
+            for (int i = r.first; i <= r.last; i++)
+                if (in_off[i] != SIZE_MAX)
+                    HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(s.dev_in.p) + in_off[i], frames[first + i].in, frames[first + i].len,
+                                           hipMemcpyHostToDevice, c->h2d));
+        } else
+            HIP_TRY(e);
+    }
+    // three lanes: all uploads queue on one stream, all downloads on another (each copy engine then
+    // runs back to back over the sub-batches), the kernels of a sub-batch on its slot's stream between
+    HIP_TRY(hipEventRecord(s.uploaded, c->h2d));
+    HIP_TRY(hipStreamWaitEvent(st, s.uploaded, 0));
+    size_t status_off = 0;
+    if (int rc = submit(c, s, frames + first, count, &geom, din.data(), dout.data(), st, &status_off))
+        return rc;
+    HIP_TRY(hipEventRecord(s.decoded, st));
+    HIP_TRY(hipStreamWaitEvent(c->d2h, s.decoded, 0));
+    // downloads: only frames the host has not rejected (a rejected frame's buffer stays untouched; the
+    // content of a buffer whose frame fails on the device is undefined)
+    for (int i = 0; i < count; i++) {
+        if (out_off[i] == SIZE_MAX || s.host_status[i] != 0 || out_len[i] == 0)
+            continue;
+        const uintptr_t a = reinterpret_cast<uintptr_t>(frames[first + i].out);
+        if (!rout.empty() && rout.back().last == i - 1 && a == rout.back().host + rout.back().bytes &&
+            out_off[i] == rout.back().dev + rout.back().bytes) {
+            rout.back().bytes += out_len[i];
+            rout.back().last = i;
+        } else
+            rout.push_back({a, out_len[i], out_off[i], i, i});
+    }
+    for (const Run &r : rout) {
+        hipError_t e = hipMemcpyAsync(reinterpret_cast<void *>(r.host), static_cast<uint8_t *>(s.dev_out.p) + r.dev, r.bytes,
+                                      hipMemcpyDeviceToHost, c->d2h);
+        if (e == hipErrorInvalidValue && r.last > r.first) {
+            (void)hipGetLastError();
+            for (int i = r.first; i <= r.last; i++)
+                HIP_TRY(hipMemcpyAsync(frames[first + i].out, static_cast<uint8_t *>(s.dev_out.p) + out_off[i], out_len[i],
+                                       hipMemcpyDeviceToHost, c->d2h));
+        } else
+            HIP_TRY(e);
+    }
+    HIP_TRY(hipEventRecord(s.done, c->d2h));
+    s.busy = true;
+    // the slot keeps this sub-batch's statuses until they are drained into the ticket: by
+    // mcraw_ticket_wait, or earlier by acquire_slot when the ring comes round (more sub-batches in
+    // flight than slots)
+    s.owner = t;
+    s.owner_part = static_cast<int>(t->parts.size());
+    t->parts.push_back({static_cast<int>(sp - c->slots), first, count, status_off, false});
+    return 0;
+}
+
 // Queue a host-memory batch (ticket->frames): returns when the last sub-batch is submitted.
 int host_submit(mcraw_ticket *t)
 {
@@ -602,6 +793,7 @@ int host_submit(mcraw_ticket *t)
     const int n = static_cast<int>(t->frames.size());
     constexpr size_t SUB_BYTES = 96ull << 20; // compressed + decoded bytes per sub-batch (64-160 MB measure within 3 %)
     t->status.assign(n, 0);
+    t->encH.assign(n, 0u);
     t->post = c->post;
     int first = 0;
     while (first < n) {
@@ -609,92 +801,24 @@ int host_submit(mcraw_ticket *t)
         int count = 0;
         while (first + count < n) {
             const mcraw_frame &f = frames[first + count];
-            size_t fb = f.len + (f.width > 0 && f.height > 0 ? static_cast<size_t>(f.width) * f.height * 2 : 0);
+            const size_t fb = frame_args_ok(f, f.in, f.out) ? f.len + static_cast<size_t>(f.width) * f.height * 2 : 0;
             if (count > 0 && bytes + fb > SUB_BYTES)
                 break;
             bytes += fb;
             count++;
         }
-        Slot *sp = nullptr;
-        if (int rc = acquire_slot(c, &sp))
-            return rc;
-        Slot &s = *sp;
-        hipStream_t st = s.stream;
-        // Device staging mirrors the host layout wherever frames are neighbours in host memory (inputs: up
-        // to 256 bytes apart; outputs: exactly adjacent, a copy must not touch bytes between two buffers):
-        // such a run moves with ONE copy per direction -- a copy call costs about 6 us, which is what a
-        // stream of small frames would otherwise be bound by.  Offsets keep the host address modulo 256.
-        struct Run {
-            uintptr_t host;
-            size_t bytes, dev;
-        };
-        std::vector<Run> rin, rout;
-        std::vector<size_t> in_off(count, SIZE_MAX), out_off(count, SIZE_MAX), out_len(count, 0);
-        size_t io = 0, oo = 0;
-        for (int i = 0; i < count; i++) {
-            const mcraw_frame &f = frames[first + i];
-            if (f.in && f.len) {
-                const uintptr_t a = reinterpret_cast<uintptr_t>(f.in);
-                if (!rin.empty() && a >= rin.back().host + rin.back().bytes && a - (rin.back().host + rin.back().bytes) <= 256) {
-                    in_off[i] = rin.back().dev + (a - rin.back().host);
-                    rin.back().bytes = a + f.len - rin.back().host;
-                } else {
-                    const size_t dev = up(io, ALIGN) + (a & (ALIGN - 1));
-                    rin.push_back({a, f.len, dev});
-                    in_off[i] = dev;
-                }
-                io = rin.back().dev + rin.back().bytes;
+        if (int rc = host_submit_part(t, first, count)) {
+            // nothing of this batch may still be moving when the caller hears of the failure (it may free its buffers)
+            (void)hipStreamSynchronize(c->h2d);
+            for (Part &p : t->parts) {
+                (void)hipEventSynchronize(c->slots[p.slot].done);
+                c->slots[p.slot].busy = false;
+                c->slots[p.slot].owner = nullptr;
+                p.drained = true;
             }
-            if (f.out && f.in && f.len && f.width > 0 && f.height > 0) { // (a frame without input is rejected: its buffer stays untouched)
-                const uintptr_t a = reinterpret_cast<uintptr_t>(f.out);
-                out_len[i] = std::min(f.out_capacity * 2, static_cast<size_t>(f.height) * post_row_bytes(static_cast<uint32_t>(f.width), c->post.mode));
-                // the kernels may write a whole frame even when the caller's capacity is smaller (that frame then
-                // fails with MCRAW_E_CAPACITY before any kernel runs): reserve the full size on the device
-                const size_t full = std::max(out_len[i], static_cast<size_t>(f.width) * f.height * 2);
-                if (!rout.empty() && a == rout.back().host + rout.back().bytes && full == out_len[i]) {
-                    out_off[i] = rout.back().dev + rout.back().bytes;
-                    rout.back().bytes += out_len[i];
-                } else {
-                    const size_t dev = up(oo, ALIGN) + (a & (ALIGN - 1));
-                    rout.push_back({a, out_len[i], dev});
-                    out_off[i] = dev;
-                }
-                oo = std::max(oo, out_off[i] + full);
-            }
+            (void)hipStreamSynchronize(c->d2h);
+            return rc;
         }
-        if (int rc = ensure(s.dev_in, io + ALIGN, false))
-            return rc;
-        if (int rc = ensure(s.dev_out, oo + ALIGN, false))
-            return rc;
-        std::vector<const uint8_t *> din(count);
-        std::vector<uint16_t *> dout(count);
-        for (int i = 0; i < count; i++) {
-            din[i] = in_off[i] != SIZE_MAX ? static_cast<uint8_t *>(s.dev_in.p) + in_off[i] : nullptr;
-            dout[i] = out_off[i] != SIZE_MAX ? reinterpret_cast<uint16_t *>(static_cast<uint8_t *>(s.dev_out.p) + out_off[i]) : nullptr;
-        }
-        for (const Run &r : rin)
-            HIP_TRY(hipMemcpyAsync(static_cast<uint8_t *>(s.dev_in.p) + r.dev, reinterpret_cast<const void *>(r.host), r.bytes,
-                                   hipMemcpyHostToDevice, c->h2d));
-        // three lanes: all uploads queue on one stream, all downloads on another (each copy engine then
-        // runs back to back over the sub-batches), the kernels of a sub-batch on its slot's stream between
-        HIP_TRY(hipEventRecord(s.uploaded, c->h2d));
-        HIP_TRY(hipStreamWaitEvent(st, s.uploaded, 0));
-        size_t status_off = 0;
-        if (int rc = submit(c, s, frames + first, count, nullptr, din.data(), dout.data(), st, &status_off))
-            return rc;
-        HIP_TRY(hipEventRecord(s.decoded, st));
-        HIP_TRY(hipStreamWaitEvent(c->d2h, s.decoded, 0));
-        for (const Run &r : rout)
-            HIP_TRY(hipMemcpyAsync(reinterpret_cast<void *>(r.host), static_cast<uint8_t *>(s.dev_out.p) + r.dev, r.bytes,
-                                   hipMemcpyDeviceToHost, c->d2h));
-        HIP_TRY(hipEventRecord(s.done, c->d2h));
-        s.busy = true;
-        // the slot keeps this sub-batch's statuses until they are drained into the ticket: by
-        // mcraw_ticket_wait, or earlier by acquire_slot when the ring comes round (more sub-batches in
-        // flight than slots)
-        s.owner = t;
-        s.owner_part = static_cast<int>(t->parts.size());
-        t->parts.push_back({static_cast<int>(sp - c->slots), first, count, status_off, false});
         first += count;
     }
     return 0;
@@ -703,59 +827,18 @@ int host_submit(mcraw_ticket *t)
 // Wait for a host-memory batch and resolve its statuses.
 int host_finish(mcraw_ticket *t, size_t *written, int32_t *status_out)
 {
-    mcraw_ctx *c = t->c;
     const mcraw_frame *frames = t->frames.data();
     const int n = static_cast<int>(t->frames.size());
-    std::vector<int32_t> &status = t->status;
     for (size_t k = 0; k < t->parts.size(); k++)
         if (int rc = drain_part(t, static_cast<int>(k)))
             return rc;
-    const Post post_now = c->post;
-    c->post = t->post; // a re-planned frame gets the post stage the batch was submitted with
-    struct RestorePost {
-        mcraw_ctx *c;
-        Post p;
-        ~RestorePost() { c->post = p; }
-    } restore{c, post_now};
-    (void)restore;
-
-    // geometry mismatches: the header is readable on the host here
     for (int i = 0; i < n; i++) {
-        uint32_t encH = static_cast<uint32_t>(up(std::max(frames[i].height, 1), 4));
-        if (status[i] == E_GEOMETRY || status[i] == E_LAYOUT) {
-            const mcraw_frame &f = frames[i];
-            uint32_t hdr[4];
-            std::memcpy(hdr, f.in, 16);
-            std::vector<Geom7> g{{hdr[0], hdr[1], 1u}};
-            Slot *sp = nullptr;
-            if (int rc = acquire_slot(c, &sp))
-                return rc;
-            Slot &s = *sp;
-            hipStream_t st = s.stream;
-            if (int rc = ensure(s.dev_in, f.len + ALIGN, false))
-                return rc;
-            if (int rc = ensure(s.dev_out, static_cast<size_t>(f.width) * f.height * 2 + ALIGN, false))
-                return rc;
-            const uint8_t *din = static_cast<uint8_t *>(s.dev_in.p);
-            uint16_t *dout = static_cast<uint16_t *>(s.dev_out.p);
-            HIP_TRY(hipMemcpyAsync(s.dev_in.p, f.in, f.len, hipMemcpyHostToDevice, st));
-            size_t so = 0;
-            if (int rc = submit(c, s, &f, 1, &g, &din, &dout, st, &so))
-                return rc;
-            size_t nbytes = std::min(f.out_capacity * 2, static_cast<size_t>(f.height) * post_row_bytes(static_cast<uint32_t>(f.width), c->post.mode));
-            HIP_TRY(hipMemcpyAsync(f.out, dout, nbytes, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipEventRecord(s.done, st));
-            s.busy = true;
-            int32_t st2 = 0;
-            if (int rc = fetch_status(c, s, so, 1, st, &st2))
-                return rc;
-            status[i] = (st2 & (E_GEOMETRY | E_LAYOUT)) ? MCRAW_E_HEADER : st2;
-            encH = hdr[1];
-        }
+        // every frame was planned from its real header (header_geometry), so no frame is left to plan again
+        const int32_t st = public_status(t->status[i]);
         if (status_out)
-            status_out[i] = status[i];
+            status_out[i] = st;
         if (written)
-            written[i] = written_of(frames[i], status[i], encH);
+            written[i] = written_of(frames[i], st, t->encH[i]);
     }
     return 0;
 }
@@ -794,6 +877,11 @@ mcraw_ctx *default_ctx()
         if (mcraw_ctx_create(-1, &c) != 0)
             return nullptr;
         g_default = c;
+        std::atexit([]() { // the process-wide context of the five-argument entry points
+            std::lock_guard<std::mutex> lk2(g_default_mu);
+            mcraw_ctx_destroy(g_default);
+            g_default = nullptr;
+        });
     }
     return g_default;
 }
@@ -849,9 +937,15 @@ int mcraw_ctx_create(int device, mcraw_ctx **out)
         return -static_cast<int>(hipErrorInvalidDevice);
     }
     HIP_TRY(hipSetDevice(device));
-    mcraw_ctx *c = new mcraw_ctx();
+    // a half-built context is torn down again on any failure below
+    struct Guard {
+        mcraw_ctx *c;
+        ~Guard() { if (c) mcraw_ctx_destroy(c); }
+    } guard{new mcraw_ctx()};
+    mcraw_ctx *c = guard.c;
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->h2d, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->d2h, hipStreamNonBlocking));
     for (Slot &s : c->slots) {
@@ -862,6 +956,7 @@ int mcraw_ctx_create(int device, mcraw_ctx **out)
     }
     for (Slot &s : c->dslots)
         HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    guard.c = nullptr;
     *out = c;
     return 0;
 }
@@ -887,6 +982,7 @@ void mcraw_ctx_destroy(mcraw_ctx *c)
         release(s);
     for (Slot &s : c->dslots)
         release(s);
+    release(c->rslot);
     for (KStat &k : c->kstat)
         for (auto &p : k.pending) {
             (void)hipEventDestroy(p.first);
@@ -896,6 +992,8 @@ void mcraw_ctx_destroy(mcraw_ctx *c)
         (void)hipEventDestroy(e);
     if (c->stream)
         (void)hipStreamDestroy(c->stream);
+    if (c->aux)
+        (void)hipStreamDestroy(c->aux);
     if (c->h2d)
         (void)hipStreamDestroy(c->h2d);
     if (c->d2h)
@@ -976,19 +1074,23 @@ int mcraw_ctx_synchronize(mcraw_ctx *c, int32_t *status, int nframes)
             HIP_TRY(hipEventSynchronize(s.done));
             s.busy = false;
         }
-    for (Slot &s : c->dslots)
-        if (s.busy) {
+    for (int k = 0; k < NDSLOT; k++) {
+        Slot &s = c->dslots[k];
+        if (!s.busy)
+            continue;
+        const bool last = k == c->last_slot;
+        if (s.unresolved) { // submitted without a status request: frames that need a second plan get it now
+            if (int rc = settle_slot(c, s, last ? &c->last_status : nullptr))
+                return rc;
+        } else {
             HIP_TRY(hipEventSynchronize(s.done));
             s.busy = false;
         }
-    if (status && c->last_slot >= 0) {
-        Slot &s = c->dslots[c->last_slot];
-        int n = std::min(nframes, c->last_n);
-        if (int rc = fetch_status(c, s, c->last_status_off, n, c->stream, status))
-            return rc;
+    }
+    if (status) {
+        const int n = std::min(nframes, c->last_n);
         for (int i = 0; i < n; i++)
-            if (status[i] & (E_GEOMETRY | E_LAYOUT))
-                status[i] = MCRAW_E_HEADER; // asynchronous submits are not re-planned
+            status[i] = i < static_cast<int>(c->last_status.size()) ? c->last_status[i] : 0;
     }
     return 0;
 }

@@ -6,13 +6,10 @@
 
 namespace mcraw {
 
-// Internal status bit on top of include/mcraw_hip.h: the coded geometry in the
-// frame header differs from the one the host planned with (ceil64(width) x
-// ceil4(height)); the host re-plans that frame from the real header.
+// Internal status bit on top of include/mcraw_hip.h: the frame's header describes a coded frame
+// with more blocks than the host planned for (it plans from the caller's width x height, or from
+// the header where it can read it); the host plans that frame again from the real header.
 constexpr int32_t E_GEOMETRY = 0x1000;
-// ... or: the bits side stream does not end before the refs side stream begins; the host
-// re-plans the frame without the extent hint (Plan7::full_extent).
-constexpr int32_t E_LAYOUT = 0x2000;
 
 constexpr int GROUP_BLOCKS = 64;   // blocks per side-stream record = per decode group
 constexpr int GROUP_TILES = 16;    // 64x4 tiles per group
@@ -24,8 +21,6 @@ constexpr int ITEM_BLOCKS = GROUP_BLOCKS / ITEM_SPLIT;
 constexpr int ITEM_TILES = GROUP_TILES / ITEM_SPLIT;
 constexpr int ITEM_SPAN = ITEM_BLOCKS * 128; // largest payload span of one item (all raw-16)
 constexpr int SPAN_MAX = 64 * 128; // largest payload span of one group (all raw-16)
-constexpr int CH7 = 1024;          // bytes of side stream per transition-map chunk
-constexpr int PH7 = 65;            // entry offsets 0,2,..,128 (record stride 2 + LEN <= 130, all even)
 
 // Optional stage fused behind the decode (what a DNG writer does next with the mosaic,
 // example.cpp:80-92): black-level subtraction and 12-bit strip packing.  Batch-wide, passed by value.
@@ -43,19 +38,17 @@ __host__ __device__ inline uint32_t post_row_bytes(uint32_t width, uint32_t mode
 }
 
 // Per-frame plan of the current ("type 7") encoding; lives in HBM for the
-// duration of one batch.
+// duration of one batch.  Geometry is NOT part of it: the kernels take it from the frame header
+// (lib/RawData.cpp:500-524); the plan only says how much workspace and grid the frame was given.
 struct Plan7 {
     const uint8_t *in;   // frame buffer (lib/RawData.cpp:528 `input`)
     uint16_t *out;       // width x rows mosaic
     uint32_t len;
     int32_t width;       // output columns kept (crop of encW, :598-608)
-    int32_t rows;        // output rows kept = min(height, encH)
-    uint32_t encW, encH; // coded geometry the plan assumes (:500-511)
-    uint32_t tilesX;     // encW / 64
-    uint32_t nblk;       // N = 4 * tilesX * encH/4  (payload blocks = side-stream entries used)
-    uint32_t ngroups;    // R = ceil(N / 64)
+    int32_t height;      // output rows the caller has room for; rows kept = min(height, encH)
+    uint32_t ngroups;    // decode groups (side-stream records) the workspace and the k7_tiles grid provide for
     uint32_t fast_store; // 1: out 16-B aligned and width % 8 == 0
-    uint32_t full_extent; // 1: do not assume the bits stream ends where the refs stream starts
+    uint32_t pad;
 };
 
 // Batch-wide view of the type-7 work, passed to the kernels BY VALUE (kernarg):
@@ -64,20 +57,14 @@ struct Plan7 {
 // without any dependent pointer load.
 struct Work7 {
     const Plan7 *plans;  // [n7]
-    int32_t *status;     // [n7] status word of every type-7 frame
-    uint32_t *cmap;      // [n7][2][nch][PH7] transition map of every side-stream chunk (exit phase | count << 8)
-    uint32_t *centry;    // [n7][2][nch]      resolved entry of every chunk (phase | first record << 8)
-    uint4 *sinfo;        // [n7][2]           per stream: first record offset, chunks to map, extent hinted, -
-    uint4 *list_maps;    // work list of k7_maps:    (stream, first of 3 chunks, its byte offset, chunks of the stream)
-    uint4 *list_recs;    // work lists of k7_records: sparse items (stream, first chunk | chunks << 24, byte offset, end of
-                         // the record range) from the front, dense items (stream, records, byte offset, entry) from the back
-    uint32_t *counters;  // [0] k7_maps items, [1] sparse / [2] dense k7_records items (zeroed by the table upload)
-    uint32_t list_cap;   // capacity of list_recs (dense items are filled in from the back)
+    int32_t *status;     // [nstatus] status word of every frame of the batch (type-7 frames first), then
+                         // [n7] the coded height of every type-7 frame (read back with the statuses)
+    uint4 *geo;          // [n7] geometry from the frame header: tilesX, blocks N, rows kept, encH (written by k7_side)
     uint8_t *bits;       // [n7][Rmax*64]  decoded `bits` stream  (:557)
     uint16_t *refs;      // [n7][Rmax*64]  decoded `refs` stream  (:560)
     uint32_t *grp_off;   // [n7][Rmax*ITEM_SPLIT+1] payload byte offset of every decode item (:562 + prefix of LEN)
     uint32_t Rmax;       // largest ngroups in the batch
-    uint32_t nch;        // side-stream chunks planned per stream (covers Rmax records of 130 bytes)
+    uint32_t nstatus;    // status words in front of the coded heights
     int32_t n7;
     Post post;           // fused post-decode stage (mode 0: none)
     // k7_tiles is launched once per SIZE CLASS of the batch (plans are sorted by ngroups, descending):

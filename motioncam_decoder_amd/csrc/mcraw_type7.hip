@@ -1,13 +1,11 @@
 // mcraw_type7.hip -- gfx950 kernels for the current MCRAW frame encoding
 // (compressionType 7).  Replaces motioncam::raw::Decode, lib/RawData.cpp:528-612.
 //
-//   k7_hdr, k7_maps, k7_follow   header checks + side-stream chain resolve
-//                                (RawData.cpp:500-524, 547-554; :463-498 the inline-header chain)
-//   k7_records (sparse / dense)  side-stream record decode (RawData.cpp:485-495)
-//                                -> bits[], refs[], byte length of every decode item
-//   k7_scan                      payload offsets (RawData.cpp:562, 576-579: offset += LEN[bits])
-//   k7_tiles                     tile unpack + reference add + Bayer interleave + crop
-//                                (RawData.cpp:410-461, 112-408, 581-593, 598-608)  <- the roofline kernel
+//   k7_side    one workgroup per side stream: header checks (RawData.cpp:500-524, 547-554), the
+//              inline-header record chain (:463-498), record decode (:485-495) -> bits[], refs[],
+//              and the payload offset of every decode item (:562, 576-579: offset += LEN[bits])
+//   k7_tiles   tile unpack + reference add + Bayer interleave + crop
+//              (RawData.cpp:410-461, 112-408, 581-593, 598-608)  <- the roofline kernel
 //
 // Integer bit-slicing on byte planes; no MFMA.  A "group" is the 64 payload blocks (16 tiles of
 // 64x4 px) described by one record of the bits stream; a decode "item" is half of it (32 blocks,
@@ -130,302 +128,39 @@ __device__ __forceinline__ Unpacked unpack8(const uint8_t *__restrict__ base, ui
     return u;
 }
 
-// ------------------------------------------------------------------ side-stream chain
+// ------------------------------------------------------------------ side streams: k7_side
 //
 // A side stream is a chain of records {hbits<<4 | ref>>8, ref & 255, LEN[hbits] payload
 // bytes}: where record i+1 starts is only known from the header of record i
-// (RawData.cpp:485-495).  A lone wave chasing ~2000 headers per stream costs ~0.3 ms,
-// so the chain is resolved in parallel with TRANSITION MAPS: record strides are even and
-// at most 130 bytes, hence a fixed 1 KiB chunk of the stream can only be entered at 65
-// offsets ("phases" 0,2,..,128 past the chunk start).
+// (RawData.cpp:485-495).  ONE WORKGROUP PER STREAM resolves the chain, decodes the records
+// and (bits stream) turns the block lengths into payload offsets -- no hand-off between
+// workgroups, one launch for everything in front of k7_tiles.
 //
-//   k7_hdr      per stream: validate the frame header (RawData.cpp:547-554), find where the
-//               stream starts and how many chunks it can span; build the work list of k7_maps
-//   k7_maps     per chunk: table of record strides, then per phase a walk over it to the chunk end
-//               -> (exit phase into the next chunk, records started)
-//   k7_follow   per stream: follow the true phase through the chunk maps
-//               -> (entry phase, first record index) per chunk; work list of k7_records
-//   k7_records  per 4 chunks (a lane walks each from its true entry), or per chunk of tiny records
-//               (pointer doubling): list the records, unpack eight of them per pass
-//               -> bits[], refs[], byte length of every decode item
+// The stream is taken through LDS in PIECES of 16 KiB (the next piece is already on its way from
+// HBM while this one is worked on).  Per piece:
+//   1. chain walk by RUN SPECULATION (one wave): the record at p has stride S; lane j reads the
+//      header that would sit at p + j*S.  All lanes up to the first one that finds another stride
+//      (or the end of the piece, or a record that crosses `len`, RawData.cpp:419-420) ARE records --
+//      each is where its predecessor ends -- and that first other lane is the next record, its
+//      stride already in hand.  One LDS gather per run of equally long records instead of one
+//      dependent read per record: coded frames are made of long runs (a few dozen to ~130 steps
+//      per UHD stream of 2 025 records; one per record when two sizes alternate at random).
+//      Exact for any content: nothing is assumed, lanes only confirm.
+//   2. record decode: eight records per wave and pass are unpacked like payload blocks (DecodeBlock
+//      on the record, RawData.cpp:489; + reference, :491-492) -> refs[] (u16) / bits[] (u8, validated);
+//   3. bits stream: byte length of every decode item, exclusive scan over the workgroup plus the
+//      running carry -> payload offset of every item (RawData.cpp:562, :576-579).
 //
-// k7_maps and k7_records are persistent grids looping over device-built work lists, so no
-// workgroup is spent on chunks that lie beyond a stream.
-constexpr uint32_t DEAD7 = 127u; // phase value: the chain has ended (record past `len`, or all records found)
-
-constexpr uint32_t MAPS_CH = 3; // chunks per 256-thread workgroup: 3 x 65 phases = 195 lanes
-constexpr uint32_t NODEAD = 0xFFFFu;
-constexpr uint32_t DENSE_RECORDS = 96; // k7_records lists chunks with more records by pointer doubling
-constexpr uint32_t REC_GROUP = 4;      // consecutive sparse chunks per k7_records work item (one walking lane each)
-
-// Where the record whose header sits at staged offset `rel` ends (= where the next one
-// starts), or NODEAD when it would cross `len` (RawData.cpp:419-420 skips such a block).
-__device__ __forceinline__ uint32_t next_of(const uint8_t *s_b, uint32_t head, uint32_t rel, uint32_t abs, uint32_t len)
-{
-    const uint32_t nx = rel + 2u + len7_of(static_cast<uint32_t>(s_b[head + rel]) >> 4);
-    return abs + nx > len ? NODEAD : nx;
-}
-
-// One wave per side stream (index fs = 2 * frame + s; s = 0 bits, 1 refs).
-__global__ __launch_bounds__(64) void k7_hdr(const Work7 W)
-{
-    const uint32_t fs = blockIdx.x, lane = threadIdx.x;
-    const uint32_t f = fs >> 1, s = fs & 1u;
-    const Plan7 *P = W.plans + f;
-    const uint32_t len = P->len;
-    const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
-    const uint4 hv = ld_b128(rs, 0); // frame header: 4 x u32 LE (RawData.cpp:500-524); zeros when len < 16
-    const uint32_t encW = __builtin_amdgcn_readfirstlane(hv.x), encH = __builtin_amdgcn_readfirstlane(hv.y);
-    const uint32_t bitsOff = __builtin_amdgcn_readfirstlane(hv.z), refsOff = __builtin_amdgcn_readfirstlane(hv.w);
-    const uint32_t so = s ? refsOff : bitsOff;
-    int32_t err = 0;
-    bool frame_ok = false;
-    if (len < 16u || bitsOff > len || refsOff > len || (encW & 63u) != 0u || encW < static_cast<uint32_t>(P->width) ||
-        encW == 0u || encH == 0u || (encH & 3u) != 0u)
-        err = MCRAW_E_HEADER; // RawData.cpp:547-554 returns 0
-    else if (encW != P->encW || encH != P->encH)
-        err = E_GEOMETRY;
-    else {
-        frame_ok = true;
-        if (so + 4u > len || so + 4u < so)
-            err = MCRAW_E_TRUNCATED;
-        else {
-            const uint32_t count = ld_u8(rs, so) | (ld_u8(rs, so + 1u) << 8) | (ld_u8(rs, so + 2u) << 16) |
-                                   (ld_u8(rs, so + 3u) << 24);
-            if (__builtin_amdgcn_readfirstlane(count) < P->nblk) // the reference would index past the vector (:573-574)
-                err = MCRAW_E_SIDESTREAM;
-        }
-    }
-    if (err && lane == 0)
-        atomicOr(W.status + f, err);
-    // Extent: the bits stream of a canonically laid out frame ends where the refs stream
-    // begins; k7_follow reports E_LAYOUT if its chain is still alive there and the host
-    // re-plans that frame with the hint off (Plan7::full_extent).
-    const uint32_t s0 = so + 4u;
-    uint32_t nchunk = 0, hinted = 0;
-    if (frame_ok && !err) {
-        uint32_t end = len;
-        if (s == 0u && !P->full_extent && refsOff > bitsOff) {
-            end = refsOff;
-            hinted = 1u;
-        }
-        if (end > s0)
-            nchunk = min(W.nch, (end - s0 + CH7 - 1u) / CH7);
-    }
-    const uint32_t nwg = (nchunk + MAPS_CH - 1u) / MAPS_CH;
-    uint32_t base = 0;
-    if (lane == 0) {
-        W.sinfo[fs] = make_uint4(s0, nchunk, hinted, 0u);
-        if (nwg)
-            base = atomicAdd(W.counters, nwg); // the order of the work list does not matter
-    }
-    base = __builtin_amdgcn_readfirstlane(base);
-    // everything k7_maps needs to start loading: stream, first chunk, its byte offset, chunk count
-    for (uint32_t i = lane; i < nwg; i += 64u)
-        W.list_maps[base + i] = make_uint4(fs, i * MAPS_CH, s0 + i * MAPS_CH * CH7, nchunk);
-}
-
-__global__ __launch_bounds__(256) void k7_maps(const Work7 W)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t s_b[MAPS_CH * CH7 + 32];
-    __shared__ uint16_t s_nxt[MAPS_CH * CH7 / 2];
-    constexpr uint32_t HALF7 = CH7 / 2;
-    __shared__ __attribute__((aligned(16))) uint8_t s_stride[MAPS_CH * HALF7 + 16 + 80]; // + head, + the last stride's reach
-
-    const uint32_t tid = threadIdx.x;
-    const uint32_t sub = tid / PH7, ph = tid - sub * PH7;
-    const uint32_t nwork = W.counters[0];
-    uint4 nextw = make_uint4(0, 0, 0, 0);
-    if (blockIdx.x < nwork)
-        nextw = W.list_maps[blockIdx.x];
-    for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
-        const uint4 e = nextw;
-        if (wi + gridDim.x < nwork) // descriptor of the next work item rides behind this one
-            nextw = W.list_maps[wi + gridDim.x];
-        const uint32_t fs = __builtin_amdgcn_readfirstlane(e.x), c0 = __builtin_amdgcn_readfirstlane(e.y);
-        const uint32_t abs0 = __builtin_amdgcn_readfirstlane(e.z), nchunk = __builtin_amdgcn_readfirstlane(e.w);
-        const Plan7 *P = W.plans + (fs >> 1);
-        const uint32_t len = P->len;
-        const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
-        const uint32_t base16 = abs0 & ~15u, head = abs0 - base16;
-        const uint32_t n16 = (head + MAPS_CH * CH7 + 15u) >> 4; // <= 194 lines: one per thread
-        const uint32_t c = c0 + sub;
-        if (len >= MAPS_CH * CH7 + 130u && abs0 <= len - (MAPS_CH * CH7 + 130u)) {
-            // No record that starts in these chunks can reach `len`.  Headers can sit at every
-            // second byte from `head` on; each thread turns the 8 candidates of one 16-byte line
-            // into record strides in half positions, 1 + LEN/2 (RawData.cpp:27-45), so that the 65
-            // walks of a chunk are chains of single-byte LDS reads
-            if (tid < n16) {
-                const uint4 v = ld_b128(rs, base16 + tid * 16u);
-                const uint32_t pick = (head & 1u) ? 0x07050301u : 0x06040200u;
-                uint32_t st[2];
-#pragma unroll
-                for (int i = 0; i < 2; i++) {
-                    const uint32_t h4 = i ? __builtin_amdgcn_perm(v.w, v.z, pick) : __builtin_amdgcn_perm(v.y, v.x, pick);
-                    const uint32_t hb = (h4 >> 4) & 0x0F0F0F0Fu;
-                    const uint32_t sel = hb & 0x07070707u;
-                    const uint32_t lo = __builtin_amdgcn_perm(0x08060504u, 0x03020100u, sel); // LEN/8, bits 0..7
-                    const uint32_t hi = __builtin_amdgcn_perm(0x10101010u, 0x100A0A08u, sel); // LEN/8, bits 8..15
-                    const uint32_t g = (hb >> 3) & 0x01010101u;
-                    const uint32_t m = (g << 8) - g;
-                    st[i] = (((hi & m) | (lo & ~m)) << 2) + 0x01010101u;
-                }
-                reinterpret_cast<uint2 *>(s_stride)[tid] = make_uint2(st[0], st[1]);
-            }
-            __syncthreads();
-            if (sub < MAPS_CH && c < nchunk) {
-                // table index u <-> staged byte 2u + (head & 1); chunk `sub` spans HALF7 indices from here
-                const uint8_t *pp = s_stride + (head >> 1) + sub * HALF7 + ph;
-                const uint8_t *const pe = s_stride + (head >> 1) + (sub + 1u) * HALF7;
-                uint32_t count = 0;
-                while (pp < pe) {
-                    pp += *pp;
-                    count++;
-                }
-                W.cmap[(static_cast<size_t>(fs) * W.nch + c) * PH7 + ph] = static_cast<uint32_t>(pp - pe) | (count << 8);
-            }
-        } else {
-            // the stream's last chunks: successor table with the `len` check (a record that would
-            // cross `len` ends the chain, RawData.cpp:419-420)
-            for (uint32_t q = tid; q < n16; q += 256u)
-                reinterpret_cast<uint4 *>(s_b)[q] = ld_b128(rs, base16 + q * 16u);
-            __syncthreads();
-            for (uint32_t i = tid; i < MAPS_CH * CH7 / 2; i += 256u)
-                s_nxt[i] = static_cast<uint16_t>(next_of(s_b, head, 2u * i, abs0, len));
-            __syncthreads();
-            if (sub < MAPS_CH && c < nchunk) {
-                const uint32_t hi = (sub + 1u) * CH7; // end of this chunk inside the staged bytes
-                uint32_t rel = sub * CH7 + 2u * ph, count = 0;
-                while (rel < hi) { // NODEAD ends the loop too
-                    rel = s_nxt[rel >> 1];
-                    count += rel != NODEAD ? 1u : 0u;
-                }
-                W.cmap[(static_cast<size_t>(fs) * W.nch + c) * PH7 + ph] =
-                    (rel == NODEAD ? DEAD7 : (rel - hi) >> 1) | (count << 8);
-            }
-        }
-        __syncthreads(); // the staging buffers are reused by the next work item
-    }
-}
-
-constexpr uint32_t FOLLOW_PIECE = 192; // chunk maps staged per pass (192 * 65 * 4 B = 49 KB)
-
-__global__ __launch_bounds__(256) void k7_follow(const Work7 W)
-{
-    __shared__ __attribute__((aligned(16))) uint32_t s_map[FOLLOW_PIECE * PH7];
-    __shared__ uint32_t s_entry[FOLLOW_PIECE];
-    __shared__ uint32_t s_state[4];
-
-    const uint32_t fs = blockIdx.x, f = fs >> 1;
-    int32_t *status = W.status + f;
-    if (*status != 0)
-        return;
-    const Plan7 *P = W.plans + f;
-    const uint32_t tid = threadIdx.x;
-    const uint4 si = W.sinfo[fs];
-    const uint32_t nchunk = si.y, hinted = si.z;
-    const uint32_t R = P->ngroups, nch = W.nch;
-    const uint32_t *maps = W.cmap + static_cast<size_t>(fs) * nch * PH7;
-    uint32_t *centry = W.centry + static_cast<size_t>(fs) * nch;
-    uint32_t p = 0, n = 0, creal = 0; // the first record sits right behind the entry count
-    for (uint32_t base = 0; base < nchunk && p != DEAD7; base += FOLLOW_PIECE) {
-        const uint32_t cnt = min(FOLLOW_PIECE, nchunk - base);
-        const uint32_t words = cnt * PH7;
-        const uint32_t *src = maps + static_cast<size_t>(base) * PH7; // 16-byte aligned (base % 4 == 0)
-        for (uint32_t i = tid * 4u; i < words; i += 1024u) {
-            if (i + 4u <= words) {
-                *reinterpret_cast<uint4 *>(&s_map[i]) = *reinterpret_cast<const uint4 *>(&src[i]);
-            } else {
-                for (uint32_t t = i; t < words; t++)
-                    s_map[t] = src[t];
-            }
-        }
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t c = 0;
-            for (; c < cnt && p != DEAD7; c++) {
-                s_entry[c] = p | (n << 8);
-                const uint32_t m = s_map[c * PH7 + p];
-                n += m >> 8;
-                p = n >= R ? DEAD7 : (m & 255u); // all records found: nothing beyond this chunk
-            }
-            s_state[0] = p;
-            s_state[1] = n;
-            s_state[2] = c; // chunks of this piece that hold records
-        }
-        __syncthreads();
-        const uint32_t live = s_state[2];
-        for (uint32_t i = tid; i < live; i += 256u)
-            centry[base + i] = s_entry[i];
-        p = s_state[0];
-        n = s_state[1];
-        creal = base + live;
-        __syncthreads();
-    }
-    if (n < R) {
-        // the chain stopped short of R records: a record crosses `len` -- or the bits stream
-        // runs past the start of the refs stream (non-canonical layout: host re-plans)
-        if (tid == 0)
-            atomicOr(status, (p != DEAD7 && hinted) ? E_LAYOUT : MCRAW_E_TRUNCATED);
-        return;
-    }
-    // Work lists of k7_records: the chunks [0, creal) of this stream, REC_GROUP consecutive chunks
-    // per item (one lane walks each).  A chunk of tiny records (more than DENSE_RECORDS of them) is
-    // listed by pointer doubling in a kernel of its own: it goes to the dense list, which grows
-    // from the back of the same array, and the rest of its group is listed chunk by chunk.
-    if (tid < 4u)
-        s_state[tid] = 0; // [0] dense items of this stream, [1] sparse slots handed out, [2] dense slots handed out, [3] sparse items
-    __syncthreads();
-    const uint32_t ngrp = (creal + REC_GROUP - 1u) / REC_GROUP;
-    auto first_record = [&](uint32_t i) { return i < creal ? min(R, centry[i] >> 8) : R; };
-    for (uint32_t g = tid; g < ngrp; g += 256u) {
-        const uint32_t c0 = g * REC_GROUP, cnt = min(REC_GROUP, creal - c0);
-        uint32_t nd = 0;
-        for (uint32_t j = 0; j < cnt; j++)
-            nd += first_record(c0 + j + 1u) - min(first_record(c0 + j + 1u), centry[c0 + j] >> 8) > DENSE_RECORDS ? 1u : 0u;
-        if (nd) {
-            atomicAdd(&s_state[0], nd);
-            atomicAdd(&s_state[3], cnt - nd);
-        } else {
-            atomicAdd(&s_state[3], 1u);
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const uint32_t nd = s_state[0];
-        s_entry[0] = atomicAdd(W.counters + 1, s_state[3]);
-        s_entry[1] = nd ? atomicAdd(W.counters + 2, nd) : 0u;
-    }
-    __syncthreads();
-    const uint32_t baseS = s_entry[0], baseD = s_entry[1];
-    for (uint32_t g = tid; g < ngrp; g += 256u) {
-        const uint32_t c0 = g * REC_GROUP, cnt = min(REC_GROUP, creal - c0);
-        uint32_t dmask = 0;
-        for (uint32_t j = 0; j < cnt; j++)
-            dmask |= (first_record(c0 + j + 1u) - min(first_record(c0 + j + 1u), centry[c0 + j] >> 8) > DENSE_RECORDS ? 1u : 0u) << j;
-        if (dmask == 0u) {
-            // sparse item: stream, first chunk | chunks << 24, byte offset of the first chunk, end of its record range
-            W.list_recs[baseS + atomicAdd(&s_state[1], 1u)] =
-                make_uint4(fs, c0 | (cnt << 24), si.x + c0 * CH7, first_record(c0 + cnt));
-            continue;
-        }
-        for (uint32_t j = 0; j < cnt; j++) {
-            const uint32_t i = c0 + j, e = centry[i];
-            if ((dmask >> j) & 1u) { // dense item: stream, records in the chunk, its byte offset, entry (phase | first record << 8)
-                const uint32_t nrec = first_record(i + 1u) - min(first_record(i + 1u), e >> 8);
-                W.list_recs[W.list_cap - 1u - (baseD + atomicAdd(&s_state[2], 1u))] = make_uint4(fs, nrec, si.x + i * CH7, e);
-            } else {
-                W.list_recs[baseS + atomicAdd(&s_state[1], 1u)] =
-                    make_uint4(fs, i | (1u << 24), si.x + i * CH7, first_record(i + 1u));
-            }
-        }
-    }
-}
-
-// staged bytes of an item of `chunks` chunks: records starting in the last one may run 130 bytes
-// past it (+ read slack), and the first chunk starts up to 15 bytes into the first 16-byte line
-constexpr int rec_bytes(int chunks) { return (chunks * CH7 + 130 + 8 + 16 + 15) / 16 * 16 + 16; }
-constexpr int REC_MAX = CH7 / 2; // records that can start in one chunk
+// The workgroup of the bits stream also publishes the frame's real geometry (Geo7) from the frame
+// header (RawData.cpp:500-524, 545-554): everything behind it works from the header, not from
+// the caller's width/height.
+constexpr uint32_t SIDE_T = 512;                            // threads per workgroup
+constexpr uint32_t SIDE_LPT = 2;                            // 16-byte lines per thread and piece
+constexpr uint32_t SIDE_PIECE = 16 * SIDE_T * SIDE_LPT;     // stream bytes per piece
+constexpr uint32_t SIDE_XL = 9;                             // lines behind the piece: 130 (reach of its last record) + 8 (read slack) bytes
+constexpr uint32_t SIDE_LCAP = 2048;                        // records listed per round
+static_assert(ITEM_SPLIT == 2, "k7_side sums the block lengths of half a record per item");
+static_assert(SIDE_PIECE + 64 * 130 < 65536, "record positions are listed as 16-bit offsets");
 
 template <int PATTERN>
 __device__ __forceinline__ uint32_t swz_xor(uint32_t v)
@@ -433,268 +168,340 @@ __device__ __forceinline__ uint32_t swz_xor(uint32_t v)
     return static_cast<uint32_t>(__builtin_amdgcn_ds_swizzle(static_cast<int>(v), PATTERN));
 }
 
-// One wave per work item.  Sparse form: REC_GROUP consecutive chunks, lane j walks chunk j from
-// its resolved entry and notes payload offset, class and reference of every record it meets (the
-// record indices of the item are contiguous, so the notes form one flat list).  Dense form: one
-// chunk of tiny records, listed by pointer doubling.  Then EIGHT records are unpacked per pass:
-// lane = (record, k) owns samples 8k..8k+7 exactly like a payload lane (DecodeBlock on the
-// record, RawData.cpp:489; + reference, :491-492).
-template <int ABL, bool DENSE>
-__global__ __launch_bounds__(64) void k7_records(const Work7 W)
+// Workgroup barrier for LDS traffic only: outstanding buffer loads (the prefetched next piece) stay in flight.
+__device__ __forceinline__ void lds_barrier()
 {
-    constexpr int NCHUNK = DENSE ? 1 : static_cast<int>(REC_GROUP);
-    constexpr int REC_BYTES = rec_bytes(NCHUNK);
-    constexpr uint32_t HDR_CAP = DENSE ? REC_MAX : REC_GROUP * DENSE_RECORDS;
-    __shared__ __attribute__((aligned(16))) uint8_t s_b[REC_BYTES];
-    __shared__ uint32_t s_hdr[HDR_CAP + 8]; // per record: payload offset | hbits << 14 | reference << 18
-    __shared__ __attribute__((aligned(16))) uint16_t s_J[DENSE ? CH7 / 2 + 8 : 8]; // successor table of the chunk's candidates
-    __shared__ __attribute__((aligned(8))) uint8_t s_M[DENSE ? CH7 / 2 + 8 : 8];   // chain marks
-    __shared__ uint4 s_tab[72];
-
-    const uint32_t lane = threadIdx.x;
-    s_tab[lane] = reinterpret_cast<const uint4 *>(c_tab7)[lane];
-    if (lane < 8u)
-        s_tab[64u + lane] = reinterpret_cast<const uint4 *>(c_tab7)[64u + lane];
-    const uint32_t nwork = W.counters[DENSE ? 2 : 1];
-    // sparse items are listed from the front of the work list, dense ones from its back
-    const uint4 *list = DENSE ? W.list_recs + (W.list_cap - 1u) : W.list_recs;
-    constexpr int STEP = DENSE ? -1 : 1;
-    uint4 nextw = make_uint4(0, 0, 0, 0);
-    if (blockIdx.x < nwork)
-        nextw = list[STEP * static_cast<int>(blockIdx.x)];
-    for (uint32_t wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
-    const uint4 we = nextw;
-    if (wi + gridDim.x < nwork) // descriptor of the next work item rides behind this one
-        nextw = list[STEP * static_cast<int>(wi + gridDim.x)];
-    const uint32_t fs = __builtin_amdgcn_readfirstlane(we.x);
-    const uint32_t f = fs >> 1, s = fs & 1u;
-    int32_t *status = W.status + f;
-    const Plan7 *P = W.plans + f;
-    const uint32_t R = P->ngroups, nblk = P->nblk;
-    const uint32_t len = P->len;
-    const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
-    const uint32_t abs = __builtin_amdgcn_readfirstlane(we.z);
-    const uint32_t base16 = abs & ~15u, head = abs - base16;
-    // sparse: entries of my chunks, one per lane (issued before the staging loads)
-    const uint32_t first = __builtin_amdgcn_readfirstlane(we.y) & 0xffffffu;
-    const uint32_t nchunk = DENSE ? 1u : __builtin_amdgcn_readfirstlane(we.y) >> 24;
-    uint32_t ce = 0;
-    if (!DENSE && lane < nchunk)
-        ce = W.centry[static_cast<size_t>(fs) * W.nch + first + lane];
-    __syncthreads(); // previous work item is done with the staging buffers
-    const uint32_t n16 = (head + nchunk * CH7 + 130u + 8u + 16u + 15u) >> 4; // <= REC_BYTES / 16
-#pragma unroll
-    for (uint32_t q = 0; q < (REC_BYTES / 16 + 63) / 64; q++)
-        if (lane + 64u * q < n16)
-            reinterpret_cast<uint4 *>(s_b)[lane + 64u * q] = ld_b128(rs, base16 + (lane + 64u * q) * 16u);
-    __syncthreads();
-
-    uint32_t n = 0, i0;
-    if (!DENSE) {
-        // Sparse item: lane j follows chunk j's chain from its true entry up to the first record of
-        // chunk j+1 (the item's end for the last lane) and parses each header (RawData.cpp:106-110).
-        i0 = __builtin_amdgcn_readfirstlane(ce) >> 8;
-        const uint32_t iend = min(R, __builtin_amdgcn_readfirstlane(we.w));
-        n = iend - min(iend, i0);
-        const uint32_t cnext = __shfl_down(ce, 1, 64);
-        if (ABL != 3 && lane < nchunk) {
-            const uint32_t myend = lane + 1u < nchunk ? min(iend, cnext >> 8) : iend;
-            uint32_t rel = 2u * (ce & 255u), idx = ce >> 8;
-            const uint32_t cb = lane * CH7; // my chunk inside the staged bytes
-            while (rel < CH7 && idx < myend) {
-                const uint32_t ro = head + cb + rel;
-                const uint32_t b0 = s_b[ro], b1 = s_b[ro + 1u];
-                const uint32_t nx = rel + 2u + len7_of(b0 >> 4);
-                if (abs + cb + nx > len)
-                    break; // cannot happen for a chunk k7_follow listed
-                s_hdr[idx - i0] = (ro + 2u) | ((b0 >> 4) << 14) | ((((b0 & 15u) << 8) | b1) << 18);
-                rel = nx;
-                idx++;
-            }
-        }
-        if (ABL == 2 || ABL == 3)
-            n = 0;
-    } else {
-    const uint32_t entry = __builtin_amdgcn_readfirstlane(we.w);
-    const uint32_t ph = entry & 255u;
-    i0 = entry >> 8;
-    // Dense chunk (runs of 2-byte records: up to 512 per KiB).  Which of the chunk's 512 even offsets start a record of the true chain?  A serial walk
-    // costs ~45 scalar instructions per record on one lane; instead the chain is marked by
-    // POINTER DOUBLING over all candidates at once: J1[p] = where the record at p ends;
-    // level l marks J_{2^l}(q) for every marked q (marks then cover distance < 2^(l+1) from the
-    // entry) and squares the table; ~6 levels for a typical chunk, 10 at most.
-    constexpr uint32_t NP = CH7 / 2; // candidates; index NP = "beyond this chunk"
-    const uint32_t p0 = lane * 8u;   // this lane owns candidates p0 .. p0+7
-    uint32_t jn[8];
-#pragma unroll
-    for (uint32_t t = 0; t < 8u; t++) {
-        const uint32_t rel = 2u * (p0 + t);
-        const uint32_t nx = rel + 2u + len7_of(static_cast<uint32_t>(s_b[head + rel]) >> 4);
-        jn[t] = (abs + nx > len || nx >= CH7) ? NP : nx >> 1; // a record crossing `len` ends the chain
-    }
-    *reinterpret_cast<uint4 *>(&s_J[p0]) = make_uint4(jn[0] | (jn[1] << 16), jn[2] | (jn[3] << 16), jn[4] | (jn[5] << 16), jn[6] | (jn[7] << 16));
-    *reinterpret_cast<uint2 *>(&s_M[p0]) = make_uint2(0u, 0u);
-    if (lane == 0)
-        s_J[NP] = static_cast<uint16_t>(NP);
-    __syncthreads();
-    if (lane == 0 && ABL != 3)
-        s_M[ph] = 1; // entry phase = candidate index (offset 2 * ph)
-    __syncthreads();
-    uint2 m = *reinterpret_cast<const uint2 *>(&s_M[p0]);
-    for (uint32_t level = 0; level < 10u; level++) {
-#pragma unroll
-        for (uint32_t t = 0; t < 8u; t++) {
-            const uint32_t mk = ((t < 4u ? m.x : m.y) >> (8u * (t & 3u))) & 1u;
-            s_M[mk ? jn[t] : NP + 1u] = 1; // branch-free: unmarked candidates hit a dummy slot (NP, NP+1 are never read as marks)
-        }
-        __syncthreads();
-        const uint2 m2 = *reinterpret_cast<const uint2 *>(&s_M[p0]);
-        const bool grew = __any((m2.x != m.x) || (m2.y != m.y));
-        m = m2;
-        if (!grew)
-            break;
-        uint32_t sq[8];
-#pragma unroll
-        for (uint32_t t = 0; t < 8u; t++)
-            sq[t] = s_J[jn[t]];
-        __syncthreads();
-#pragma unroll
-        for (uint32_t t = 0; t < 8u; t++)
-            jn[t] = sq[t];
-        *reinterpret_cast<uint4 *>(&s_J[p0]) = make_uint4(jn[0] | (jn[1] << 16), jn[2] | (jn[3] << 16), jn[4] | (jn[5] << 16), jn[6] | (jn[7] << 16));
-        __syncthreads();
-    }
-    // rank of every marked candidate = its record index inside the chunk (candidates are in stream order)
-    const uint32_t mine = static_cast<uint32_t>(__popc(m.x) + __popc(m.y));
-    uint32_t ntot;
-    const uint32_t rank0 = wave_excl_scan(mine, lane, &ntot);
-    n = min(ntot, R - i0);
-    if (ABL == 2 || ABL == 3)
-        n = 0;
-    // payload offset, class and reference of each record (RawData.cpp:106-110)
-    uint32_t rk = rank0;
-#pragma unroll
-    for (uint32_t t = 0; t < 8u; t++) {
-        const uint32_t mk = ((t < 4u ? m.x : m.y) >> (8u * (t & 3u))) & 1u;
-        if (mk) {
-            if (rk < n) {
-                const uint32_t ro = head + 2u * (p0 + t);
-                const uint32_t b0 = s_b[ro], b1 = s_b[ro + 1u];
-                s_hdr[rk] = (ro + 2u) | ((b0 >> 4) << 14) | ((((b0 & 15u) << 8) | b1) << 18);
-            }
-            rk++;
-        }
-    }
-    }
-    if (lane < 8u)
-        s_hdr[n + lane] = 0u; // padding: idle lanes of the last pass unpack "class 0"
-    __syncthreads();
-
-    const uint32_t k = lane & 7u, sub = lane >> 3;
-    uint8_t *bits = W.bits + static_cast<size_t>(f) * W.Rmax * 64u;
-    uint16_t *refs = W.refs + static_cast<size_t>(f) * W.Rmax * 64u;
-    uint32_t *glen = W.grp_off + static_cast<size_t>(f) * (W.Rmax * ITEM_SPLIT + 1u);
-    for (uint32_t qb = 0; qb < (ABL == 1 ? 0u : n); qb += 8u) {
-        const uint32_t q = qb + sub;
-        const bool live = q < n;
-        const uint32_t h = s_hdr[q];
-        const uint32_t hb = (h >> 14) & 15u, ref = h >> 18;
-        Unpacked U = unpack8<false>(s_b, h & 0x3fffu, cls7_of(hb), k, s_tab);
-        const u16x2 rr = __builtin_bit_cast(u16x2, ref | (ref << 16));
-#pragma unroll
-        for (int i = 0; i < 4; i++) // uint16 wrap (RawData.cpp:492)
-            U.x[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, U.x[i]) + rr);
-        const uint32_t r = i0 + q;
-        const uint32_t idx = r * 64u + 8u * k;
-        if (s == 1u) {
-            if (live)
-                *reinterpret_cast<uint4 *>(refs + idx) = make_uint4(U.x[0], U.x[1], U.x[2], U.x[3]);
-            continue;
-        }
-        // bits stream: validate, narrow to bytes, and add up the byte length of the lane's 8 blocks
-        const uint32_t nvalid = live ? min(8u, nblk - min(nblk, idx)) : 0u;
-        if (nvalid < 8u) { // the record's entries past the last block are decoded by the reference but never used
-#pragma unroll
-            for (uint32_t i = 0; i < 4u; i++)
-                U.x[i] &= nvalid >= 2u * i + 2u ? 0xffffffffu : nvalid == 2u * i + 1u ? 0xffffu : 0u;
-        }
-        uint32_t c[4], over = 0;
-#pragma unroll
-        for (uint32_t i = 0; i < 4u; i++) { // an entry above 16 would index past ENCODING_BLOCK_LENGTH (RawData.cpp:419)
-            c[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, U.x[i]),
-                                                                          __builtin_bit_cast(u16x2, 0x00100010u)));
-            over |= c[i] ^ U.x[i];
-        }
-        if (over)
-            atomicOr(status, MCRAW_E_SIDESTREAM);
-        const uint32_t bytes_lo = __builtin_amdgcn_perm(c[1], c[0], 0x06040200u);
-        const uint32_t bytes_hi = __builtin_amdgcn_perm(c[3], c[2], 0x06040200u);
-        if (live)
-            *reinterpret_cast<uint2 *>(bits + idx) = make_uint2(bytes_lo, bytes_hi);
-        // LEN[v] / 8 for four entries at a time (RawData.cpp:27-45): two 8-entry byte tables picked by
-        // bit 3, 16 for v == 16; then a byte sum
-        uint32_t l8 = 0;
-#pragma unroll
-        for (uint32_t i = 0; i < 2u; i++) {
-            const uint32_t v4 = i ? bytes_hi : bytes_lo;
-            const uint32_t sel = v4 & 0x07070707u;
-            const uint32_t lo = __builtin_amdgcn_perm(0x08060504u, 0x03020100u, sel); // v = 0..7
-            const uint32_t hi = __builtin_amdgcn_perm(0x10101010u, 0x100A0A08u, sel); // v = 8..15
-            const uint32_t g = (v4 >> 3) & 0x01010101u;
-            const uint32_t m = (g << 8) - g;
-            const uint32_t l4 = ((hi & m) | (lo & ~m)) | (v4 & 0x10101010u);
-            l8 = __builtin_amdgcn_sad_u8(l4, 0u, l8);
-        }
-        // sum over the lanes of one decode item (ds_swizzle bit-mask mode: lane ^ 1, ^ 2, ^ 4)
-        l8 += swz_xor<0x041F>(l8);
-        l8 += swz_xor<0x081F>(l8);
-        if (ITEM_SPLIT == 1)
-            l8 += swz_xor<0x101F>(l8);
-        if (live && (k & (8u / ITEM_SPLIT - 1u)) == 0u)
-            glen[r * ITEM_SPLIT + k / (8u / ITEM_SPLIT)] = l8 << 3; // lengths until k7_scan turns them into offsets
-    }
-    } // work items
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// ------------------------------------------------------------------ k7_scan
-//
-// Payload offset of every group: 16 + sum of the lengths before it
-// (RawData.cpp:562 `offset = METADATA_OFFSET`, :576-579 `offset += ...`).
-__global__ __launch_bounds__(1024) void k7_scan(const Work7 W)
+#ifdef MCRAW_DIAG // phase stamps of one workgroup (timing experiments only; not in the product library)
+__device__ unsigned long long g_side_prof[16];
+#define SIDE_STAMP(slot)                                                                                               \
+    do {                                                                                                               \
+        if (blockIdx.x == 1u && tid == 64u) {                                                                          \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                              \
+            g_side_prof[slot] += now_ - stamp_;                                                                        \
+            stamp_ = now_;                                                                                             \
+        }                                                                                                              \
+    } while (0)
+#else
+#define SIDE_STAMP(slot)
+#endif
+
+__global__ __launch_bounds__(SIDE_T) void k7_side(const Work7 W)
 {
-    __shared__ uint32_t s_w[16];
-    const Plan7 *P = W.plans + blockIdx.x;
-    int32_t *status = W.status + blockIdx.x;
-    if (*status != 0)
-        return;
-    const uint32_t R = P->ngroups * ITEM_SPLIT, tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-    uint32_t *__restrict__ g = W.grp_off + static_cast<size_t>(blockIdx.x) * (W.Rmax * ITEM_SPLIT + 1u);
-    uint32_t carry = 16u;
-    for (uint32_t base = 0; base < R; base += 1024u) {
-        const uint32_t i = base + tid;
-        const uint32_t v = i < R ? g[i] : 0u;
-        uint32_t wtot;
-        const uint32_t ex = wave_excl_scan(v, lane, &wtot);
-        if (lane == 63u)
-            s_w[w] = wtot;
-        __syncthreads();
-        uint32_t before = 0, total = 0;
-#pragma unroll
-        for (uint32_t q = 0; q < 16u; q++) {
-            const uint32_t x = s_w[q];
-            before += q < w ? x : 0u;
-            total += x;
+    __shared__ __attribute__((aligned(16))) uint8_t s_b[SIDE_PIECE + SIDE_XL * 16 + 16];
+    __shared__ __attribute__((aligned(16))) uint16_t s_L[SIDE_LCAP];
+    __shared__ __attribute__((aligned(16))) uint16_t s_len[2 * SIDE_LCAP];
+    __shared__ uint4 s_tab[72];
+    __shared__ uint32_t s_st[4];
+    __shared__ uint32_t s_w[SIDE_T / 64];
+
+    const uint32_t fs = blockIdx.x, f = fs >> 1, s = fs & 1u;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < 72u)
+        s_tab[tid] = reinterpret_cast<const uint4 *>(c_tab7)[tid];
+
+    const Plan7 *P = W.plans + f;
+    int32_t *status = W.status + f;
+    const uint32_t len = P->len;
+    const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
+
+    // ---- frame header (RawData.cpp:500-524) and its checks (:547-554)
+    const uint4 hv = ld_b128(rs, 0); // zeros when len < 16
+    const uint32_t encW = __builtin_amdgcn_readfirstlane(hv.x), encH = __builtin_amdgcn_readfirstlane(hv.y);
+    const uint32_t bitsOff = __builtin_amdgcn_readfirstlane(hv.z), refsOff = __builtin_amdgcn_readfirstlane(hv.w);
+    const uint32_t so = s ? refsOff : bitsOff;
+    int32_t err = 0;
+    uint32_t tilesX = 0, nblk = 0, R = 0;
+    if (len < 16u || bitsOff > len || refsOff > len || (encW & 63u) != 0u || encW < static_cast<uint32_t>(P->width) ||
+        encW == 0u || encH == 0u || (encH & 3u) != 0u ||
+        static_cast<uint64_t>(encW) * encH >= (1ull << 31)) {
+        err = MCRAW_E_HEADER; // RawData.cpp:547-554 returns 0
+    } else {
+        tilesX = encW >> 6;
+        nblk = 4u * tilesX * (encH >> 2);
+        R = (nblk + GROUP_BLOCKS - 1u) / GROUP_BLOCKS;
+        // The workspace and the k7_tiles grid were sized from the geometry the host planned with; a frame
+        // coded larger than that is planned again from its real header by the host.
+        if (R > P->ngroups)
+            err = E_GEOMETRY;
+        else if (so + 4u > len || so + 4u < so)
+            err = MCRAW_E_TRUNCATED;
+        else {
+            const uint32_t count = ld_u8(rs, so) | (ld_u8(rs, so + 1u) << 8) | (ld_u8(rs, so + 2u) << 16) |
+                                   (ld_u8(rs, so + 3u) << 24);
+            if (__builtin_amdgcn_readfirstlane(count) < nblk) // the reference would index past the vector (:573-574)
+                err = MCRAW_E_SIDESTREAM;
         }
-        if (i < R)
-            g[i] = carry + before + ex;
-        carry += total;
-        __syncthreads();
     }
-    if (tid == 0) {
-        g[R] = carry;
-        if (carry > P->len) // some block crosses `len` (RawData.cpp:419-420)
-            atomicOr(status, MCRAW_E_TRUNCATED);
+    if (s == 0u && tid == 0u) {
+        const uint32_t rows = min(static_cast<uint32_t>(P->height), encH);
+        W.geo[f] = make_uint4(tilesX, err == MCRAW_E_HEADER ? 0u : nblk, rows, encH);
+        W.status[W.nstatus + f] = static_cast<int32_t>(encH); // read back with the statuses (rows written = min(height, encH))
     }
+    if (err) {
+        if (tid == 0u)
+            atomicOr(status, err);
+        return;
+    }
+
+    uint8_t *bits = W.bits + static_cast<size_t>(f) * W.Rmax * 64u;
+    uint16_t *refs = W.refs + static_cast<size_t>(f) * W.Rmax * 64u;
+    uint32_t *goff = W.grp_off + static_cast<size_t>(f) * (W.Rmax * ITEM_SPLIT + 1u);
+
+    // ---- pieces: s_b[x] holds frame byte A + x; A is 16-byte aligned (relative to the frame buffer: the
+    // bounds check of the buffer loads works on whole dwords), the first record sits behind the 4-byte count
+    uint64_t A = (static_cast<uint64_t>(so) + 4u) & ~15ull;
+    uint32_t n = 0;                 // records done
+    uint32_t p = (so + 4u) & 15u;   // where the chain stands, relative to A
+    uint32_t S = 0;        // stride of the record at p when already known, else 0
+    uint64_t carry = 16u;  // payload offset of the next item (RawData.cpp:562)
+    int32_t lane_err = 0;  // per lane (a bits entry above 16)
+    bool dead = false;     // uniform: the chain ended before R records
+
+    auto fetch = [&](uint64_t base, uint32_t line) -> uint4 {
+        const uint64_t o = base + 16ull * line;
+        return o < len ? ld_b128(rs, static_cast<uint32_t>(o)) : make_uint4(0, 0, 0, 0);
+    };
+    uint4 v[SIDE_LPT], vx = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (uint32_t j = 0; j < SIDE_LPT; j++)
+        v[j] = fetch(A, tid + SIDE_T * j);
+    if (tid < SIDE_XL)
+        vx = fetch(A, SIDE_T * SIDE_LPT + tid);
+
+    const uint32_t k = lane & 7u, sub = lane >> 3;
+#ifdef MCRAW_DIAG
+    unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+#endif
+    while (true) {
+        lds_barrier(); // the previous piece's readers are done
+        SIDE_STAMP(0);
+#pragma unroll
+        for (uint32_t j = 0; j < SIDE_LPT; j++)
+            reinterpret_cast<uint4 *>(s_b)[tid + SIDE_T * j] = v[j];
+        if (tid < SIDE_XL)
+            reinterpret_cast<uint4 *>(s_b)[SIDE_T * SIDE_LPT + tid] = vx;
+        // next piece on its way
+        const uint64_t An = A + SIDE_PIECE;
+#pragma unroll
+        for (uint32_t j = 0; j < SIDE_LPT; j++)
+            v[j] = fetch(An, tid + SIDE_T * j);
+        if (tid < SIDE_XL)
+            vx = fetch(An, SIDE_T * SIDE_LPT + tid);
+        lds_barrier();
+        SIDE_STAMP(1);
+
+        // rounds over the piece: at most SIDE_LCAP records are listed at a time
+        while (true) {
+            if (wave == 0u) {
+                // run speculation: lane j looks at p + j * S.  `code` of a lane: 0 = behind the piece, 1 = a record
+                // that crosses `len` (RawData.cpp:419-420), else the stride of the record that starts there.
+                const uint32_t room = min(R - n, SIDE_LCAP);
+                const uint64_t left = len - min(static_cast<uint64_t>(len), A);
+                const uint32_t lim = static_cast<uint32_t>(min(left, static_cast<uint64_t>(1u << 30))); // frame bytes from A on
+                uint32_t cnt = 0, why = 0; // why: 1 list full / stream complete, 2 behind the piece, 3 chain dead
+                uint32_t pp = p, SS = S;   // scalar copies
+                auto code_at = [&](uint32_t q) -> uint32_t {
+                    const bool inb = q < SIDE_PIECE; // a record that starts in the piece has all its bytes staged
+                    const uint32_t hb = static_cast<uint32_t>(s_b[inb ? q : 0u]) >> 4;
+                    // LEN / 8 (RawData.cpp:27-45): nibble table for hbits 0..10, 16 above
+                    const uint32_t l8 = hb > 10u ? 16u : static_cast<uint32_t>(0xAA886543210ull >> (4u * hb)) & 15u;
+                    const uint32_t Sj = 2u + 8u * l8;
+                    return inb ? (q + Sj <= lim ? Sj : 1u) : 0u;
+                };
+                while (true) {
+                    if (pp >= SIDE_PIECE) {
+                        SS = 0u;
+                        why = 2u;
+                        break;
+                    }
+                    if (SS == 0u) {
+                        SS = __builtin_amdgcn_readfirstlane(code_at(pp));
+                        if (SS == 1u) {
+                            SS = 0u;
+                            why = 3u;
+                            break;
+                        }
+                    }
+                    const uint32_t q = pp + lane * SS;
+                    const uint32_t code = code_at(q);
+                    const unsigned long long m = __ballot(code == SS);
+                    const uint32_t nb = m == ~0ull ? 64u : static_cast<uint32_t>(__builtin_ctzll(~m)); // >= 1
+                    const uint32_t take = min(nb, room - cnt);
+                    if (lane < take)
+                        s_L[cnt + lane] = static_cast<uint16_t>(q);
+                    cnt += take;
+                    pp += take * SS;
+                    if (take < nb) { // list full / stream complete inside the run: pp is a record of stride SS
+                        why = 1u;
+                        break;
+                    }
+                    if (cnt == room) { // ... at the end of the run: what follows has not been looked at
+                        SS = 0u;
+                        why = 1u;
+                        break;
+                    }
+                    if (nb == 64u)
+                        continue; // the run goes on, same stride
+                    // lane nb: the record behind the run, if it is one
+                    SS = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(code), static_cast<int>(nb)));
+                    if (SS == 0u) {
+                        why = 2u;
+                        break;
+                    }
+                    if (SS == 1u) {
+                        SS = 0u;
+                        why = 3u;
+                        break;
+                    }
+                }
+                if (lane == 0u) {
+                    s_st[0] = pp;
+                    s_st[1] = cnt;
+                    s_st[2] = why;
+                    s_st[3] = SS;
+                }
+            }
+            lds_barrier();
+            SIDE_STAMP(2);
+            p = __builtin_amdgcn_readfirstlane(s_st[0]);
+            const uint32_t total = __builtin_amdgcn_readfirstlane(s_st[1]);
+            const uint32_t why = __builtin_amdgcn_readfirstlane(s_st[2]);
+            S = __builtin_amdgcn_readfirstlane(s_st[3]);
+
+            // record decode: lane = (record, k) owns samples 8k..8k+7
+            for (uint32_t qb = wave * 8u; qb < total; qb += (SIDE_T / 64u) * 8u) {
+                const uint32_t q = qb + sub;
+                const bool live = q < total;
+                const uint32_t ro = live ? s_L[q] : 0u;
+                const uint32_t b0 = live ? s_b[ro] : 0u, b1 = s_b[ro + 1u];
+                const uint32_t hb = b0 >> 4, ref = ((b0 & 15u) << 8) | b1; // RawData.cpp:106-110
+                Unpacked U = unpack8<false>(s_b, ro + 2u, cls7_of(hb), k, s_tab);
+                const u16x2 rr = __builtin_bit_cast(u16x2, ref | (ref << 16));
+#pragma unroll
+                for (int i = 0; i < 4; i++) // uint16 wrap (RawData.cpp:492)
+                    U.x[i] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, U.x[i]) + rr);
+                const uint32_t r = n + q;
+                const uint32_t idx = r * 64u + 8u * k;
+                if (s == 1u) {
+                    if (live)
+                        *reinterpret_cast<uint4 *>(refs + idx) = make_uint4(U.x[0], U.x[1], U.x[2], U.x[3]);
+                    continue;
+                }
+                // bits stream: validate, narrow to bytes, and add up the byte length of the lane's 8 blocks
+                const uint32_t nvalid = live ? min(8u, nblk - min(nblk, idx)) : 0u;
+                if (nvalid < 8u) { // the record's entries past the last block are decoded by the reference but never used
+#pragma unroll
+                    for (uint32_t i = 0; i < 4u; i++)
+                        U.x[i] &= nvalid >= 2u * i + 2u ? 0xffffffffu : nvalid == 2u * i + 1u ? 0xffffu : 0u;
+                }
+                uint32_t c[4], over = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; i++) { // an entry above 16 would index past ENCODING_BLOCK_LENGTH (RawData.cpp:419)
+                    c[i] = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, U.x[i]),
+                                                                                  __builtin_bit_cast(u16x2, 0x00100010u)));
+                    over |= c[i] ^ U.x[i];
+                }
+                if (over)
+                    lane_err |= MCRAW_E_SIDESTREAM;
+                const uint32_t bytes_lo = __builtin_amdgcn_perm(c[1], c[0], 0x06040200u);
+                const uint32_t bytes_hi = __builtin_amdgcn_perm(c[3], c[2], 0x06040200u);
+                if (live)
+                    *reinterpret_cast<uint2 *>(bits + idx) = make_uint2(bytes_lo, bytes_hi);
+                // LEN[v] / 8 for four entries at a time (RawData.cpp:27-45): two 8-entry byte tables picked by
+                // bit 3, 16 for v == 16; then a byte sum
+                uint32_t l8 = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < 2u; i++) {
+                    const uint32_t v4 = i ? bytes_hi : bytes_lo;
+                    const uint32_t sel = v4 & 0x07070707u;
+                    const uint32_t lo = __builtin_amdgcn_perm(0x08060504u, 0x03020100u, sel); // v = 0..7
+                    const uint32_t hi = __builtin_amdgcn_perm(0x10101010u, 0x100A0A08u, sel); // v = 8..15
+                    const uint32_t g = (v4 >> 3) & 0x01010101u;
+                    const uint32_t m = (g << 8) - g;
+                    const uint32_t l4 = ((hi & m) | (lo & ~m)) | (v4 & 0x10101010u);
+                    l8 = __builtin_amdgcn_sad_u8(l4, 0u, l8);
+                }
+                // sum over the four lanes of one decode item (ds_swizzle bit-mask mode: lane ^ 1, ^ 2)
+                l8 += swz_xor<0x041F>(l8);
+                l8 += swz_xor<0x081F>(l8);
+                if (live && (k & 3u) == 0u)
+                    s_len[2u * q + (k >> 2)] = static_cast<uint16_t>(l8 << 3); // <= 32 * 128 bytes
+            }
+            SIDE_STAMP(3);
+
+            if (s == 0u) {
+                // item lengths -> payload offsets: exclusive scan over the round, eight items per thread
+                lds_barrier();
+                constexpr uint32_t IPT = 2u * SIDE_LCAP / SIDE_T;
+                static_assert(IPT == 8u, "one 16-byte read of item lengths per thread");
+                const uint32_t nitems = 2u * total;
+                const uint32_t i0 = IPT * tid;
+                uint4 lv = make_uint4(0u, 0u, 0u, 0u);
+                if (i0 < nitems)
+                    lv = *reinterpret_cast<const uint4 *>(&s_len[i0]);
+                uint32_t a[IPT] = {lv.x & 0xffffu, lv.x >> 16, lv.y & 0xffffu, lv.y >> 16,
+                                   lv.z & 0xffffu, lv.z >> 16, lv.w & 0xffffu, lv.w >> 16};
+                uint32_t mine = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < IPT; i++) {
+                    a[i] = i0 + i < nitems ? a[i] : 0u;
+                    mine += a[i];
+                }
+                uint32_t wtot;
+                const uint32_t ex = wave_excl_scan(mine, lane, &wtot);
+                if (lane == 63u)
+                    s_w[wave] = wtot;
+                lds_barrier();
+                uint32_t before = 0, rtot = 0;
+#pragma unroll
+                for (uint32_t q = 0; q < SIDE_T / 64u; q++) {
+                    const uint32_t x = s_w[q];
+                    before += q < wave ? x : 0u;
+                    rtot += x;
+                }
+                // offsets past 2^32 only occur in frames that fail the `len` check below
+                uint32_t o = static_cast<uint32_t>(carry) + before + ex;
+#pragma unroll
+                for (uint32_t i = 0; i < IPT; i++) {
+                    if (i0 + i < nitems)
+                        goff[2u * n + i0 + i] = o;
+                    o += a[i];
+                }
+                carry += rtot;
+                SIDE_STAMP(4);
+            }
+
+            n += total;
+            if (n >= R)
+                break;
+            if (why == 3u) { // a record crosses `len` before the stream has its R records
+                dead = true;
+                break;
+            }
+            if (why == 2u)
+                break;     // the chain left the piece
+            lds_barrier(); // list full: the next round overwrites it
+        }
+        if (n >= R || dead)
+            break;
+        p -= SIDE_PIECE;
+        A = An;
+    }
+    if (tid == 0u) {
+        if (dead) // RawData.cpp:419-420
+            lane_err |= MCRAW_E_TRUNCATED;
+        if (s == 0u && !dead) {
+            goff[ITEM_SPLIT * R] = static_cast<uint32_t>(min(carry, static_cast<uint64_t>(0xffffffffu)));
+            if (carry > len) // some block crosses `len` (RawData.cpp:419-420)
+                lane_err |= MCRAW_E_TRUNCATED;
+        }
+    }
+    if (lane_err)
+        atomicOr(status, lane_err);
 }
 
 // ------------------------------------------------------------------ k7_tiles
@@ -732,17 +539,22 @@ __device__ __forceinline__ ItemS item_scalars(const Work7 &W, uint32_t item, uin
     const uint32_t f = first_frame + fc;
     const uint32_t g = item - fc * cper;
     const Plan7 *P = W.plans + f;
+    const uint4 geo = W.geo[f]; // the frame's real geometry, from its header (k7_side): tilesX, blocks, rows kept, encH
     const uint32_t *grp = W.grp_off + static_cast<size_t>(f) * (per + 1u) + g;
-    const uint32_t start = grp[0], end = grp[1];
-    I.valid = (g * ITEM_BLOCKS < P->nblk && W.status[f] == 0) ? 1u : 0u;
+    I.valid = (g * ITEM_BLOCKS < geo.y && W.status[f] == 0) ? 1u : 0u;
+    uint32_t start = 0, end = 0;
+    if (I.valid) {
+        start = grp[0];
+        end = grp[1];
+    }
     I.g = g;
-    I.nblk = P->nblk;
-    I.tilesX = P->tilesX;
+    I.nblk = geo.y;
+    I.tilesX = geo.x;
     I.base16 = start & ~15u;
     I.head = start - I.base16;
     I.n16 = I.valid ? min((end - I.base16 + 15u) >> 4, PAY_CHUNKS) : 0u; // never more than ITEM_SPAN + head
     I.width = P->width;
-    I.rows = P->rows;
+    I.rows = static_cast<int32_t>(geo.z);
     I.fast = P->fast_store;
     I.in = P->in;
     I.len = P->len;
@@ -917,55 +729,24 @@ __global__ __launch_bounds__(256) void k7_tiles(const Work7 W, uint32_t total, u
 
 // ------------------------------------------------------------------ launchers
 
-// Grid of a persistent kernel: as many workgroups as the device keeps resident.
-static uint32_t persistent_grid(int which)
+#ifdef MCRAW_DIAG
+extern "C" void mcraw_diag_side_prof(unsigned long long *out, int reset)
 {
-    static uint32_t g[2] = {0, 0};
-    if (!g[which]) {
-        int dev = 0, cus = 256, per_cu = 0;
-        hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
-            cus = p.multiProcessorCount;
-        hipError_t e = which == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k7_maps, 256, 0)
-                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k7_records<0, false>, 64, 0);
-        if (e != hipSuccess || per_cu <= 0)
-            per_cu = which == 0 ? 8 : 16;
-        g[which] = static_cast<uint32_t>(cus * per_cu);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_side_prof), sizeof(g_side_prof));
+    if (reset) {
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_side_prof), z, sizeof(z));
     }
-    return g[which];
 }
+#endif
 
 void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st)
 {
     const uint32_t n7 = static_cast<uint32_t>(W.n7);
     switch (stage) {
-    case MCRAW_K7_WALK:
-        hipLaunchKernelGGL(k7_hdr, dim3(2 * n7), dim3(64), 0, st, W);
-        hipLaunchKernelGGL(k7_maps, dim3(persistent_grid(0)), dim3(256), 0, st, W);
-        hipLaunchKernelGGL(k7_follow, dim3(2 * n7), dim3(256), 0, st, W);
-        break;
-    case MCRAW_K7_META: {
-        const dim3 g(persistent_grid(1));
-#ifdef MCRAW_DIAG // timing experiments (tools/abl7.sh builds with -DMCRAW_DIAG); not in the product library
-        static const int abl = []() {
-            const char *e = std::getenv("MCRAW_ABLATE_REC");
-            return e ? std::atoi(e) : 0;
-        }();
-        if (abl == 1)
-            hipLaunchKernelGGL((k7_records<1, false>), g, dim3(64), 0, st, W);
-        else if (abl == 2)
-            hipLaunchKernelGGL((k7_records<2, false>), g, dim3(64), 0, st, W);
-        else if (abl == 3)
-            hipLaunchKernelGGL((k7_records<3, false>), g, dim3(64), 0, st, W);
-        else
-#endif
-            hipLaunchKernelGGL((k7_records<0, false>), g, dim3(64), 0, st, W);
-        // chunks made of runs of tiny records (flat image regions): usually none
-        hipLaunchKernelGGL((k7_records<0, true>), dim3(2048), dim3(64), 0, st, W);
-        break;
-    }
-    case MCRAW_K7_SCAN:
-        hipLaunchKernelGGL(k7_scan, dim3(n7), dim3(1024), 0, st, W);
+    case MCRAW_K7_SIDE:
+        hipLaunchKernelGGL(k7_side, dim3(2 * n7), dim3(SIDE_T), 0, st, W);
         break;
     case MCRAW_K7_TILES: {
 #ifdef MCRAW_DIAG // timing experiments of the same kernel (see item_decode); not in the product library
