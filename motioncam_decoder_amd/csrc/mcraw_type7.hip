@@ -136,31 +136,43 @@ __device__ __forceinline__ Unpacked unpack8(const uint8_t *__restrict__ base, ui
 // and (bits stream) turns the block lengths into payload offsets -- no hand-off between
 // workgroups, one launch for everything in front of k7_tiles.
 //
-// The stream is taken through LDS in PIECES of 16 KiB (the next piece is already on its way from
-// HBM while this one is worked on).  Per piece:
-//   1. chain walk by RUN SPECULATION (one wave): the record at p has stride S; lane j reads the
-//      header that would sit at p + j*S.  All lanes up to the first one that finds another stride
-//      (or the end of the piece, or a record that crosses `len`, RawData.cpp:419-420) ARE records --
-//      each is where its predecessor ends -- and that first other lane is the next record, its
-//      stride already in hand.  One LDS gather per run of equally long records instead of one
-//      dependent read per record: coded frames are made of long runs (a few dozen to ~130 steps
-//      per UHD stream of 2 025 records; one per record when two sizes alternate at random).
-//      Exact for any content: nothing is assumed, lanes only confirm.
-//   2. record decode: eight records per wave and pass are unpacked like payload blocks (DecodeBlock
-//      on the record, RawData.cpp:489; + reference, :491-492) -> refs[] (u16) / bits[] (u8, validated);
-//   3. bits stream: byte length of every decode item, exclusive scan over the workgroup plus the
+// The stream is taken through LDS in PIECES of 32 KiB (the next two pieces are in registers / on
+// their way from HBM meanwhile).  Per piece:
+//   B  build: the bytes go to LDS together with a STRIDE TABLE: every second byte is a candidate
+//      record start; each thread turns its 16-byte lines into strides (byte-parallel table lookups,
+//      in 2-byte units: 1 + LEN/2, RawData.cpp:27-45; 0 = the record would cross `len`, :419-420).
+//   W  chain walk by RUN SPECULATION (wave 0): the record at p has stride S; lane j looks up the
+//      stride of the candidate at p + j*S.  All lanes up to the first one that finds another stride
+//      ARE records -- each is where its predecessor ends -- and that first other lane is the next
+//      record, its stride already in hand.  One LDS gather per run of equally long records instead
+//      of one dependent read per record: coded frames are made of long runs (~100 steps per UHD
+//      stream of 2 025 records; one step per record at worst).  Exact for any content: nothing is
+//      assumed, lanes only confirm.
+//   D  record decode (waves 1..7, WHILE wave 0 walks the next piece): eight records per wave and
+//      pass are unpacked like payload blocks (DecodeBlock on the record, RawData.cpp:489; +
+//      reference, :491-492) -> refs[] (u16) / bits[] (u8, validated);
+//   S  bits stream: byte length of every decode item, exclusive scan over the workgroup plus the
 //      running carry -> payload offset of every item (RawData.cpp:562, :576-579).
 //
 // The workgroup of the bits stream also publishes the frame's real geometry (Geo7) from the frame
 // header (RawData.cpp:500-524, 545-554): everything behind it works from the header, not from
 // the caller's width/height.
 constexpr uint32_t SIDE_T = 512;                            // threads per workgroup
-constexpr uint32_t SIDE_LPT = 2;                            // 16-byte lines per thread and piece
+#ifndef MCRAW_SIDE_LPT
+#define MCRAW_SIDE_LPT 4
+#endif
+#ifndef MCRAW_SIDE_LCAP
+#define MCRAW_SIDE_LCAP 512
+#endif
+constexpr uint32_t SIDE_LPT = MCRAW_SIDE_LPT;               // 16-byte lines per thread and piece
 constexpr uint32_t SIDE_PIECE = 16 * SIDE_T * SIDE_LPT;     // stream bytes per piece
+constexpr uint32_t SIDE_HALF = SIDE_PIECE / 2;              // candidate positions per piece (2 bytes apart)
 constexpr uint32_t SIDE_XL = 9;                             // lines behind the piece: 130 (reach of its last record) + 8 (read slack) bytes
-constexpr uint32_t SIDE_LCAP = 2048;                        // records listed per round
+constexpr uint32_t SIDE_BYTES = SIDE_PIECE + SIDE_XL * 16 + 16;
+constexpr uint32_t SIDE_LCAP = MCRAW_SIDE_LCAP;              // records per UNIT of the walk / decode pipeline
+constexpr uint32_t SIDE_OUT = 0xFFu;                        // stride table: "behind the piece"
+constexpr uint32_t SIDE_DEAD = 0xFEu;                       // stride table: a record here would cross `len`
 static_assert(ITEM_SPLIT == 2, "k7_side sums the block lengths of half a record per item");
-static_assert(SIDE_PIECE + 64 * 130 < 65536, "record positions are listed as 16-bit offsets");
 
 template <int PATTERN>
 __device__ __forceinline__ uint32_t swz_xor(uint32_t v)
@@ -168,19 +180,41 @@ __device__ __forceinline__ uint32_t swz_xor(uint32_t v)
     return static_cast<uint32_t>(__builtin_amdgcn_ds_swizzle(static_cast<int>(v), PATTERN));
 }
 
-// Workgroup barrier for LDS traffic only: outstanding buffer loads (the prefetched next piece) stay in flight.
+// Workgroup barrier for LDS traffic only: outstanding buffer loads (the prefetched piece) stay in flight.
 __device__ __forceinline__ void lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// 8 candidate record starts of one 16-byte line -> 8 strides in 2-byte units (1 + LEN/2), one byte each.
+__device__ __forceinline__ uint2 side_strides(const uint4 v, uint32_t odd)
+{
+    const uint32_t pick = odd ? 0x07050301u : 0x06040200u; // header bytes sit at every second byte
+    uint32_t st[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const uint32_t h4 = i ? __builtin_amdgcn_perm(v.w, v.z, pick) : __builtin_amdgcn_perm(v.y, v.x, pick);
+        const uint32_t hb = (h4 >> 4) & 0x0F0F0F0Fu;
+        const uint32_t sel = hb & 0x07070707u;
+        const uint32_t lo = __builtin_amdgcn_perm(0x08060504u, 0x03020100u, sel); // LEN/8, hbits 0..7
+        const uint32_t hi = __builtin_amdgcn_perm(0x10101010u, 0x100A0A08u, sel); // LEN/8, hbits 8..15
+        const uint32_t g = (hb >> 3) & 0x01010101u;
+        const uint32_t m = (g << 8) - g;
+        st[i] = (((hi & m) | (lo & ~m)) << 2) + 0x01010101u;
+    }
+    return make_uint2(st[0], st[1]);
+}
+
 #ifdef MCRAW_DIAG // phase stamps of one workgroup (timing experiments only; not in the product library)
-__device__ unsigned long long g_side_prof[16];
+#ifndef SIDE_PROF_BLOCK
+#define SIDE_PROF_BLOCK 1u
+#endif
+__device__ unsigned long long g_side_prof[32];
 #define SIDE_STAMP(slot)                                                                                               \
     do {                                                                                                               \
-        if (blockIdx.x == 1u && tid == 64u) {                                                                          \
+        if (blockIdx.x == SIDE_PROF_BLOCK && (tid == 0u || tid == 64u)) {                                              \
             const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                              \
-            g_side_prof[slot] += now_ - stamp_;                                                                        \
+            g_side_prof[(slot) + (tid ? 16 : 0)] += now_ - stamp_;                                                      \
             stamp_ = now_;                                                                                             \
         }                                                                                                              \
     } while (0)
@@ -190,18 +224,20 @@ __device__ unsigned long long g_side_prof[16];
 
 __global__ __launch_bounds__(SIDE_T) void k7_side(const Work7 W)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_b[SIDE_PIECE + SIDE_XL * 16 + 16];
-    __shared__ __attribute__((aligned(16))) uint16_t s_L[SIDE_LCAP];
-    __shared__ __attribute__((aligned(16))) uint16_t s_len[2 * SIDE_LCAP];
+    __shared__ __attribute__((aligned(16))) uint8_t s_b[SIDE_BYTES];       // bytes of the piece the decoders work on
+    __shared__ __attribute__((aligned(16))) uint8_t s_T[SIDE_HALF + 16];   // strides of the piece the walker is in; [SIDE_HALF] = SIDE_OUT
+    __shared__ __attribute__((aligned(16))) uint16_t s_L[2][SIDE_LCAP];
+    __shared__ __attribute__((aligned(16))) uint16_t s_len[2][2 * SIDE_LCAP]; // item lengths of a unit (bits stream)
     __shared__ uint4 s_tab[72];
-    __shared__ uint32_t s_st[4];
-    __shared__ uint32_t s_w[SIDE_T / 64];
+    __shared__ __attribute__((aligned(16))) uint32_t s_st[2][4]; // what the walker reports with list 0 / 1
 
     const uint32_t fs = blockIdx.x, f = fs >> 1, s = fs & 1u;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid < 72u)
         s_tab[tid] = reinterpret_cast<const uint4 *>(c_tab7)[tid];
+    if (tid < 16u)
+        s_T[SIDE_HALF + tid] = static_cast<uint8_t>(SIDE_OUT);
 
     const Plan7 *P = W.plans + f;
     int32_t *status = W.status + f;
@@ -251,135 +287,213 @@ __global__ __launch_bounds__(SIDE_T) void k7_side(const Work7 W)
     uint16_t *refs = W.refs + static_cast<size_t>(f) * W.Rmax * 64u;
     uint32_t *goff = W.grp_off + static_cast<size_t>(f) * (W.Rmax * ITEM_SPLIT + 1u);
 
-    // ---- pieces: s_b[x] holds frame byte A + x; A is 16-byte aligned (relative to the frame buffer: the
-    // bounds check of the buffer loads works on whole dwords), the first record sits behind the 4-byte count
-    uint64_t A = (static_cast<uint64_t>(so) + 4u) & ~15ull;
-    uint32_t n = 0;                 // records done
-    uint32_t p = (so + 4u) & 15u;   // where the chain stands, relative to A
-    uint32_t S = 0;        // stride of the record at p when already known, else 0
-    uint64_t carry = 16u;  // payload offset of the next item (RawData.cpp:562)
-    int32_t lane_err = 0;  // per lane (a bits entry above 16)
-    bool dead = false;     // uniform: the chain ended before R records
+    // ---- pieces: s_b[.][x] holds frame byte A + x; A is 16-byte aligned (relative to the frame buffer: the
+    // bounds check of the buffer loads works on whole dwords); the first record sits behind the 4-byte count.
+    // Candidate u of a piece is the byte pair at 2u + odd.
+    const uint64_t A0 = (static_cast<uint64_t>(so) + 4u) & ~15ull;
+    const uint32_t odd = (so + 4u) & 1u;
+    uint32_t upc = 0;                      // piece of the unit just walked (the decoders' next work)
+    uint32_t bb = 0;                       // piece whose bytes are in s_b
+    uint32_t tb = 0;                       // piece whose strides are in s_T
+    uint32_t n = 0;                        // records decoded
+    uint64_t carry = 16u;                  // payload offset of the next item (RawData.cpp:562)
+    int32_t lane_err = 0;                  // per lane (a bits entry above 16)
+    bool dead = false;                     // uniform: the chain ended before R records
 
-    auto fetch = [&](uint64_t base, uint32_t line) -> uint4 {
-        const uint64_t o = base + 16ull * line;
-        return o < len ? ld_b128(rs, static_cast<uint32_t>(o)) : make_uint4(0, 0, 0, 0);
-    };
-    uint4 v[SIDE_LPT], vx = make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (uint32_t j = 0; j < SIDE_LPT; j++)
-        v[j] = fetch(A, tid + SIDE_T * j);
-    if (tid < SIDE_XL)
-        vx = fetch(A, SIDE_T * SIDE_LPT + tid);
-
-    const uint32_t k = lane & 7u, sub = lane >> 3;
 #ifdef MCRAW_DIAG
     unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
 #endif
-    while (true) {
-        lds_barrier(); // the previous piece's readers are done
-        SIDE_STAMP(0);
+    struct Lines {
+        uint4 v[SIDE_LPT], x;
+    };
+    auto load_piece = [&](Lines &r, uint32_t piece) {
+        const uint64_t base = A0 + static_cast<uint64_t>(piece) * SIDE_PIECE;
+#pragma unroll
+        for (uint32_t j = 0; j < SIDE_LPT; j++) {
+            const uint64_t o = base + 16ull * (tid + SIDE_T * j);
+            r.v[j] = o < len ? ld_b128(rs, static_cast<uint32_t>(o)) : make_uint4(0, 0, 0, 0);
+        }
+        r.x = make_uint4(0, 0, 0, 0);
+        if (tid < SIDE_XL) {
+            const uint64_t o = base + 16ull * (SIDE_T * SIDE_LPT + tid);
+            r.x = o < len ? ld_b128(rs, static_cast<uint32_t>(o)) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    // registers -> bytes of a piece (what the decoders read)
+    auto store_bytes = [&](const Lines &r) {
 #pragma unroll
         for (uint32_t j = 0; j < SIDE_LPT; j++)
-            reinterpret_cast<uint4 *>(s_b)[tid + SIDE_T * j] = v[j];
+            reinterpret_cast<uint4 *>(s_b)[tid + SIDE_T * j] = r.v[j];
         if (tid < SIDE_XL)
-            reinterpret_cast<uint4 *>(s_b)[SIDE_T * SIDE_LPT + tid] = vx;
-        // next piece on its way
-        const uint64_t An = A + SIDE_PIECE;
+            reinterpret_cast<uint4 *>(s_b)[SIDE_T * SIDE_LPT + tid] = r.x;
+    };
+    // registers -> stride table of `piece` (what the walker reads)
+    auto build_strides = [&](const Lines &r, uint32_t piece) {
+        const uint64_t base = A0 + static_cast<uint64_t>(piece) * SIDE_PIECE;
+        const uint64_t left = len - min(static_cast<uint64_t>(len), base);
+        const uint32_t lim = static_cast<uint32_t>(min(left, static_cast<uint64_t>(1u << 30))); // frame bytes from `base` on
 #pragma unroll
-        for (uint32_t j = 0; j < SIDE_LPT; j++)
-            v[j] = fetch(An, tid + SIDE_T * j);
-        if (tid < SIDE_XL)
-            vx = fetch(An, SIDE_T * SIDE_LPT + tid);
-        lds_barrier();
-        SIDE_STAMP(1);
-
-        // rounds over the piece: at most SIDE_LCAP records are listed at a time
-        while (true) {
-            if (wave == 0u) {
-                // run speculation: lane j looks at p + j * S.  `code` of a lane: 0 = behind the piece, 1 = a record
-                // that crosses `len` (RawData.cpp:419-420), else the stride of the record that starts there.
-                const uint32_t room = min(R - n, SIDE_LCAP);
-                const uint64_t left = len - min(static_cast<uint64_t>(len), A);
-                const uint32_t lim = static_cast<uint32_t>(min(left, static_cast<uint64_t>(1u << 30))); // frame bytes from A on
-                uint32_t cnt = 0, why = 0; // why: 1 list full / stream complete, 2 behind the piece, 3 chain dead
-                uint32_t pp = p, SS = S;   // scalar copies
-                auto code_at = [&](uint32_t q) -> uint32_t {
-                    const bool inb = q < SIDE_PIECE; // a record that starts in the piece has all its bytes staged
-                    const uint32_t hb = static_cast<uint32_t>(s_b[inb ? q : 0u]) >> 4;
-                    // LEN / 8 (RawData.cpp:27-45): nibble table for hbits 0..10, 16 above
-                    const uint32_t l8 = hb > 10u ? 16u : static_cast<uint32_t>(0xAA886543210ull >> (4u * hb)) & 15u;
-                    const uint32_t Sj = 2u + 8u * l8;
-                    return inb ? (q + Sj <= lim ? Sj : 1u) : 0u;
-                };
-                while (true) {
-                    if (pp >= SIDE_PIECE) {
-                        SS = 0u;
-                        why = 2u;
-                        break;
-                    }
-                    if (SS == 0u) {
-                        SS = __builtin_amdgcn_readfirstlane(code_at(pp));
-                        if (SS == 1u) {
-                            SS = 0u;
-                            why = 3u;
-                            break;
-                        }
-                    }
-                    const uint32_t q = pp + lane * SS;
-                    const uint32_t code = code_at(q);
-                    const unsigned long long m = __ballot(code == SS);
-                    const uint32_t nb = m == ~0ull ? 64u : static_cast<uint32_t>(__builtin_ctzll(~m)); // >= 1
-                    const uint32_t take = min(nb, room - cnt);
-                    if (lane < take)
-                        s_L[cnt + lane] = static_cast<uint16_t>(q);
-                    cnt += take;
-                    pp += take * SS;
-                    if (take < nb) { // list full / stream complete inside the run: pp is a record of stride SS
-                        why = 1u;
-                        break;
-                    }
-                    if (cnt == room) { // ... at the end of the run: what follows has not been looked at
-                        SS = 0u;
-                        why = 1u;
-                        break;
-                    }
-                    if (nb == 64u)
-                        continue; // the run goes on, same stride
-                    // lane nb: the record behind the run, if it is one
-                    SS = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(code), static_cast<int>(nb)));
-                    if (SS == 0u) {
-                        why = 2u;
-                        break;
-                    }
-                    if (SS == 1u) {
-                        SS = 0u;
-                        why = 3u;
-                        break;
-                    }
+        for (uint32_t j = 0; j < SIDE_LPT; j++) {
+            const uint32_t line = tid + SIDE_T * j;
+            uint2 st = side_strides(r.v[j], odd);
+            if (16u * line + 16u + 130u > lim) { // near the end of the frame: a record that would cross `len` ends the chain
+                uint32_t w[2] = {st.x, st.y};
+#pragma unroll
+                for (uint32_t i = 0; i < 8u; i++) {
+                    const uint32_t sv = (w[i >> 2] >> (8u * (i & 3u))) & 0xffu;
+                    if (16u * line + 2u * i + odd + 2u * sv > lim)
+                        w[i >> 2] = (w[i >> 2] & ~(0xffu << (8u * (i & 3u)))) | (SIDE_DEAD << (8u * (i & 3u)));
                 }
-                if (lane == 0u) {
-                    s_st[0] = pp;
-                    s_st[1] = cnt;
-                    s_st[2] = why;
-                    s_st[3] = SS;
-                }
+                st = make_uint2(w[0], w[1]);
             }
-            lds_barrier();
-            SIDE_STAMP(2);
-            p = __builtin_amdgcn_readfirstlane(s_st[0]);
-            const uint32_t total = __builtin_amdgcn_readfirstlane(s_st[1]);
-            const uint32_t why = __builtin_amdgcn_readfirstlane(s_st[2]);
-            S = __builtin_amdgcn_readfirstlane(s_st[3]);
+            reinterpret_cast<uint2 *>(s_T)[line] = st;
+        }
+    };
+    // W (wave 0): list up to `room` (>= 1) records of the piece in s_T from candidate pu on; result in s_st:
+    // where the chain stands, records listed, why it stopped (1 list full / stream complete, 2 behind the
+    // piece, 3 chain dead) and the stride of the record it stands on when that is known (else 0).
+    // SU == 0 on entry makes the first pass a probe: every lane looks at pu itself, nothing matches stride 0,
+    // and "the record behind the run" is the record at pu.
+    auto walk = [&](uint32_t lst, uint32_t pu, uint32_t SU, uint32_t room) {
+        uint16_t *L = s_L[lst];
+        uint32_t cnt = 0, why = 2u;
+        if (pu < SIDE_HALF) {
+            // one pass per run, one exit test per pass
+            uint32_t nb, take, nxt;
+            bool go;
+            do {
+                const uint32_t u = pu + lane * SU;
+                const uint32_t code = s_T[min(u, SIDE_HALF)];
+                const unsigned long long m = __ballot(code != SU);
+                nb = m == 0ull ? 64u : static_cast<uint32_t>(__builtin_ctzll(m));
+                take = min(nb, room - cnt);
+                if (lane < take)
+                    L[cnt + lane] = static_cast<uint16_t>(u);
+                // lane nb: the record behind the run, if it is one (SIDE_OUT: behind the piece, SIDE_DEAD: it would cross `len`)
+                nxt = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(code), static_cast<int>(nb & 63u)));
+                cnt += take;
+                pu += take * SU;
+                go = take == nb && cnt < room && (nb == 64u || nxt < SIDE_DEAD);
+                SU = (go && nb != 64u) ? nxt : SU;
+#ifdef MCRAW_DIAG
+                if (blockIdx.x == SIDE_PROF_BLOCK && lane == 0u)
+                    g_side_prof[6]++;
+#endif
+            } while (go);
+            if (take < nb) {
+                why = 1u; // list full / stream complete inside the run: pu is a record of stride SU
+            } else if (cnt >= room) {
+                why = 1u; // ... at the end of the run
+                SU = (nb != 64u && nxt < SIDE_DEAD) ? nxt : 0u;
+            } else {
+                why = nxt == SIDE_OUT ? 2u : 3u;
+                SU = 0u;
+            }
+        } else {
+            SU = 0u;
+        }
+        if (lane == 0u)
+            *reinterpret_cast<uint4 *>(s_st[lst]) = make_uint4(pu, cnt, why, SU);
+#ifdef MCRAW_DIAG
+        if (blockIdx.x == SIDE_PROF_BLOCK && lane == 0u)
+            g_side_prof[7]++;
+#endif
+    };
 
-            // record decode: lane = (record, k) owns samples 8k..8k+7
-            for (uint32_t qb = wave * 8u; qb < total; qb += (SIDE_T / 64u) * 8u) {
-                const uint32_t q = qb + sub;
+    const uint32_t k = lane & 7u, sub = lane >> 3;
+    // prologue: piece 0 in LDS, pieces 1 and 2 on their way, first unit walked
+    Lines nx, ny; // invariant at the top of the loop: the two pieces behind the one in s_b (bb + 1, bb + 2)
+    load_piece(nx, 0u);
+    store_bytes(nx);
+    build_strides(nx, 0u);
+    load_piece(nx, 1u);
+    load_piece(ny, 2u);
+    lds_barrier();
+    if (wave == 0u)
+        walk(0u, static_cast<uint32_t>((so + 4u) & 15u) >> 1, 0u, min(R, SIDE_LCAP));
+    // S (wave 0, bits stream): item lengths of one unit -> payload offsets: exclusive scan, eight items per lane and pass
+    static_assert((2u * SIDE_LCAP) % 512u == 0u, "whole passes of 512 items");
+    auto scan_unit = [&](uint32_t par, uint32_t n0, uint32_t cnt) {
+        const uint32_t nitems = 2u * cnt;
+        for (uint32_t base = 0; base < nitems; base += 512u) {
+            const uint32_t i0 = base + 8u * lane;
+            uint4 lv = make_uint4(0u, 0u, 0u, 0u);
+            if (i0 < nitems)
+                lv = *reinterpret_cast<const uint4 *>(&s_len[par][i0]);
+            uint32_t a[8] = {lv.x & 0xffffu, lv.x >> 16, lv.y & 0xffffu, lv.y >> 16,
+                             lv.z & 0xffffu, lv.z >> 16, lv.w & 0xffffu, lv.w >> 16};
+            uint32_t mine = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 8u; i++) {
+                a[i] = i0 + i < nitems ? a[i] : 0u;
+                mine += a[i];
+            }
+            uint32_t utot;
+            const uint32_t ex = wave_excl_scan(mine, lane, &utot);
+            // offsets past 2^32 only occur in frames that fail the `len` check at the end
+            uint32_t o = static_cast<uint32_t>(carry) + ex;
+#pragma unroll
+            for (uint32_t i = 0; i < 8u; i++) {
+                if (i0 + i < nitems)
+                    goff[2u * n0 + i0 + i] = o;
+                o += a[i];
+            }
+            carry += utot;
+        }
+    };
+
+    uint32_t cur = 0;                 // list (and item-length buffer) of the unit the decoders work on
+    uint32_t prev_n = 0, prev_total = 0; // the unit before it, not yet scanned
+    while (true) {
+        lds_barrier();
+        SIDE_STAMP(0);
+        // the unit just walked: `total` records of piece upc in list `cur`; where the walker stands
+        const uint4 st4 = *reinterpret_cast<const uint4 *>(s_st[cur]);
+        const uint32_t pu = __builtin_amdgcn_readfirstlane(st4.x);
+        const uint32_t total = __builtin_amdgcn_readfirstlane(st4.y);
+        const uint32_t why = __builtin_amdgcn_readfirstlane(st4.z);
+        const uint32_t SU = __builtin_amdgcn_readfirstlane(st4.w);
+        const bool last = n + total >= R || why == 3u;
+        const uint32_t npc = why == 2u ? upc + 1u : upc; // piece of the next unit
+        const bool moved = upc > bb, build = !last && npc > tb;
+        if (moved) { // the decoders move on to piece bb + 1: every unit of piece bb has been decoded
+            store_bytes(nx);
+            bb = upc;
+            nx = ny;
+            load_piece(ny, bb + 2u);
+        }
+        if (build) { // the walker moves on to piece bb + 1: it has left the piece whose strides are in s_T
+            build_strides(nx, npc);
+            tb = npc;
+        }
+        if (moved || build)
+            lds_barrier();
+        SIDE_STAMP(1);
+        if (wave == 0u) {
+            if (!last)
+                walk(cur ^ 1u, npc > upc ? pu - SIDE_HALF : pu, SU, min(R - (n + total), SIDE_LCAP));
+            SIDE_STAMP(2);
+            if (s == 0u && prev_total) // the unit the decoders finished before the last barrier
+                scan_unit(cur ^ 1u, prev_n, prev_total);
+            SIDE_STAMP(5);
+        } else {
+            // D: record decode, lane = (record, k) owns samples 8k..8k+7; the list entry and header of the
+            // next pass are fetched while this pass is unpacked
+            const uint8_t *B = s_b;
+            const uint16_t *L = s_L[cur];
+            constexpr uint32_t STEP = (SIDE_T / 64u - 1u) * 8u;
+            uint32_t q = (wave - 1u) * 8u + sub;
+            uint32_t ro_n = q < total ? 2u * L[q] + odd : 0u;
+            uint32_t hd_n = *reinterpret_cast<const uint16_t *>(B + (ro_n & ~1u)) | (static_cast<uint32_t>(B[(ro_n & ~1u) + 2u]) << 16);
+            for (uint32_t qb = (wave - 1u) * 8u; qb < total; qb += STEP, q += STEP) {
                 const bool live = q < total;
-                const uint32_t ro = live ? s_L[q] : 0u;
-                const uint32_t b0 = live ? s_b[ro] : 0u, b1 = s_b[ro + 1u];
+                const uint32_t ro = ro_n;
+                const uint32_t hd = hd_n >> (8u * (ro & 1u)); // header bytes b0, b1 (the stream may sit at odd addresses)
+                ro_n = q + STEP < total ? 2u * L[q + STEP] + odd : 0u;
+                hd_n = *reinterpret_cast<const uint16_t *>(B + (ro_n & ~1u)) | (static_cast<uint32_t>(B[(ro_n & ~1u) + 2u]) << 16);
+                const uint32_t b0 = live ? hd & 0xffu : 0u, b1 = (hd >> 8) & 0xffu;
                 const uint32_t hb = b0 >> 4, ref = ((b0 & 15u) << 8) | b1; // RawData.cpp:106-110
-                Unpacked U = unpack8<false>(s_b, ro + 2u, cls7_of(hb), k, s_tab);
+                Unpacked U = unpack8<false>(B, ro + 2u, cls7_of(hb), k, s_tab);
                 const u16x2 rr = __builtin_bit_cast(u16x2, ref | (ref << 16));
 #pragma unroll
                 for (int i = 0; i < 4; i++) // uint16 wrap (RawData.cpp:492)
@@ -429,70 +543,27 @@ __global__ __launch_bounds__(SIDE_T) void k7_side(const Work7 W)
                 l8 += swz_xor<0x041F>(l8);
                 l8 += swz_xor<0x081F>(l8);
                 if (live && (k & 3u) == 0u)
-                    s_len[2u * q + (k >> 2)] = static_cast<uint16_t>(l8 << 3); // <= 32 * 128 bytes
+                    s_len[cur][2u * q + (k >> 2)] = static_cast<uint16_t>(l8 << 3); // <= 32 * 128 bytes
             }
             SIDE_STAMP(3);
-
-            if (s == 0u) {
-                // item lengths -> payload offsets: exclusive scan over the round, eight items per thread
-                lds_barrier();
-                constexpr uint32_t IPT = 2u * SIDE_LCAP / SIDE_T;
-                static_assert(IPT == 8u, "one 16-byte read of item lengths per thread");
-                const uint32_t nitems = 2u * total;
-                const uint32_t i0 = IPT * tid;
-                uint4 lv = make_uint4(0u, 0u, 0u, 0u);
-                if (i0 < nitems)
-                    lv = *reinterpret_cast<const uint4 *>(&s_len[i0]);
-                uint32_t a[IPT] = {lv.x & 0xffffu, lv.x >> 16, lv.y & 0xffffu, lv.y >> 16,
-                                   lv.z & 0xffffu, lv.z >> 16, lv.w & 0xffffu, lv.w >> 16};
-                uint32_t mine = 0;
-#pragma unroll
-                for (uint32_t i = 0; i < IPT; i++) {
-                    a[i] = i0 + i < nitems ? a[i] : 0u;
-                    mine += a[i];
-                }
-                uint32_t wtot;
-                const uint32_t ex = wave_excl_scan(mine, lane, &wtot);
-                if (lane == 63u)
-                    s_w[wave] = wtot;
-                lds_barrier();
-                uint32_t before = 0, rtot = 0;
-#pragma unroll
-                for (uint32_t q = 0; q < SIDE_T / 64u; q++) {
-                    const uint32_t x = s_w[q];
-                    before += q < wave ? x : 0u;
-                    rtot += x;
-                }
-                // offsets past 2^32 only occur in frames that fail the `len` check below
-                uint32_t o = static_cast<uint32_t>(carry) + before + ex;
-#pragma unroll
-                for (uint32_t i = 0; i < IPT; i++) {
-                    if (i0 + i < nitems)
-                        goff[2u * n + i0 + i] = o;
-                    o += a[i];
-                }
-                carry += rtot;
-                SIDE_STAMP(4);
-            }
-
-            n += total;
-            if (n >= R)
-                break;
-            if (why == 3u) { // a record crosses `len` before the stream has its R records
-                dead = true;
-                break;
-            }
-            if (why == 2u)
-                break;     // the chain left the piece
-            lds_barrier(); // list full: the next round overwrites it
         }
-        if (n >= R || dead)
+        prev_n = n;
+        prev_total = total;
+        n += total;
+        if (last) {
+            dead = n < R;
             break;
-        p -= SIDE_PIECE;
-        A = An;
+        }
+        upc = npc;
+        cur ^= 1u;
+    }
+    if (s == 0u && prev_total) { // the last unit's offsets
+        lds_barrier();
+        if (wave == 0u)
+            scan_unit(cur, prev_n, prev_total);
     }
     if (tid == 0u) {
-        if (dead) // RawData.cpp:419-420
+        if (dead) // a record crosses `len` before the stream has its R records (RawData.cpp:419-420)
             lane_err |= MCRAW_E_TRUNCATED;
         if (s == 0u && !dead) {
             goff[ITEM_SPLIT * R] = static_cast<uint32_t>(min(carry, static_cast<uint64_t>(0xffffffffu)));
@@ -735,7 +806,7 @@ extern "C" void mcraw_diag_side_prof(unsigned long long *out, int reset)
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_side_prof), sizeof(g_side_prof));
     if (reset) {
-        unsigned long long z[16] = {0};
+        unsigned long long z[32] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_side_prof), z, sizeof(z));
     }
 }

@@ -25,7 +25,7 @@ frames = M.Context.make_frames([(tin[i].data_ptr(), tin[i].numel(), w, h, 7, tou
 ctx = M.Context(0)
 lib = M.load()
 ctx.decode_batch(frames)
-prof = (C.c_ulonglong * 16)()
+prof = (C.c_ulonglong * 32)()
 lib.mcraw_diag_side_prof(prof, 1)
 ctx.profile(True)
 reps = 5
@@ -33,8 +33,11 @@ for _ in range(reps):
     ctx.decode_batch(frames, want_status=False)
 torch.cuda.synchronize()
 lib.mcraw_diag_side_prof(prof, 1)
-names = ["barrier+load wait", "store bytes+prefetch issue", "walk", "decode", "scan", "-", "-", "-"]
-tot = sum(prof[:8])
+names0 = ["wait units", "build..barrier", "walk(w0)", "decode(w1)", "scan wait", "scan", "walk steps", "walk calls",
+          "walk: entry", "walk: first stride", "walk: loop", "top: s_st read", "top: build", "top: load issue", "-", "-"]
+names = ["w0 " + x for x in names0] + ["w1 " + x for x in names0]
+tot = sum(prof[:6])
+tot1 = sum(prof[16:22])
 for i, nm in enumerate(names):
-    print("%-24s %10.0f ticks/launch  %5.1f %%" % (nm, prof[i] / reps, 100.0 * prof[i] / max(tot, 1)))
+    print("%-24s %10.0f ticks/launch  %5.1f %%" % (nm, prof[i] / reps, 100.0 * prof[i] / max(tot if i < 16 else tot1, 1)))
 print("total ticks/launch", tot / reps, " k7_side ms/launch", ctx.kernel_ms("k7_side")[0] / reps, "tiles", ctx.kernel_ms("k7_tiles")[0] / reps)
