@@ -8,10 +8,15 @@
 A "step" is one pass of the decode path (mcraw_decode_batch through the C ABI,
 kernels k7_side -> k7_tiles) over one batch of synthetic
 frames that are already resident in HBM.  Workload = BASELINE.json config 3:
-240 frames of 3840x2160 12-bit, current (type 7) encoding, per GPU.  Frames
-shard by index, no collective on the data path (weak scaling: every rank decodes
-its own 240 frames); torch.distributed only carries the barrier and the max of
-the per-rank times.
+240 frames of 3840x2160 12-bit, current (type 7) encoding, per GPU (--config 5:
+120 frames of 7680x4320 per GPU).  Frames shard by index, no collective on the
+data path (weak scaling: every rank decodes its own frames); torch.distributed
+only carries the barriers and the max of the per-rank times.
+
+Timed region: W warm-up steps, then rounds of exactly K steps, each round
+bracketed by barrier + synchronise; as many rounds as it takes to cover 0.5 s
+(motioncam_decoder_amd/benchlib.py).  `ms_per_step` is the median round / K,
+the spread is reported beside it.
 
 Prints ONE JSON line on rank 0 (see the keys at the bottom).
 """
@@ -39,10 +44,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=240, help="frames per GPU per step")
+    ap.add_argument("--config", type=int, default=3, choices=(3, 5),
+                    help="BASELINE.json config: 3 = 240 x 3840x2160 per GPU (the metric's workload), 5 = 120 x 7680x4320 per GPU")
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (default: the config's)")
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="timed rounds cover at least this long")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) legs")
+    ap.add_argument("--stub-decode", action="store_true",
+                    help="CPU rehearsal of the multi-rank protocol (gloo, no GPU, the step is a sleep): tests only")
     ap.add_argument("--distinct", type=int, default=48, help="distinct synthetic frames generated per rank")
-    ap.add_argument("--width", type=int, default=3840)
-    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--nbits", type=int, default=12)
     ap.add_argument("--sigma", type=float, default=12.0)
     ap.add_argument("--dist", choices=["nat", "u"], default="nat")
@@ -54,7 +65,12 @@ def parse():
     ap.add_argument("--no-also", action="store_true", help="skip the second (other distribution) measurement")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=6.0)
-    return ap.parse_args()
+    a = ap.parse_args()
+    cw, ch, cf = {3: (3840, 2160, 240), 5: (7680, 4320, 120)}[a.config]
+    a.width = a.width or cw
+    a.height = a.height or ch
+    a.frames = a.frames or cf
+    return a
 
 
 def synth_lib():
@@ -79,7 +95,7 @@ class Workload:
         frame g is generated from seed 1000 * 3 + g (config 3 of SURVEY 8d)."""
         self.w, self.h = args.width, args.height
         self.frames = args.frames
-        seeds = [1000 * 3 + g for g in gidx[: min(args.distinct, args.frames)]]
+        seeds = [1000 * args.config + g for g in gidx[: min(args.distinct, args.frames)]]
         self.pairs = make_frames(L, seeds, self.w, self.h, args.nbits, dist, args.sigma)
         lens = [p[1].size for p in self.pairs]
         d = len(self.pairs)
@@ -120,7 +136,11 @@ class Workload:
         return True
 
 
-def run_timed(torch, dist_mod, ctx, M, wl, steps, warmup, world):
+def run_timed(torch, comm, ctx, M, wl, args):
+    """Warm-up, per-kernel breakdown (untimed), then the timed rounds.  Returns (round times [s, max over
+    ranks], kernels_ms_per_step, (k7_tiles ms summed over the timed rounds, launches), steps timed, ok)."""
+    from motioncam_decoder_amd import benchlib
+    steps, warmup = args.steps, args.warmup
     nset = len(wl.desc_sets)
     cur = torch.cuda.current_stream()
     streams = [cur] if nset == 1 else [torch.cuda.Stream() for _ in range(nset)]
@@ -131,9 +151,6 @@ def run_timed(torch, dist_mod, ctx, M, wl, steps, warmup, world):
     assert all(s == 0 for s in status), "decode failed: %s" % [hex(s) for s in status if s][:4]
     assert all(wr == wl.w * wl.h for wr in written)
     ok = wl.verify(torch, sorted({0, wl.frames // 2, wl.frames - 1}))
-    for i in range(max(0, warmup - 1)):
-        ctx.decode_batch(wl.desc_sets[i % nset], mem=M.MEM_DEVICE, stream=streams[i % nset].cuda_stream, want_status=False)
-    torch.cuda.synchronize()
     # untimed: a few steps on one stream with every kernel bracketed by events, for the per-kernel breakdown
     names = ("k7_side", "k7_tiles")
     ctx.profile(True)
@@ -148,23 +165,85 @@ def run_timed(torch, dist_mod, ctx, M, wl, steps, warmup, world):
         t.zero_()
     # timed: only the roofline kernel carries events (each bracket is two event records in the stream)
     ctx.profile(only=("k7_tiles",))
-    if dist_mod.is_initialized():
-        dist_mod.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
+    ctx.kernel_ms("k7_tiles", reset=True)
+    counted = [0]
+
+    def step(i):
         ctx.decode_batch(wl.desc_sets[i % nset], mem=M.MEM_DEVICE, stream=streams[i % nset].cuda_stream, want_status=False)
-    torch.cuda.synchronize()
-    if dist_mod.is_initialized():
-        dist_mod.barrier()
-    t1 = time.perf_counter()
+        counted[0] += 1
+
+    times = benchlib.timed_rounds(step, torch.cuda.synchronize, comm, steps, max(0, warmup - 1), args.min_seconds)
     st = ctx.synchronize(wl.frames)
     ok = ok and all(s == 0 for s in st)
     for which in range(min(nset, steps)): # every buffer set the timed steps wrote
         ok = ok and wl.verify(torch, sorted({min(1, wl.frames - 1), wl.frames // 3, max(0, wl.frames - 2)}), which)
-    tiles = ctx.kernel_ms("k7_tiles", reset=True) # (ms summed over the timed region, launches)
+    tiles = ctx.kernel_ms("k7_tiles", reset=True) # (ms summed over warm-up + timed rounds, launches)
     ctx.profile(True)
-    return t1 - t0, kms, tiles, ok
+    return times, kms, tiles, ok
+
+
+def link_probe(torch, dev, nbytes=256 << 20, reps=3):
+    """The host link of this GPU, measured now: pinned copies up, down, and both at once (GB/s)."""
+    h1 = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    h2 = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    d1 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    d2 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def t(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    def both():
+        with torch.cuda.stream(s1):
+            d1.copy_(h1, non_blocking=True)
+        with torch.cuda.stream(s2):
+            h2.copy_(d2, non_blocking=True)
+
+    up = nbytes / t(lambda: d1.copy_(h1, non_blocking=True)) / 1e9
+    down = nbytes / t(lambda: h2.copy_(d2, non_blocking=True)) / 1e9
+    duplex = nbytes / t(both) / 1e9
+    return {"h2d_GBs": round(up, 1), "d2h_GBs": round(down, 1), "each_way_when_both_GBs": round(duplex, 1)}
+
+
+def mixed64_leg(torch, ctx, M, L, dev, reps=5):
+    """BASELINE config 4, timed: 64 frames, 14-bit type 7 (U and Nat) interleaved with legacy frames (10/12/14-bit,
+    one width with w % 32 != 0), 1920x1080 and 12 MP; verified against the images the encoder was given."""
+    items = []
+    for i in range(64):
+        if i % 2 == 0:
+            w, h = ((1920, 1080), (4032, 3024))[(i // 2) % 2]
+            img = L.synth_image(w, h, 14, (i // 4) % 2, 40.0, 4000 + i)
+            items.append((M.TYPE_BLOCK, img, L.encode7(img)))
+        else:
+            w, h = ((1920, 1080), (4000, 3000))[(i // 2) % 2]
+            img = L.synth_image(w, h, (10, 12, 14)[(i // 2) % 3], (i // 4) % 2, 12.0, 4000 + i)
+            items.append((M.TYPE_LEGACY, img, L.encode6(img, None, flags=1)))
+    tin = [torch.from_numpy(it[2]).to(dev) for it in items]
+    tout = [torch.zeros(it[1].size * 2, dtype=torch.uint8, device=dev) for it in items]
+    descs = [(tin[i].data_ptr(), tin[i].numel(), it[1].shape[1], it[1].shape[0], it[0], tout[i].data_ptr(), it[1].size)
+             for i, it in enumerate(items)]
+    frames = M.Context.make_frames(descs)
+    written, status = ctx.decode_batch(frames)
+    ok = all(s == 0 for s in status)
+    for i, it in enumerate(items):
+        ok = ok and np.array_equal(tout[i].cpu().numpy().view(np.uint16).reshape(it[1].shape), it[1])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.decode_batch(frames, want_status=False)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / reps
+    px = sum(it[1].size for it in items)
+    byts = sum(it[2].size for it in items) + 2 * px
+    return {"workload": "config 4: 64 frames, type 7 (14-bit U/Nat) and type 6 (10/12/14-bit) interleaved, 1920x1080 / 4032x3024 / 4000x3000",
+            "ms_per_batch": round(t * 1e3, 4), "mpix_s": round(px / t / 1e6, 1), "in_plus_out_GBs": round(byts / t / 1e9, 1),
+            "bit_exact": bool(ok)}
 
 
 def cpu_baseline(L, wl, seconds):
@@ -215,7 +294,7 @@ def cpu_baseline(L, wl, seconds):
                       "%.1f s on %d threads + %.1f s on 1 thread" % (n, wl.w, wl.h, 12, res["all_s"], cores, res["one_s"])}
 
 
-def pcie_inclusive(M, L, ctx, wl, nframes=240, reps=2, pack12=False):
+def pcie_inclusive(M, L, ctx, wl, comm, link=None, nframes=240, reps=2, pack12=False):
     """End-to-end rate when the boundary hands over HOST buffers (never `value`): frames in pinned
     memory -> H2D -> decode -> D2H into pinned memory, sub-batches pipelined on the context's
     streams (mcraw_decode_batch, MCRAW_MEM_HOST).  pack12: with the fused 12-bit strip stage, which
@@ -239,18 +318,30 @@ def pcie_inclusive(M, L, ctx, wl, nframes=240, reps=2, pack12=False):
             descs.append((pi, buf.size, wl.w, wl.h, M.TYPE_BLOCK, po, out_bytes // 2))
         frames = M.Context.make_frames(descs)
         ctx.decode_batch(frames, mem=M.MEM_HOST)  # warm-up: staging buffers get allocated
+        comm.barrier()                             # every rank pulls on the host's memory and its own link at the same time
         t0 = time.perf_counter()
         for _ in range(reps):
             written, status = ctx.decode_batch(frames, mem=M.MEM_HOST)
-        t = (time.perf_counter() - t0) / reps
+        t_local = (time.perf_counter() - t0) / reps
+        comm.barrier()
+        t = comm.max([t_local])[0]                 # the job's rate is set by its slowest rank
         ok = all(s == 0 for s in status)
         got = np.ctypeslib.as_array(C.cast(outs[0], C.POINTER(C.c_uint8)), shape=(wl.h, row_bytes))
         ok = ok and np.array_equal(got, L.oracle_post(wl.pairs[0][0], None, pack12))
+        ok = bool(comm.min([1.0 if ok else 0.0])[0] > 0.5)
         in_b = sum(wl.pairs[i % d][1].size for i in range(n))
-        return {"frames": n, "mpix_s": round(n * wl.w * wl.h / t / 1e6, 1), "frames_per_s": round(n / t, 1),
-                "h2d_GBs": round(in_b / t / 1e9, 2), "d2h_GBs": round(n * out_bytes / t / 1e9, 2), "bit_exact": bool(ok),
-                "note": "pinned host buffers in and out; sub-batches flow through upload stream / kernels / download stream; PCIe-bound"
-                        + ("; 12-bit strips out (mcraw_ctx_set_post)" if pack12 else "")}
+        world = comm.world
+        res = {"frames_per_rank": n, "mpix_s": round(world * n * wl.w * wl.h / t / 1e6, 1), "frames_per_s": round(world * n / t, 1),
+               "frames_per_s_per_rank": round(n / t, 1), "h2d_GBs_per_rank": round(in_b / t / 1e9, 2),
+               "d2h_GBs_per_rank": round(n * out_bytes / t / 1e9, 2), "bit_exact": ok,
+               "note": "pinned host buffers in and out; sub-batches flow through upload stream / kernels / download stream; PCIe-bound"
+                       + ("; 12-bit strips out (mcraw_ctx_set_post)" if pack12 else "")
+                       + ("; all ranks at once" if world > 1 else "")}
+        if link:
+            # time the two directions need at the rates this link showed with both directions busy
+            t_link = max(in_b / (link["each_way_when_both_GBs"] * 1e9), n * out_bytes / (link["each_way_when_both_GBs"] * 1e9))
+            res["link_frac"] = round(t_link / t_local, 3)
+        return res
     finally:
         ctx.set_post()
         for p in ins + outs:
@@ -337,11 +428,49 @@ def traffic_from_profile(workload_key):
         return None
 
 
+def stub_main(args):
+    """CPU rehearsal of the multi-rank protocol (tests/test_bench_dist_gloo.py): the same process-group set-up,
+    timed rounds, reductions and rank-0 JSON line as the GPU run, over gloo, with a sleep standing in for the decode."""
+    import torch
+    import torch.distributed as dist_mod
+    from motioncam_decoder_amd import benchlib, shard
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "RANK" in os.environ and "MASTER_ADDR" in os.environ:
+        dist_mod.init_process_group("gloo")
+    comm = benchlib.Comm(dist_mod, "cpu")
+    mine = shard.shard_frames(world * args.frames, rank, world)
+    assert len(mine) == args.frames
+    per_step = 0.002 * (1 + rank)  # the slower rank sets the job's time
+    times = benchlib.timed_rounds(lambda i: time.sleep(per_step), lambda: None, comm, args.steps, args.warmup, args.min_seconds)
+    ok = bool(comm.min([1.0])[0] > 0.5)
+    if comm.rank == 0:
+        st = benchlib.round_stats(times, args.steps)
+        pixels = world * args.frames * args.width * args.height
+        print(json.dumps({"metric": METRIC, "value": round(pixels / (st["median"] * 1e-3) / 1e6, 1), "unit": "MPixels/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(st["median"], 4),
+                          "ms_per_step_min": round(st["min"], 4), "ms_per_step_max": round(st["max"], 4), "rounds": st["rounds"],
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16",
+                          "data": "stub: no decode (CPU rehearsal of the multi-rank protocol)", "bit_exact": ok,
+                          "config": {"workload": "stub", "frames_per_gpu": args.frames}}), flush=True)
+    if comm.dist:
+        dist_mod.barrier()
+        dist_mod.destroy_process_group()
+
+
+METRIC = "MPixels/s unpacked + achieved HBM GB/s %peak, 4K 12-bit, 1/2/4/8 GPUs"
+
+
 def main():
     args = parse()
+    if args.stub_decode:
+        return stub_main(args)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    from motioncam_decoder_amd import benchlib
+    # before the first GPU call: this process, and the pinned buffers it will first-touch, next to its GPU
+    numa = benchlib.bind_to_gpu_numa(local) if world > 1 else None
     import torch
     import torch.distributed as dist_mod
 
@@ -351,6 +480,7 @@ def main():
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched by torch.distributed.run
     if use_dist:
         dist_mod.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+    comm = benchlib.Comm(dist_mod, dev)
 
     import motioncam_decoder_amd as M
     from motioncam_decoder_amd import build as B
@@ -359,8 +489,7 @@ def main():
         if not os.path.exists(M.lib_path()):
             B.build_hip()
         B.build_synth()
-    if use_dist:
-        dist_mod.barrier()
+    comm.barrier()
     L = synth_lib()
     ctx = M.Context(local)
     ctx.profile(True)
@@ -370,82 +499,100 @@ def main():
     for d in dists:
         # weak scaling: the job is world * frames frames, frame i decoded by rank i % world
         wl = Workload(torch, M, L, dev, args, d, shard.shard_frames(world * args.frames, rank, world))
-        el, kms, tiles, ok = run_timed(torch, dist_mod, ctx, M, wl, args.steps, args.warmup, world)
-        results[d] = dict(wl=wl, elapsed=shard.reduce_max(dist_mod, el, dev), kms=kms, tiles=tiles,
-                          ok=shard.reduce_min_flag(dist_mod, ok, dev))
+        times, kms, tiles, ok = run_timed(torch, comm, ctx, M, wl, args)
+        results[d] = dict(wl=wl, times=times, kms=kms, tiles=tiles, ok=bool(comm.min([1.0 if ok else 0.0])[0] > 0.5))
+
+    wl = results[args.dist]["wl"]
+    extra = {}
+    if not args.no_pcie and not args.no_cpu:
+        # the host-buffer legs run on EVERY rank at once: what limits a node is its PCIe links and the host
+        # memory feeding them, not the HBM-resident kernels
+        try:
+            link = link_probe(torch, dev)
+            extra["pcie_link"] = link
+            extra["pcie_inclusive"] = pcie_inclusive(M, L, ctx, wl, comm, link, nframes=min(240, args.frames))
+            extra["pcie_inclusive_pack12"] = pcie_inclusive(M, L, ctx, wl, comm, link, nframes=min(240, args.frames), pack12=True)
+        except Exception as e:
+            extra["pcie_inclusive"] = {"error": repr(e)}
 
     if rank == 0:
-        r = results[args.dist]
-        wl = r["wl"]
-
         def summarize(r):
             wl = r["wl"]
-            tile_ms, tile_n = r["tiles"]                    # summed over the timed region
-            launches_per_step = max(tile_n, 1) / args.steps  # a batch may be unpacked in sub-batches
-            step_tiles_ms = tile_ms / args.steps
+            st = benchlib.round_stats(r["times"], args.steps)
+            tile_ms, tile_n = r["tiles"]                    # summed over every launch since the counters' reset
             bytes_step = wl.in_bytes + wl.out_bytes
-            ach = bytes_step / (step_tiles_ms * 1e-3) / 1e9 if step_tiles_ms > 0 else 0.0
+            tile_avg = tile_ms / max(tile_n, 1)
+            ach = bytes_step / (tile_avg * 1e-3) / 1e9 if tile_avg > 0 else 0.0
             return {
-                "mpix_s": world * wl.pixels * args.steps / r["elapsed"] / 1e6,
-                "ms_per_step": 1e3 * r["elapsed"] / args.steps,
-                "tiles_ms_per_launch": tile_ms / max(tile_n, 1),
-                "launches_per_step": launches_per_step,
+                "mpix_s": world * wl.pixels / (st["median"] * 1e-3) / 1e6,
+                "st": st,
+                "tiles_ms_per_launch": tile_avg,
                 "achieved_gbs": ach,
-                "bytes_per_launch": bytes_step / launches_per_step,
+                "step_gbs": bytes_step / (st["median"] * 1e-3) / 1e9,
+                "bytes_per_launch": bytes_step,
                 "bpp": wl.bpp,
                 "kernels_ms_per_step": r["kms"],  # untimed pass with every kernel bracketed
             }
 
-        s = summarize(r)
+        s = summarize(results[args.dist])
         wname = "%dx%d %d-bit type-7 x %d frames/GPU, %s" % (args.width, args.height, args.nbits, args.frames,
                                                              "Nat (smooth field + noise sigma %g)" % args.sigma if args.dist == "nat" else "U (uniform)")
         key = "%dx%d_%dbit_%d_%s" % (args.width, args.height, args.nbits, args.frames, args.dist)
+        traffic = traffic_from_profile(key)
         out = {
-            "metric": "MPixels/s unpacked + achieved HBM GB/s %peak, 4K 12-bit, 1/2/4/8 GPUs",
+            "metric": METRIC,
             "value": round(s["mpix_s"], 1),
             "unit": "MPixels/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(s["ms_per_step"], 4),
+            "ms_per_step": round(s["st"]["median"], 4),
+            "ms_per_step_min": round(s["st"]["min"], 4),
+            "ms_per_step_max": round(s["st"]["max"], 4),
+            "rounds": s["st"]["rounds"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u16",
             "data": "synthetic: %d seeded distinct frames per rank (own encoder), replicated to %d frames at distinct "
                     "HBM addresses; inputs resident in HBM before the timed region" % (len(wl.pairs), args.frames),
-            "bit_exact": r["ok"],
-            "frames_per_s": round(world * args.frames * args.steps / r["elapsed"], 1),
-            "config": {"workload": wname, "frames_per_gpu": args.frames, "width": args.width, "height": args.height,
-                       "bits": args.nbits, "encoding": 7, "input_bpp": round(s["bpp"], 2), "sharding": "frame index, no collective",
-                       "streams": args.streams},
+            "bit_exact": results[args.dist]["ok"],
+            "frames_per_s": round(world * args.frames / (s["st"]["median"] * 1e-3), 1),
+            "config": {"workload": wname, "baseline_config": args.config, "frames_per_gpu": args.frames, "width": args.width,
+                       "height": args.height, "bits": args.nbits, "encoding": 7, "input_bpp": round(s["bpp"], 2),
+                       "sharding": "frame index, no collective", "streams": args.streams, "numa": numa},
             "roofline": {"bound": "hbm", "kernel": "k7_tiles", "achieved": round(s["achieved_gbs"], 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(s["achieved_gbs"] / HBM_PEAK_GBS, 4),
-                         "traffic": traffic_from_profile(key),
+                         # the whole step (every launch of the path) against the same peak: what a caller sees
+                         "step_achieved": round(s["step_gbs"], 1), "step_frac": round(s["step_gbs"] / HBM_PEAK_GBS, 4),
+                         "traffic": traffic,
+                         "traffic_source": ("profiles/traffic.json (rocprofv3 --pmc passes of this command, committed; not "
+                                            "measured in this run)") if traffic else None,
                          "algorithmic_bytes_per_launch": round(s["bytes_per_launch"]),
                          "avg_launch_ms": round(s["tiles_ms_per_launch"], 4),
-                         "launches_per_step": s["launches_per_step"]},
+                         "launches_per_step": 1.0, "kernel_launches_per_step": 2},
             "kernels_ms_per_step": {k: round(v, 4) for k, v in s["kernels_ms_per_step"].items()},
         }
         for d in dists[1:]:
             s2 = summarize(results[d])
-            out["also_" + d] = {"mpix_s": round(s2["mpix_s"], 1), "ms_per_step": round(s2["ms_per_step"], 4),
+            out["also_" + d] = {"mpix_s": round(s2["mpix_s"], 1), "ms_per_step": round(s2["st"]["median"], 4),
                                 "input_bpp": round(s2["bpp"], 2), "achieved_gbs": round(s2["achieved_gbs"], 1),
-                                "frac": round(s2["achieved_gbs"] / HBM_PEAK_GBS, 4), "bit_exact": results[d]["ok"]}
+                                "frac": round(s2["achieved_gbs"] / HBM_PEAK_GBS, 4),
+                                "step_frac": round(s2["step_gbs"] / HBM_PEAK_GBS, 4), "bit_exact": results[d]["ok"]}
+        out.update(extra)
         if world == 1 and not args.no_cpu:
             try:
                 out["legacy"] = legacy_leg(torch, ctx, M, L, dev)
             except Exception as e:
                 out["legacy"] = {"error": repr(e)}
             try:
+                out["mixed64"] = mixed64_leg(torch, ctx, M, L, dev)
+            except Exception as e:
+                out["mixed64"] = {"error": repr(e)}
+            try:
                 out["post_stage"] = post_stage(torch, ctx, M, L, wl, max(2, args.steps // 2))
             except Exception as e:
                 out["post_stage"] = {"error": repr(e)}
-            try:
-                out["pcie_inclusive"] = pcie_inclusive(M, L, ctx, wl)
-                out["pcie_inclusive_pack12"] = pcie_inclusive(M, L, ctx, wl, pack12=True)
-            except Exception as e:
-                out["pcie_inclusive"] = {"error": repr(e)}
             try:
                 out["cpu_baseline"] = cpu_baseline(L, wl, args.cpu_seconds)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU line

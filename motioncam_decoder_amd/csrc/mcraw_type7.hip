@@ -249,6 +249,29 @@ __global__ __launch_bounds__(SIDE_T) void k7_side(const Work7 W)
     const uint32_t encW = __builtin_amdgcn_readfirstlane(hv.x), encH = __builtin_amdgcn_readfirstlane(hv.y);
     const uint32_t bitsOff = __builtin_amdgcn_readfirstlane(hv.z), refsOff = __builtin_amdgcn_readfirstlane(hv.w);
     const uint32_t so = s ? refsOff : bitsOff;
+    // ---- pieces: s_b[x] holds frame byte A + x; A is 16-byte aligned (relative to the frame buffer: the
+    // bounds check of the buffer loads works on whole dwords); the first record sits behind the 4-byte count.
+    // Candidate u of a piece is the byte pair at 2u + odd.
+    const uint64_t A0 = (static_cast<uint64_t>(so) + 4u) & ~15ull;
+    const uint32_t odd = (so + 4u) & 1u;
+    struct Lines {
+        uint4 v[SIDE_LPT], x;
+    };
+    auto load_piece = [&](Lines &r, uint32_t piece) {
+        const uint64_t base = A0 + static_cast<uint64_t>(piece) * SIDE_PIECE;
+#pragma unroll
+        for (uint32_t j = 0; j < SIDE_LPT; j++) {
+            const uint64_t o = base + 16ull * (tid + SIDE_T * j);
+            r.v[j] = o < len ? ld_b128(rs, static_cast<uint32_t>(o)) : make_uint4(0, 0, 0, 0);
+        }
+        r.x = make_uint4(0, 0, 0, 0);
+        if (tid < SIDE_XL) {
+            const uint64_t o = base + 16ull * (SIDE_T * SIDE_LPT + tid);
+            r.x = o < len ? ld_b128(rs, static_cast<uint32_t>(o)) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    Lines nx, ny; // invariant at the top of the loop below: the two pieces behind the one in s_b (bb + 1, bb + 2)
+    load_piece(nx, 0u); // on its way while the header is checked (bounds-checked loads: harmless whatever `so` says)
     int32_t err = 0;
     uint32_t tilesX = 0, nblk = 0, R = 0;
     if (len < 16u || bitsOff > len || refsOff > len || (encW & 63u) != 0u || encW < static_cast<uint32_t>(P->width) ||
@@ -287,11 +310,6 @@ __global__ __launch_bounds__(SIDE_T) void k7_side(const Work7 W)
     uint16_t *refs = W.refs + static_cast<size_t>(f) * W.Rmax * 64u;
     uint32_t *goff = W.grp_off + static_cast<size_t>(f) * (W.Rmax * ITEM_SPLIT + 1u);
 
-    // ---- pieces: s_b[.][x] holds frame byte A + x; A is 16-byte aligned (relative to the frame buffer: the
-    // bounds check of the buffer loads works on whole dwords); the first record sits behind the 4-byte count.
-    // Candidate u of a piece is the byte pair at 2u + odd.
-    const uint64_t A0 = (static_cast<uint64_t>(so) + 4u) & ~15ull;
-    const uint32_t odd = (so + 4u) & 1u;
     uint32_t upc = 0;                      // piece of the unit just walked (the decoders' next work)
     uint32_t bb = 0;                       // piece whose bytes are in s_b
     uint32_t tb = 0;                       // piece whose strides are in s_T
@@ -303,22 +321,6 @@ __global__ __launch_bounds__(SIDE_T) void k7_side(const Work7 W)
 #ifdef MCRAW_DIAG
     unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
 #endif
-    struct Lines {
-        uint4 v[SIDE_LPT], x;
-    };
-    auto load_piece = [&](Lines &r, uint32_t piece) {
-        const uint64_t base = A0 + static_cast<uint64_t>(piece) * SIDE_PIECE;
-#pragma unroll
-        for (uint32_t j = 0; j < SIDE_LPT; j++) {
-            const uint64_t o = base + 16ull * (tid + SIDE_T * j);
-            r.v[j] = o < len ? ld_b128(rs, static_cast<uint32_t>(o)) : make_uint4(0, 0, 0, 0);
-        }
-        r.x = make_uint4(0, 0, 0, 0);
-        if (tid < SIDE_XL) {
-            const uint64_t o = base + 16ull * (SIDE_T * SIDE_LPT + tid);
-            r.x = o < len ? ld_b128(rs, static_cast<uint32_t>(o)) : make_uint4(0, 0, 0, 0);
-        }
-    };
     // registers -> bytes of a piece (what the decoders read)
     auto store_bytes = [&](const Lines &r) {
 #pragma unroll
@@ -402,15 +404,13 @@ __global__ __launch_bounds__(SIDE_T) void k7_side(const Work7 W)
 
     const uint32_t k = lane & 7u, sub = lane >> 3;
     // prologue: piece 0 in LDS, pieces 1 and 2 on their way, first unit walked
-    Lines nx, ny; // invariant at the top of the loop: the two pieces behind the one in s_b (bb + 1, bb + 2)
-    load_piece(nx, 0u);
     store_bytes(nx);
     build_strides(nx, 0u);
     load_piece(nx, 1u);
     load_piece(ny, 2u);
     lds_barrier();
     if (wave == 0u)
-        walk(0u, static_cast<uint32_t>((so + 4u) & 15u) >> 1, 0u, min(R, SIDE_LCAP));
+        walk(0u, static_cast<uint32_t>((so + 4u) & 15u) >> 1, 0u, min(R, SIDE_LCAP / 4u)); // a short first unit: the decoders start early
     // S (wave 0, bits stream): item lengths of one unit -> payload offsets: exclusive scan, eight items per lane and pass
     static_assert((2u * SIDE_LCAP) % 512u == 0u, "whole passes of 512 items");
     auto scan_unit = [&](uint32_t par, uint32_t n0, uint32_t cnt) {

@@ -1,0 +1,57 @@
+"""CPU: the multi-rank protocol of bench.py -- process group, NUMA binding helper, timed rounds bracketed by
+barriers, max-over-ranks, rank-0 JSON line -- run exactly as the driver launches it (torch.distributed.run,
+world size 2), over gloo, with a sleep standing in for the GPU decode (`--stub-decode`)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from motioncam_decoder_amd import benchlib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(300)
+def test_bench_protocol_world2_gloo():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--stub-decode", "--min-seconds", "0.1", "--frames", "5"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout          # rank 0 alone prints, once
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["rounds"] >= 2                   # 3 steps of 4 ms: several rounds to cover 0.1 s
+    # the slower rank (4 ms per step) sets the time; the faster one (2 ms) does not
+    assert 3.9 <= d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"] < 12.0
+    assert d["bit_exact"] is True
+    px = 2 * 5 * 3840 * 2160
+    assert abs(d["value"] - px / (d["ms_per_step"] * 1e-3) / 1e6) < 1.0   # whole-job rate over both ranks
+
+
+def test_timed_rounds_single_process():
+    calls = []
+    comm = benchlib.Comm(None)
+    times = benchlib.timed_rounds(lambda i: calls.append(i), lambda: None, comm, steps=4, warmup=2, min_seconds=0.0)
+    assert len(times) == 1 and calls[:2] == [0, 1]
+    assert len(calls) == 2 + 4 + 4            # warm-up, the sizing round, one timed round
+    st = benchlib.round_stats([0.004, 0.008, 0.006], 2)
+    assert st == {"median": 3.0, "min": 2.0, "max": 4.0, "rounds": 3}
+
+
+def test_numa_helpers_do_not_need_a_gpu():
+    # no AMD GPU in this container: the helper says so instead of failing
+    assert benchlib.gpu_numa_node(0) is None or isinstance(benchlib.gpu_numa_node(0), int)
+    assert benchlib.bind_to_gpu_numa(63) is None
