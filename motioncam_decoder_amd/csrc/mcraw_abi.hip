@@ -329,8 +329,10 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     // ---- lay out the upload image and the workspace ------------------------
     Layout L;
     size_t off = 0;
-    const size_t nstatus = static_cast<size_t>(n7) + n6 + 1;
-    L.status = carve(off, sizeof(int32_t) * (nstatus + n7)); // statuses, then the coded height of every type-7 frame
+    // status words: two per type-7 frame (one per side stream, each written once by its workgroup), one per legacy
+    // frame, one spare; then the coded height of every type-7 frame
+    const size_t nstatus = 2 * static_cast<size_t>(n7) + n6 + 1;
+    L.status = carve(off, sizeof(int32_t) * (nstatus + n7));
     L.plans7 = carve(off, sizeof(Plan7) * n7);
     L.plans6 = carve(off, sizeof(Plan6) * n6);
     L.map_base = carve(off, sizeof(uint32_t) * (n6 + 1));
@@ -343,7 +345,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     size_t Rmax = 0;
     for (const Plan7 &p : B.p7)
         Rmax = std::max<size_t>(Rmax, p.ngroups);
-    const size_t w_geo = carve(off, sizeof(uint4) * n7);
+    const size_t w_frames = carve(off, sizeof(Frame7) * n7);
     const size_t w_bits = carve(off, Rmax * 64 * n7);
     const size_t w_refs = carve(off, Rmax * 64 * sizeof(uint16_t) * n7);
     const size_t w_grp = carve(off, sizeof(uint32_t) * (Rmax * ITEM_SPLIT + 1) * n7);
@@ -382,7 +384,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         p.smap = reinterpret_cast<uint32_t *>(dev + w_smap[k]);
         p.centry = reinterpret_cast<uint32_t *>(dev + w_centry[k]);
         p.sentry = reinterpret_cast<uint32_t *>(dev + w_sentry[k]);
-        p.status = reinterpret_cast<int32_t *>(dev + L.status) + n7 + k;
+        p.status = reinterpret_cast<int32_t *>(dev + L.status) + 2 * n7 + k;
         map_base[k] = nmap;
         super_base[k] = nsup;
         row_base[k] = nrow;
@@ -396,14 +398,17 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     if (n6)
         std::memcpy(img + L.plans6, B.p6.data(), sizeof(Plan6) * n6);
 
-    HIP_TRY(hipMemcpyAsync(dev, img, L.upload_bytes, hipMemcpyHostToDevice, st));
+    // Type-7 frames need no upload: k7_side reads their plans straight from this pinned image and every status
+    // word of theirs is written by a plain store.  The legacy kernels take their tables (and zeroed status words) from HBM.
+    if (n6)
+        HIP_TRY(hipMemcpyAsync(dev, img, L.upload_bytes, hipMemcpyHostToDevice, st));
 
     // ---- launches -----------------------------------------------------------
     if (n7) {
         Work7 W{};
-        W.plans = reinterpret_cast<const Plan7 *>(dev + L.plans7);
+        W.plans = reinterpret_cast<const Plan7 *>(img + L.plans7); // pinned host memory, device-visible at the same address
         W.status = reinterpret_cast<int32_t *>(dev + L.status);
-        W.geo = reinterpret_cast<uint4 *>(dev + w_geo);
+        W.frames = reinterpret_cast<Frame7 *>(dev + w_frames);
         W.nstatus = static_cast<uint32_t>(nstatus);
         W.bits = dev + w_bits;
         W.refs = reinterpret_cast<uint16_t *>(dev + w_refs);
@@ -515,8 +520,9 @@ int acquire_slot(mcraw_ctx *c, Slot **out, bool device_batch = false)
 // height of every type-7 frame, from its header (rows written = min(height, encH), RawData.cpp:571, :611).
 int fetch_status(mcraw_ctx *c, Slot &s, size_t status_off, int n, hipStream_t st, int32_t *status, uint32_t *encH)
 {
-    const int ndev = static_cast<int>(s.order.size());
-    const size_t words = static_cast<size_t>(ndev) + 1 + s.n7; // statuses, one spare word, coded heights
+    const int ndev = static_cast<int>(s.order.size()), n7 = s.n7, n6 = ndev - n7;
+    const size_t nstatus = 2 * static_cast<size_t>(n7) + n6 + 1;
+    const size_t words = nstatus + n7; // statuses (two per type-7 frame, one per legacy frame, one spare), coded heights
     if (int rc = ensure(s.status_host, sizeof(int32_t) * words, true))
         return rc;
     if (ndev)
@@ -528,11 +534,11 @@ int fetch_status(mcraw_ctx *c, Slot &s, size_t status_off, int n, hipStream_t st
         status[i] = s.host_status[i];
     for (int j = 0; j < ndev; j++)
         if (s.order[j] < n)
-            status[s.order[j]] |= dev[j];
+            status[s.order[j]] |= j < n7 ? (dev[2 * j] | dev[2 * j + 1]) : dev[2 * n7 + (j - n7)];
     if (encH)
-        for (int j = 0; j < s.n7; j++)
+        for (int j = 0; j < n7; j++)
             if (s.order[j] < n)
-                encH[s.order[j]] = static_cast<uint32_t>(dev[ndev + 1 + j]);
+                encH[s.order[j]] = static_cast<uint32_t>(dev[nstatus + j]);
     (void)c;
     return 0;
 }

@@ -37,8 +37,9 @@ __host__ __device__ inline uint32_t post_row_bytes(uint32_t width, uint32_t mode
     return (mode & POST_PACK12) ? (width * 12u + 7u) >> 3 : width * 2u;
 }
 
-// Per-frame plan of the current ("type 7") encoding; lives in HBM for the
-// duration of one batch.  Geometry is NOT part of it: the kernels take it from the frame header
+// Per-frame plan of the current ("type 7") encoding, written by the host into PINNED HOST memory
+// that k7_side reads directly (one 48-byte read per stream over the link: no upload copy in front
+// of the kernels).  Geometry is NOT part of it: the kernels take it from the frame header
 // (lib/RawData.cpp:500-524); the plan only says how much workspace and grid the frame was given.
 struct Plan7 {
     const uint8_t *in;   // frame buffer (lib/RawData.cpp:528 `input`)
@@ -51,20 +52,36 @@ struct Plan7 {
     uint32_t pad;
 };
 
+// What k7_tiles needs to know about a frame, in HBM: written by k7_side (the workgroup of the bits
+// stream) from the plan and the frame header.
+struct Frame7 {
+    const uint8_t *in;
+    uint16_t *out;
+    uint32_t len;
+    int32_t width;       // output columns kept
+    uint32_t rows;       // output rows kept = min(height, encH) (RawData.cpp:571, :598-608)
+    uint32_t tilesX;     // encW / 64
+    uint32_t nblk;       // N = 4 * tilesX * encH/4 payload blocks; 0: nothing to decode (the header was rejected)
+    uint32_t fast_store;
+    uint32_t encH;
+    uint32_t pad;
+};
+
 // Batch-wide view of the type-7 work, passed to the kernels BY VALUE (kernarg):
 // every workspace array has the same per-frame stride (sized for the largest
 // frame of the batch), so a workgroup finds its slice from (frame, group)
 // without any dependent pointer load.
 struct Work7 {
-    const Plan7 *plans;  // [n7]
-    int32_t *status;     // [nstatus] status word of every frame of the batch (type-7 frames first), then
+    const Plan7 *plans;  // [n7] in pinned host memory (read by k7_side only)
+    Frame7 *frames;      // [n7] in HBM (written by k7_side, read by k7_tiles)
+    int32_t *status;     // [nstatus] status words: two per type-7 frame (its bits / refs stream, each written once,
+                         // by a plain store: nothing to initialise), then one per legacy frame, then
                          // [n7] the coded height of every type-7 frame (read back with the statuses)
-    uint4 *geo;          // [n7] geometry from the frame header: tilesX, blocks N, rows kept, encH (written by k7_side)
     uint8_t *bits;       // [n7][Rmax*64]  decoded `bits` stream  (:557)
     uint16_t *refs;      // [n7][Rmax*64]  decoded `refs` stream  (:560)
     uint32_t *grp_off;   // [n7][Rmax*ITEM_SPLIT+1] payload byte offset of every decode item (:562 + prefix of LEN)
     uint32_t Rmax;       // largest ngroups in the batch
-    uint32_t nstatus;    // status words in front of the coded heights
+    uint32_t nstatus;    // status words in front of the coded heights (2 * n7 + legacy frames + 1)
     int32_t n7;
     Post post;           // fused post-decode stage (mode 0: none)
     // k7_tiles is launched once per SIZE CLASS of the batch (plans are sorted by ngroups, descending):

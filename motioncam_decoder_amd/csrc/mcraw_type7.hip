@@ -230,6 +230,7 @@ __global__ __launch_bounds__(SIDE_T) void k7_side(const Work7 W)
     __shared__ __attribute__((aligned(16))) uint16_t s_len[2][2 * SIDE_LCAP]; // item lengths of a unit (bits stream)
     __shared__ uint4 s_tab[72];
     __shared__ __attribute__((aligned(16))) uint32_t s_st[2][4]; // what the walker reports with list 0 / 1
+    __shared__ int32_t s_err;
 
     const uint32_t fs = blockIdx.x, f = fs >> 1, s = fs & 1u;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -238,9 +239,12 @@ __global__ __launch_bounds__(SIDE_T) void k7_side(const Work7 W)
         s_tab[tid] = reinterpret_cast<const uint4 *>(c_tab7)[tid];
     if (tid < 16u)
         s_T[SIDE_HALF + tid] = static_cast<uint8_t>(SIDE_OUT);
+    if (tid == 0u)
+        s_err = 0;
 
-    const Plan7 *P = W.plans + f;
-    int32_t *status = W.status + f;
+    const Plan7 PL = W.plans[f]; // pinned host memory: one read over the link
+    const Plan7 *P = &PL;
+    int32_t *status = W.status + fs; // this stream's word
     const uint32_t len = P->len;
     const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
 
@@ -296,13 +300,23 @@ __global__ __launch_bounds__(SIDE_T) void k7_side(const Work7 W)
         }
     }
     if (s == 0u && tid == 0u) {
-        const uint32_t rows = min(static_cast<uint32_t>(P->height), encH);
-        W.geo[f] = make_uint4(tilesX, err == MCRAW_E_HEADER ? 0u : nblk, rows, encH);
+        Frame7 F;
+        F.in = P->in;
+        F.out = P->out;
+        F.len = len;
+        F.width = P->width;
+        F.rows = min(static_cast<uint32_t>(P->height), encH);
+        F.tilesX = tilesX;
+        F.nblk = err ? 0u : nblk; // a frame rejected here is not touched by k7_tiles
+        F.fast_store = P->fast_store;
+        F.encH = encH;
+        F.pad = 0u;
+        W.frames[f] = F;
         W.status[W.nstatus + f] = static_cast<int32_t>(encH); // read back with the statuses (rows written = min(height, encH))
     }
     if (err) {
         if (tid == 0u)
-            atomicOr(status, err);
+            *status = err;
         return;
     }
 
@@ -571,8 +585,12 @@ __global__ __launch_bounds__(SIDE_T) void k7_side(const Work7 W)
                 lane_err |= MCRAW_E_TRUNCATED;
         }
     }
+    // one status word per stream, written once (no initialisation needed in front of the kernel)
     if (lane_err)
-        atomicOr(status, lane_err);
+        atomicOr(&s_err, lane_err);
+    lds_barrier();
+    if (tid == 0u)
+        *status = s_err;
 }
 
 // ------------------------------------------------------------------ k7_tiles
@@ -609,27 +627,29 @@ __device__ __forceinline__ ItemS item_scalars(const Work7 &W, uint32_t item, uin
     const uint32_t fc = item / cper;
     const uint32_t f = first_frame + fc;
     const uint32_t g = item - fc * cper;
-    const Plan7 *P = W.plans + f;
-    const uint4 geo = W.geo[f]; // the frame's real geometry, from its header (k7_side): tilesX, blocks, rows kept, encH
+    const Frame7 *F = W.frames + f; // plan + header geometry, written by k7_side
+    const uint32_t nblk = F->nblk;
     const uint32_t *grp = W.grp_off + static_cast<size_t>(f) * (per + 1u) + g;
-    I.valid = (g * ITEM_BLOCKS < geo.y && W.status[f] == 0) ? 1u : 0u;
+    // a frame whose side streams failed behind the header checks is decoded from whatever the workspace
+    // holds (its status says so; every read below is bounds-checked and every offset clamped)
+    I.valid = g * ITEM_BLOCKS < nblk ? 1u : 0u;
     uint32_t start = 0, end = 0;
     if (I.valid) {
         start = grp[0];
         end = grp[1];
     }
     I.g = g;
-    I.nblk = geo.y;
-    I.tilesX = geo.x;
+    I.nblk = nblk;
+    I.tilesX = F->tilesX;
     I.base16 = start & ~15u;
     I.head = start - I.base16;
-    I.n16 = I.valid ? min((end - I.base16 + 15u) >> 4, PAY_CHUNKS) : 0u; // never more than ITEM_SPAN + head
-    I.width = P->width;
-    I.rows = static_cast<int32_t>(geo.z);
-    I.fast = P->fast_store;
-    I.in = P->in;
-    I.len = P->len;
-    I.out = P->out;
+    I.n16 = I.valid ? min((end - min(end, I.base16) + 15u) >> 4, PAY_CHUNKS) : 0u; // never more than ITEM_SPAN + head
+    I.width = F->width;
+    I.rows = static_cast<int32_t>(F->rows);
+    I.fast = F->fast_store;
+    I.in = F->in;
+    I.len = F->len;
+    I.out = F->out;
     I.meta = static_cast<size_t>(f) * W.Rmax * 64u + static_cast<size_t>(g) * ITEM_BLOCKS;
     return I;
 }
