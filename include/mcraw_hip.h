@@ -104,6 +104,39 @@ int mcraw_ticket_wait(mcraw_ticket *ticket, size_t *written, int32_t *status);
  * last batch (status may be NULL).  Returns 0 or negative. */
 int mcraw_ctx_synchronize(mcraw_ctx *ctx, int32_t *status, int nframes);
 
+/* ---- several GPUs of one node (device pool) --------------------------------------------------
+ *
+ * The reference walks a clip frame by frame on one thread (example.cpp:187-195 over
+ * lib/Decoder.cpp:184-235).  Frames are independent, so a batch shards by frame index: frame i is
+ * decoded by pool member i mod G -- no exchange between devices.  Every member is a context of its
+ * own, driven by one host thread of its own that is bound to the CPUs of its GPU's NUMA node.
+ * Results do not depend on the pool size.  Buffers are host memory (MCRAW_MEM_HOST semantics). */
+typedef struct mcraw_pool mcraw_pool;
+typedef struct mcraw_pool_ticket mcraw_pool_ticket;
+struct mcraw_post;
+
+/* The partition rule, usable without a GPU: which member decodes frame `index` (index mod ndevices;
+ * -1 on bad arguments), and how many of `nframes` frames member `member` gets. */
+int mcraw_shard_of(long index, int ndevices);
+int mcraw_shard_count(long nframes, int member, int ndevices);
+
+/* devices[0..ndevices): HIP device indices.  ndevices == 0: env MCRAW_DEVICES ("all" or "0,1,5"),
+ * else one member on MCRAW_DEVICE / the current device.  Returns 0 or a negative value. */
+int mcraw_pool_create(const int *devices, int ndevices, mcraw_pool **pool);
+void mcraw_pool_destroy(mcraw_pool *pool);
+const char *mcraw_pool_last_error(void);
+int mcraw_pool_size(const mcraw_pool *pool);
+int mcraw_pool_device(const mcraw_pool *pool, int member);    /* its HIP device index */
+int mcraw_pool_numa_cpus(const mcraw_pool *pool, int member); /* CPUs its host thread is bound to (0: not bound) */
+mcraw_ctx *mcraw_pool_ctx(mcraw_pool *pool, int member);      /* for the measurement calls below */
+int mcraw_pool_set_post(mcraw_pool *pool, const struct mcraw_post *post);
+/* Pinned host memory allocated by the member's own (NUMA-bound) thread: local to its GPU.  Free with mcraw_host_free. */
+void *mcraw_pool_host_alloc(mcraw_pool *pool, int member, size_t bytes);
+/* One batch over all members; the asynchronous form returns when every member has queued its share. */
+int mcraw_pool_decode_batch(mcraw_pool *pool, const mcraw_frame *frames, int nframes, size_t *written, int32_t *status);
+int mcraw_pool_decode_batch_async(mcraw_pool *pool, const mcraw_frame *frames, int nframes, mcraw_pool_ticket **ticket);
+int mcraw_pool_ticket_wait(mcraw_pool_ticket *ticket, size_t *written, int32_t *status);
+
 /* ---- measurement -------------------------------------------------------- */
 
 /* Kernel ids for mcraw_ctx_kernel_ms. */

@@ -11,7 +11,7 @@ present, every decode call raises.
 import ctypes as C
 import os
 
-__all__ = ["lib_path", "load", "Context", "Frame", "McrawError", "TYPE_LEGACY", "TYPE_BLOCK",
+__all__ = ["lib_path", "load", "Context", "Pool", "Frame", "McrawError", "TYPE_LEGACY", "TYPE_BLOCK",
            "MEM_DEVICE", "MEM_HOST", "KERNELS", "ABI_SYMBOLS"]
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
@@ -31,6 +31,9 @@ ABI_SYMBOLS = [
     "mcraw_ctx_create", "mcraw_ctx_destroy", "mcraw_last_error", "mcraw_decode7", "mcraw_decode6",
     "mcraw_decode_batch", "mcraw_ctx_synchronize", "mcraw_ctx_profile", "mcraw_ctx_kernel_ms",
     "mcraw_host_alloc", "mcraw_host_free", "mcraw_ctx_set_post", "mcraw_decode_batch_async", "mcraw_ticket_wait",
+    "mcraw_shard_of", "mcraw_shard_count", "mcraw_pool_create", "mcraw_pool_destroy", "mcraw_pool_last_error",
+    "mcraw_pool_size", "mcraw_pool_device", "mcraw_pool_numa_cpus", "mcraw_pool_ctx", "mcraw_pool_set_post",
+    "mcraw_pool_host_alloc", "mcraw_pool_decode_batch", "mcraw_pool_decode_batch_async", "mcraw_pool_ticket_wait",
 ]
 
 POST_BLACK, POST_PACK12 = 1, 2
@@ -113,8 +116,112 @@ def load():
     lib.mcraw_ticket_wait.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
     lib.mcraw_ctx_set_post.restype = C.c_int
     lib.mcraw_ctx_set_post.argtypes = [C.c_void_p, C.POINTER(Post)]
+    lib.mcraw_shard_of.restype = C.c_int
+    lib.mcraw_shard_of.argtypes = [C.c_long, C.c_int]
+    lib.mcraw_shard_count.restype = C.c_int
+    lib.mcraw_shard_count.argtypes = [C.c_long, C.c_int, C.c_int]
+    lib.mcraw_pool_create.restype = C.c_int
+    lib.mcraw_pool_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]
+    lib.mcraw_pool_destroy.restype = None
+    lib.mcraw_pool_destroy.argtypes = [C.c_void_p]
+    lib.mcraw_pool_last_error.restype = C.c_char_p
+    lib.mcraw_pool_last_error.argtypes = []
+    for name in ("mcraw_pool_size",):
+        getattr(lib, name).restype = C.c_int
+        getattr(lib, name).argtypes = [C.c_void_p]
+    for name in ("mcraw_pool_device", "mcraw_pool_numa_cpus"):
+        getattr(lib, name).restype = C.c_int
+        getattr(lib, name).argtypes = [C.c_void_p, C.c_int]
+    lib.mcraw_pool_ctx.restype = C.c_void_p
+    lib.mcraw_pool_ctx.argtypes = [C.c_void_p, C.c_int]
+    lib.mcraw_pool_set_post.restype = C.c_int
+    lib.mcraw_pool_set_post.argtypes = [C.c_void_p, C.POINTER(Post)]
+    lib.mcraw_pool_host_alloc.restype = C.c_void_p
+    lib.mcraw_pool_host_alloc.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    lib.mcraw_pool_decode_batch.restype = C.c_int
+    lib.mcraw_pool_decode_batch.argtypes = [C.c_void_p, C.POINTER(Frame), C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
+    lib.mcraw_pool_decode_batch_async.restype = C.c_int
+    lib.mcraw_pool_decode_batch_async.argtypes = [C.c_void_p, C.POINTER(Frame), C.c_int, C.POINTER(C.c_void_p)]
+    lib.mcraw_pool_ticket_wait.restype = C.c_int
+    lib.mcraw_pool_ticket_wait.argtypes = [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
     _lib = lib
     return lib
+
+
+class Pool:
+    """Owner of one ``mcraw_pool``: several GPUs of one node, frame i -> member i mod size."""
+
+    def __init__(self, devices=None):
+        self._lib = load()
+        h = C.c_void_p()
+        devices = list(devices or [])
+        arr = (C.c_int * max(len(devices), 1))(*devices)
+        rc = self._lib.mcraw_pool_create(arr if devices else None, len(devices), C.byref(h))
+        if rc != 0 or not h.value:
+            raise McrawError("mcraw_pool_create failed (%d): %s" % (rc, self._lib.mcraw_pool_last_error().decode()))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mcraw_pool_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def size(self):
+        return self._lib.mcraw_pool_size(self._h)
+
+    def devices(self):
+        return [self._lib.mcraw_pool_device(self._h, m) for m in range(self.size)]
+
+    def numa_cpus(self):
+        return [self._lib.mcraw_pool_numa_cpus(self._h, m) for m in range(self.size)]
+
+    def host_alloc(self, member, nbytes):
+        return self._lib.mcraw_pool_host_alloc(self._h, member, nbytes)
+
+    def set_post(self, black=None, pack12=False):
+        if black is None and not pack12:
+            return self._lib.mcraw_pool_set_post(self._h, None)
+        p = Post()
+        if black is not None:
+            p.flags |= POST_BLACK
+            for i in range(4):
+                p.black[i] = int(black[i])
+        if pack12:
+            p.flags |= POST_PACK12
+        return self._lib.mcraw_pool_set_post(self._h, C.byref(p))
+
+    def decode_batch(self, frames):
+        """frames: ctypes array from Context.make_frames (host pointers).  Returns (written, status)."""
+        n = len(frames)
+        written = (C.c_size_t * max(n, 1))()
+        status = (C.c_int32 * max(n, 1))()
+        rc = self._lib.mcraw_pool_decode_batch(self._h, frames, n, written, status)
+        if rc != 0:
+            raise McrawError("mcraw_pool_decode_batch failed (%d): %s" % (rc, self._lib.mcraw_pool_last_error().decode()))
+        return list(written)[:n], list(status)[:n]
+
+    def decode_batch_async(self, frames):
+        t = C.c_void_p()
+        rc = self._lib.mcraw_pool_decode_batch_async(self._h, frames, len(frames), C.byref(t))
+        if rc != 0:
+            raise McrawError("mcraw_pool_decode_batch_async failed (%d): %s" % (rc, self._lib.mcraw_pool_last_error().decode()))
+        return (t, len(frames))
+
+    def wait(self, ticket):
+        t, n = ticket
+        written = (C.c_size_t * max(n, 1))()
+        status = (C.c_int32 * max(n, 1))()
+        rc = self._lib.mcraw_pool_ticket_wait(t, written, status)
+        if rc != 0:
+            raise McrawError("mcraw_pool_ticket_wait failed (%d): %s" % (rc, self._lib.mcraw_pool_last_error().decode()))
+        return list(written)[:n], list(status)[:n]
 
 
 class Context:

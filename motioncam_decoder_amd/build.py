@@ -42,13 +42,13 @@ def _run(cmd):
 def build_hip(force=False):
     os.makedirs(LIB, exist_ok=True)
     out = os.path.join(LIB, "libmcraw_hip.so")
-    srcs = [os.path.join(CSRC, f) for f in ("mcraw_abi.hip", "mcraw_type7.hip", "mcraw_type6.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("mcraw_abi.hip", "mcraw_pool.hip", "mcraw_type7.hip", "mcraw_type6.hip")]
     deps = srcs + [os.path.join(CSRC, f) for f in ("mcraw_plan.h", "mcraw_dev.h")] + [
         os.path.join(ROOT, "include", "mcraw_hip.h")]
     if force or _newer(out, deps):
         diag = ["-DMCRAW_DIAG"] if os.environ.get("MCRAW_DIAG") else []  # timing-experiment kernels (tools/abl7.sh)
         _run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
-              "-Wall", "-Wno-unused-function"] + diag + ["-o", out] + srcs)
+              "-Wall", "-Wno-unused-function"] + diag + ["-o", out] + srcs + ["-lpthread"])
     return out
 
 

@@ -1,0 +1,410 @@
+// mcraw_pool.hip -- several GPUs of one node behind one handle (include/mcraw_hip.h, "device pool").
+//
+// The reference decodes a clip one frame after the other on one thread (example.cpp:187-195 ->
+// lib/Decoder.cpp:184-235).  Frames are independent, so a batch shards by frame index: frame i
+// goes to pool member i mod G -- no exchange between devices, nothing collective.
+// Every member is a mcraw_ctx of its own (streams, staging, workspace) driven by ONE HOST THREAD
+// of its own, which is bound to the CPUs of the GPU's NUMA node before it touches the device, so
+// that the plans it writes and the pinned memory it allocates are local to that GPU's PCIe root.
+// Results do not depend on the pool size.
+#include <hip/hip_runtime.h>
+#include <sched.h>
+
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mcraw_hip.h"
+
+namespace {
+
+// CPUs of the NUMA node a PCI device hangs off (sysfs), empty when the host does not say.
+std::vector<int> cpus_near_pci(const char *bus_id)
+{
+    std::vector<int> cpus;
+    char path[256];
+    std::snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus_id);
+    int node = -1;
+    if (FILE *f = std::fopen(path, "r")) {
+        if (std::fscanf(f, "%d", &node) != 1)
+            node = -1;
+        std::fclose(f);
+    }
+    if (node < 0)
+        return cpus;
+    std::snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = std::fopen(path, "r");
+    if (!f)
+        return cpus;
+    char buf[4096];
+    if (std::fgets(buf, sizeof(buf), f)) {
+        for (char *tok = std::strtok(buf, ",\n"); tok; tok = std::strtok(nullptr, ",\n")) {
+            int a = 0, b = 0;
+            if (std::sscanf(tok, "%d-%d", &a, &b) == 2) {
+                for (int c = a; c <= b; c++)
+                    cpus.push_back(c);
+            } else if (std::sscanf(tok, "%d", &a) == 1) {
+                cpus.push_back(a);
+            }
+        }
+    }
+    std::fclose(f);
+    return cpus;
+}
+
+// One pool member: a device, its context, and the host thread that drives it.
+struct Member {
+    int device = 0;
+    int numa_cpus = 0; // CPUs the thread was bound to (0: not bound)
+    mcraw_ctx *ctx = nullptr;
+    std::thread thread;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> task; // one at a time
+    bool has_task = false, done = true, quit = false;
+    int create_rc = 0;
+    std::string create_err;
+
+    void run(std::function<void()> fn)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        task = std::move(fn);
+        has_task = true;
+        done = false;
+        cv.notify_all();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return done; });
+    }
+    void loop()
+    {
+        // before the first HIP call of this thread: next to the GPU
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) == hipSuccess) {
+            for (char *p = bus; *p; p++)
+                if (*p >= 'A' && *p <= 'F')
+                    *p = static_cast<char>(*p - 'A' + 'a');
+            const std::vector<int> cpus = cpus_near_pci(bus);
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            for (int c : cpus)
+                if (c >= 0 && c < CPU_SETSIZE)
+                    CPU_SET(c, &set);
+            if (!cpus.empty() && sched_setaffinity(0, sizeof(set), &set) == 0)
+                numa_cpus = static_cast<int>(cpus.size());
+        }
+        create_rc = mcraw_ctx_create(device, &ctx);
+        if (create_rc != 0)
+            create_err = mcraw_last_error();
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            done = true; // "created"
+            cv.notify_all();
+        }
+        for (;;) {
+            std::function<void()> fn;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return has_task || quit; });
+                if (quit && !has_task)
+                    break;
+                fn = std::move(task);
+                has_task = false;
+            }
+            fn();
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                done = true;
+                cv.notify_all();
+            }
+        }
+        if (ctx)
+            mcraw_ctx_destroy(ctx);
+        ctx = nullptr;
+    }
+};
+
+thread_local std::string g_pool_err;
+
+} // namespace
+
+struct mcraw_pool {
+    std::vector<Member *> members;
+    std::mutex mu; // one batch at a time
+};
+
+// A sharded batch in flight.
+struct mcraw_pool_ticket {
+    mcraw_pool *pool = nullptr;
+    int n = 0;
+    std::vector<std::vector<mcraw_frame>> sub; // per member
+    std::vector<std::vector<int>> index;       // per member: position of its frames in the caller's batch
+    std::vector<mcraw_ticket *> tickets;
+    std::vector<int> rc;
+    std::vector<std::string> err;
+};
+
+extern "C" {
+
+int mcraw_shard_of(long index, int ndevices)
+{
+    if (ndevices <= 0 || index < 0)
+        return -1;
+    return static_cast<int>(index % ndevices);
+}
+
+int mcraw_shard_count(long nframes, int member, int ndevices)
+{
+    if (ndevices <= 0 || member < 0 || member >= ndevices || nframes < 0)
+        return -1;
+    return static_cast<int>((nframes - member + ndevices - 1) / ndevices);
+}
+
+const char *mcraw_pool_last_error(void) { return g_pool_err.c_str(); }
+
+int mcraw_pool_create(const int *devices, int ndevices, mcraw_pool **out)
+{
+    if (!out || ndevices < 0 || (ndevices > 0 && !devices)) {
+        g_pool_err = "mcraw_pool_create: bad arguments";
+        return -1;
+    }
+    *out = nullptr;
+    int have = 0;
+    hipError_t e = hipGetDeviceCount(&have);
+    if (e != hipSuccess || have <= 0) {
+        g_pool_err = "mcraw: no HIP device available (the decode path has no CPU fallback)";
+        return e != hipSuccess ? -static_cast<int>(e) : -static_cast<int>(hipErrorNoDevice);
+    }
+    std::vector<int> devs;
+    if (ndevices > 0) {
+        devs.assign(devices, devices + ndevices);
+    } else {
+        const char *env = std::getenv("MCRAW_DEVICES"); // "all" or a comma separated list
+        if (env && std::strcmp(env, "all") == 0) {
+            for (int d = 0; d < have; d++)
+                devs.push_back(d);
+        } else if (env && *env) {
+            std::string s(env);
+            size_t pos = 0;
+            while (pos < s.size()) {
+                size_t end = s.find(',', pos);
+                if (end == std::string::npos)
+                    end = s.size();
+                if (end > pos)
+                    devs.push_back(std::atoi(s.substr(pos, end - pos).c_str()));
+                pos = end + 1;
+            }
+        }
+        if (devs.empty()) { // one member: MCRAW_DEVICE, else the current device (like mcraw_ctx_create(-1))
+            const char *one = std::getenv("MCRAW_DEVICE");
+            int d = 0;
+            if (one && *one)
+                d = std::atoi(one);
+            else if (hipGetDevice(&d) != hipSuccess)
+                d = 0;
+            devs.push_back(d);
+        }
+    }
+    for (int d : devs)
+        if (d < 0 || d >= have) {
+            g_pool_err = "mcraw_pool_create: device index out of range";
+            return -static_cast<int>(hipErrorInvalidDevice);
+        }
+    mcraw_pool *p = new mcraw_pool();
+    for (int d : devs) {
+        Member *m = new Member();
+        m->device = d;
+        m->done = false;
+        m->thread = std::thread([m] { m->loop(); });
+        p->members.push_back(m);
+    }
+    int rc = 0;
+    for (Member *m : p->members) {
+        m->wait();
+        if (m->create_rc != 0 && rc == 0) {
+            rc = m->create_rc;
+            g_pool_err = m->create_err;
+        }
+    }
+    if (rc != 0) {
+        mcraw_pool_destroy(p);
+        return rc;
+    }
+    *out = p;
+    return 0;
+}
+
+void mcraw_pool_destroy(mcraw_pool *p)
+{
+    if (!p)
+        return;
+    for (Member *m : p->members) {
+        {
+            std::unique_lock<std::mutex> lk(m->mu);
+            m->quit = true;
+            m->cv.notify_all();
+        }
+        if (m->thread.joinable())
+            m->thread.join();
+        delete m;
+    }
+    delete p;
+}
+
+int mcraw_pool_size(const mcraw_pool *p) { return p ? static_cast<int>(p->members.size()) : 0; }
+
+int mcraw_pool_device(const mcraw_pool *p, int member)
+{
+    if (!p || member < 0 || member >= static_cast<int>(p->members.size()))
+        return -1;
+    return p->members[member]->device;
+}
+
+int mcraw_pool_numa_cpus(const mcraw_pool *p, int member)
+{
+    if (!p || member < 0 || member >= static_cast<int>(p->members.size()))
+        return -1;
+    return p->members[member]->numa_cpus;
+}
+
+mcraw_ctx *mcraw_pool_ctx(mcraw_pool *p, int member)
+{
+    if (!p || member < 0 || member >= static_cast<int>(p->members.size()))
+        return nullptr;
+    return p->members[member]->ctx;
+}
+
+int mcraw_pool_set_post(mcraw_pool *p, const mcraw_post *post)
+{
+    if (!p)
+        return -1;
+    int rc = 0;
+    for (Member *m : p->members)
+        if (int r = mcraw_ctx_set_post(m->ctx, post))
+            rc = r;
+    return rc;
+}
+
+void *mcraw_pool_host_alloc(mcraw_pool *p, int member, size_t bytes)
+{
+    if (!p || member < 0 || member >= static_cast<int>(p->members.size()))
+        return nullptr;
+    Member *m = p->members[member];
+    void *res = nullptr;
+    m->run([&] { res = mcraw_host_alloc(bytes); }); // pages are taken by the member's (NUMA-bound) thread
+    m->wait();
+    return res;
+}
+
+int mcraw_pool_decode_batch_async(mcraw_pool *p, const mcraw_frame *frames, int nframes, mcraw_pool_ticket **out)
+{
+    if (out)
+        *out = nullptr;
+    if (!p || !out || nframes < 0 || (nframes > 0 && !frames)) {
+        g_pool_err = "mcraw_pool_decode_batch_async: bad arguments";
+        return -1;
+    }
+    const int G = static_cast<int>(p->members.size());
+    mcraw_pool_ticket *t = new mcraw_pool_ticket();
+    t->pool = p;
+    t->n = nframes;
+    t->sub.resize(G);
+    t->index.resize(G);
+    t->tickets.assign(G, nullptr);
+    t->rc.assign(G, 0);
+    t->err.resize(G);
+    for (int i = 0; i < nframes; i++) { // frame i -> member i mod G
+        const int m = mcraw_shard_of(i, G);
+        t->sub[m].push_back(frames[i]);
+        t->index[m].push_back(i);
+    }
+    std::lock_guard<std::mutex> lk(p->mu);
+    for (int m = 0; m < G; m++) {
+        Member *mem = p->members[m];
+        mem->run([t, m, mem] {
+            if (t->sub[m].empty())
+                return;
+            t->rc[m] = mcraw_decode_batch_async(mem->ctx, t->sub[m].data(), static_cast<int>(t->sub[m].size()), &t->tickets[m]);
+            if (t->rc[m] != 0)
+                t->err[m] = mcraw_last_error();
+        });
+    }
+    int rc = 0;
+    for (int m = 0; m < G; m++) {
+        p->members[m]->wait();
+        if (t->rc[m] != 0 && rc == 0) {
+            rc = t->rc[m];
+            g_pool_err = t->err[m];
+        }
+    }
+    if (rc != 0) { // what was queued on the other members still runs into the caller's buffers: wait for it
+        for (int m = 0; m < G; m++)
+            if (t->tickets[m])
+                (void)mcraw_ticket_wait(t->tickets[m], nullptr, nullptr);
+        delete t;
+        return rc;
+    }
+    *out = t;
+    return 0;
+}
+
+int mcraw_pool_ticket_wait(mcraw_pool_ticket *t, size_t *written, int32_t *status)
+{
+    if (!t)
+        return -1;
+    mcraw_pool *p = t->pool;
+    const int G = static_cast<int>(p->members.size());
+    std::vector<std::vector<size_t>> wr(G);
+    std::vector<std::vector<int32_t>> st(G);
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        for (int m = 0; m < G; m++) {
+            wr[m].assign(t->sub[m].size(), 0);
+            st[m].assign(t->sub[m].size(), 0);
+            Member *mem = p->members[m];
+            mem->run([t, m, &wr, &st] {
+                if (!t->tickets[m])
+                    return;
+                t->rc[m] = mcraw_ticket_wait(t->tickets[m], wr[m].data(), st[m].data());
+                t->tickets[m] = nullptr;
+                if (t->rc[m] != 0)
+                    t->err[m] = mcraw_last_error();
+            });
+        }
+        for (int m = 0; m < G; m++)
+            p->members[m]->wait();
+    }
+    int rc = 0;
+    for (int m = 0; m < G; m++) {
+        if (t->rc[m] != 0 && rc == 0) {
+            rc = t->rc[m];
+            g_pool_err = t->err[m];
+        }
+        for (size_t k = 0; k < t->index[m].size(); k++) {
+            if (written)
+                written[t->index[m][k]] = wr[m][k];
+            if (status)
+                status[t->index[m][k]] = st[m][k];
+        }
+    }
+    delete t;
+    return rc;
+}
+
+int mcraw_pool_decode_batch(mcraw_pool *p, const mcraw_frame *frames, int nframes, size_t *written, int32_t *status)
+{
+    mcraw_pool_ticket *t = nullptr;
+    if (int rc = mcraw_pool_decode_batch_async(p, frames, nframes, &t))
+        return rc;
+    return mcraw_pool_ticket_wait(t, written, status);
+}
+
+} // extern "C"

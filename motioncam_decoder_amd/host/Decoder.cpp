@@ -147,22 +147,35 @@ struct Decoder::Impl {
     };
     std::unique_ptr<Loader> loader;
 
-    // pinned staging reused across loadFrames() calls
+    // Pinned staging reused across loadFrames() calls.  Every slot has one slice per pool member (GPU),
+    // allocated by that member's own thread: on the NUMA node of its GPU.
     static constexpr int kOutSlots = 4; // decoded chunks whose copy-out may still be running
     static constexpr int kInSlots = 3;  // (loadFramesInto) chunk being read, chunk queued, chunk finishing on the GPU
-    uint8_t *pinIn[kInSlots] = {nullptr, nullptr, nullptr}, *pinOut[kOutSlots] = {nullptr, nullptr, nullptr, nullptr};
-    size_t pinInCap[kInSlots] = {0, 0, 0}, pinOutCap[kOutSlots] = {0, 0, 0, 0};
-    mcraw_ctx *ctx = nullptr;
+    struct Slice {
+        uint8_t *p = nullptr;
+        size_t cap = 0;
+    };
+    std::vector<Slice> pinIn[kInSlots], pinOut[kOutSlots]; // [slot][member]
+    mcraw_pool *pool = nullptr; // the GPUs this decoder shards its batches over (frame i of a batch -> member i mod G)
+    std::vector<int> devices;   // empty: MCRAW_DEVICES / MCRAW_DEVICE / the current device
 
-    ~Impl()
+    void releaseGpu()
     {
-        for (int s = 0; s < kInSlots; s++)
-            mcraw_host_free(pinIn[s]);
-        for (int s = 0; s < kOutSlots; s++)
-            mcraw_host_free(pinOut[s]);
-        if (ctx)
-            mcraw_ctx_destroy(ctx);
+        for (auto &slot : pinIn)
+            for (Slice &s : slot)
+                mcraw_host_free(s.p);
+        for (auto &slot : pinOut)
+            for (Slice &s : slot)
+                mcraw_host_free(s.p);
+        for (auto &slot : pinIn)
+            slot.clear();
+        for (auto &slot : pinOut)
+            slot.clear();
+        if (pool)
+            mcraw_pool_destroy(pool);
+        pool = nullptr;
     }
+    ~Impl() { releaseGpu(); }
 
     void open();
     FrameSpan locate(Timestamp ts) const;
@@ -363,6 +376,20 @@ void Decoder::loadFramesInto(const std::vector<Timestamp> &timestamps, const std
     loadFramesImpl(timestamps, nullptr, &outBuffers, outMetadata, output);
 }
 
+void Decoder::useDevices(const std::vector<int> &devices)
+{
+    mImpl->releaseGpu(); // staging lives on the old members' NUMA nodes
+    mImpl->devices = devices;
+}
+
+int Decoder::deviceCount()
+{
+    Impl &I = *mImpl;
+    if (!I.pool && mcraw_pool_create(I.devices.empty() ? nullptr : I.devices.data(), static_cast<int>(I.devices.size()), &I.pool) != 0)
+        throw IOException(std::string("No GPU to decode on (") + mcraw_pool_last_error() + ")");
+    return mcraw_pool_size(I.pool);
+}
+
 void Decoder::loadFrameMetadata(const Timestamp timestamp, nlohmann::json &outMetadata)
 {
     Impl &I = *mImpl;
@@ -446,10 +473,12 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
         f.out_capacity = (outBytes[i] + 1) / 2; // counted in uint16 units
     }
 
-    if (!I.ctx && mcraw_ctx_create(-1, &I.ctx) != 0) // no GPU: decoding fails, there is no CPU codec behind this class
+    // no GPU: decoding fails, there is no CPU codec behind this class
+    if (!I.pool && mcraw_pool_create(I.devices.empty() ? nullptr : I.devices.data(), static_cast<int>(I.devices.size()), &I.pool) != 0)
         throw IOException(std::string(frames[0].type == kTypeBlock ? "Failed to uncompress frame"
                                                                    : "Failed to uncompress legacy frame") +
-                          " (" + mcraw_last_error() + ")");
+                          " (" + mcraw_pool_last_error() + ")");
+    const size_t G = static_cast<size_t>(mcraw_pool_size(I.pool)); // frame k of a chunk is decoded by member k mod G
 
     // chunks: as many frames as fit the staging budget of one slot (at least one frame)
     constexpr size_t kSlotBudget = 192ull << 20;
@@ -470,45 +499,59 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
         }
         chunks.push_back(c);
     }
-    auto grow = [](uint8_t *&p, size_t &cap, size_t want) {
-        if (want <= cap)
+    auto grow = [&](Impl::Slice &sl, size_t member, size_t want) {
+        if (want <= sl.cap)
             return;
-        mcraw_host_free(p);
-        p = static_cast<uint8_t *>(mcraw_host_alloc(want));
-        cap = p ? want : 0;
-        if (!p)
+        mcraw_host_free(sl.p);
+        sl.p = static_cast<uint8_t *>(mcraw_pool_host_alloc(I.pool, static_cast<int>(member), want));
+        sl.cap = sl.p ? want : 0;
+        if (!sl.p)
             throw IOException("Failed to allocate pinned staging");
     };
-    size_t maxIn = 0, maxOut = 0;
+    // staging bytes a chunk needs from every member's slice
+    std::vector<size_t> maxIn(G, 0), maxOut(G, 0);
     for (const Chunk &c : chunks) {
-        maxIn = std::max(maxIn, c.inBytes);
-        maxOut = std::max(maxOut, c.outBytes);
+        std::vector<size_t> in(G, 0), out(G, 0);
+        for (size_t k = 0; k < c.count; k++) {
+            in[k % G] += up(frames[c.first + k].len);
+            out[k % G] += up(frames[c.first + k].out_capacity * 2);
+        }
+        for (size_t m = 0; m < G; m++) {
+            maxIn[m] = std::max(maxIn[m], in[m]);
+            maxOut[m] = std::max(maxOut[m], out[m]);
+        }
     }
     // with the caller's buffers as destination the GPU stage is asynchronous (below): one more input slot
     const int nslots = static_cast<int>(std::min<size_t>(direct ? Impl::kInSlots : 2, chunks.size()));
     // a copy-out is one thread per frame (vector::assign faults its pages in as it copies), so several
     // chunks' copy-outs have to be in flight to keep up with the GPU: one output slot each
     const int noutslots = static_cast<int>(std::min<size_t>(Impl::kOutSlots, chunks.size()));
-    for (int s = 0; s < nslots; s++)
-        grow(I.pinIn[s], I.pinInCap[s], maxIn);
-    for (int s = 0; s < noutslots && !direct; s++)
-        grow(I.pinOut[s], I.pinOutCap[s], maxOut);
+    for (int sl = 0; sl < nslots; sl++) {
+        I.pinIn[sl].resize(G);
+        for (size_t m = 0; m < G; m++)
+            grow(I.pinIn[sl][m], m, maxIn[m]);
+    }
+    for (int sl = 0; sl < noutslots && !direct; sl++) {
+        I.pinOut[sl].resize(G);
+        for (size_t m = 0; m < G; m++)
+            grow(I.pinOut[sl][m], m, maxOut[m]);
+    }
     const unsigned hostThreads = std::max(2u, std::min(8u, std::thread::hardware_concurrency() / 2));
 
     auto readChunk = [&](size_t ci) { // file -> pinned input slot
         const Chunk &c = chunks[ci];
-        uint8_t *base = I.pinIn[ci % nslots];
-        std::vector<size_t> off(c.count);
-        size_t o = 0;
-        for (size_t k = 0; k < c.count; k++) {
-            off[k] = o;
-            o += up(frames[c.first + k].len);
+        std::vector<Impl::Slice> &slot = I.pinIn[ci % nslots];
+        std::vector<size_t> off(c.count), fill(G, 0);
+        for (size_t k = 0; k < c.count; k++) { // frame k lands in the slice of the GPU that will decode it
+            off[k] = fill[k % G];
+            fill[k % G] += up(frames[c.first + k].len);
         }
         parallelFor(c.count, hostThreads, [&](size_t k) {
             mcraw_frame &f = frames[c.first + k];
+            uint8_t *dst = slot[k % G].p + off[k];
             if (f.len)
-                I.reader.readAt(spans[c.first + k].payload, base + off[k], f.len);
-            f.in = base + off[k];
+                I.reader.readAt(spans[c.first + k].payload, dst, f.len);
+            f.in = dst;
         });
     };
     auto copyOut = [&](size_t ci) { // pinned output slot -> the caller's vectors
@@ -555,23 +598,23 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
                                                                : "Failed to uncompress legacy frame");
     };
     struct Queued { // loadFramesInto: the chunk whose ticket is still open
-        mcraw_ticket *ticket = nullptr;
+        mcraw_pool_ticket *ticket = nullptr;
         size_t ci = 0;
         ~Queued()
         {
             if (ticket) // an exception is on its way out: the batch still writes into the caller's buffers
-                (void)mcraw_ticket_wait(ticket, nullptr, nullptr);
+                (void)mcraw_pool_ticket_wait(ticket, nullptr, nullptr);
         }
     } queued;
-    auto finishQueued = [&]() {
-        if (!queued.ticket)
+    // Wait for a queued chunk.  The ticket is taken out of `queued` first, so that whatever is put there next is
+    // already owned (and waited for by ~Queued) if this chunk turns out to have failed.
+    auto finishTicket = [&](mcraw_pool_ticket *t, size_t ci) {
+        if (!t)
             return;
-        const Chunk &c = chunks[queued.ci];
-        mcraw_ticket *t = queued.ticket;
-        queued.ticket = nullptr;
-        if (mcraw_ticket_wait(t, written.data() + c.first, status.data() + c.first) != 0)
-            throw IOException(std::string("GPU decode failed: ") + mcraw_last_error());
-        checkChunk(queued.ci);
+        const Chunk &c = chunks[ci];
+        if (mcraw_pool_ticket_wait(t, written.data() + c.first, status.data() + c.first) != 0)
+            throw IOException(std::string("GPU decode failed: ") + mcraw_pool_last_error());
+        checkChunk(ci);
     };
     for (size_t ci = 0; ci < chunks.size(); ci++) {
         const Chunk &c = chunks[ci];
@@ -584,31 +627,33 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
         if (copying[ci % noutslots].valid())
             copying[ci % noutslots].get(); // chunk ci - noutslots used this output slot
         tWaitCopy += ms(t0, now());
-        uint8_t *obase = direct ? nullptr : I.pinOut[ci % noutslots];
-        size_t oo = 0;
+        std::vector<size_t> ofill(G, 0);
         for (size_t k = 0; k < c.count; k++) {
-            frames[c.first + k].out = reinterpret_cast<uint16_t *>(direct ? (*outBuffers)[c.first + k] : obase + oo);
-            oo += up(frames[c.first + k].out_capacity * 2);
+            uint8_t *dst = direct ? (*outBuffers)[c.first + k] : I.pinOut[ci % noutslots][k % G].p + ofill[k % G];
+            frames[c.first + k].out = reinterpret_cast<uint16_t *>(dst);
+            ofill[k % G] += up(frames[c.first + k].out_capacity * 2);
         }
         t0 = now();
-        // the post stage is a property of this call, not of the context: set for the batch, cleared behind it
-        int rc = post.flags ? mcraw_ctx_set_post(I.ctx, &post) : 0;
-        mcraw_ticket *ticket = nullptr;
+        // the post stage is a property of this call, not of the contexts: set for the batch, cleared behind it
+        int rc = post.flags ? mcraw_pool_set_post(I.pool, &post) : 0;
+        mcraw_pool_ticket *ticket = nullptr;
         if (rc == 0) {
             if (direct) // queued BEHIND chunk ci-1, which is waited for below: the PCIe lanes never drain
-                rc = mcraw_decode_batch_async(I.ctx, frames.data() + c.first, static_cast<int>(c.count), &ticket);
+                rc = mcraw_pool_decode_batch_async(I.pool, frames.data() + c.first, static_cast<int>(c.count), &ticket);
             else
-                rc = mcraw_decode_batch(I.ctx, frames.data() + c.first, static_cast<int>(c.count), MCRAW_MEM_HOST, nullptr,
-                                        written.data() + c.first, status.data() + c.first);
+                rc = mcraw_pool_decode_batch(I.pool, frames.data() + c.first, static_cast<int>(c.count),
+                                             written.data() + c.first, status.data() + c.first);
         }
         if (post.flags)
-            (void)mcraw_ctx_set_post(I.ctx, nullptr);
+            (void)mcraw_pool_set_post(I.pool, nullptr);
         if (rc != 0)
-            throw IOException(std::string("GPU decode failed: ") + mcraw_last_error());
+            throw IOException(std::string("GPU decode failed: ") + mcraw_pool_last_error());
         if (direct) {
-            finishQueued(); // chunk ci-1
-            queued.ticket = ticket;
+            mcraw_pool_ticket *prev = queued.ticket;
+            const size_t prevCi = queued.ci;
+            queued.ticket = ticket; // owned from here on, whatever chunk ci-1 turns out to be
             queued.ci = ci;
+            finishTicket(prev, prevCi);
         } else {
             checkChunk(ci);
             copying[ci % noutslots] = std::async(std::launch::async, copyOut, ci);
@@ -617,7 +662,9 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
     }
     {
         const auto t0 = now();
-        finishQueued();
+        mcraw_pool_ticket *lastTicket = queued.ticket;
+        queued.ticket = nullptr;
+        finishTicket(lastTicket, queued.ci);
         tDecode += ms(t0, now());
     }
     const auto t1 = now();

@@ -80,6 +80,14 @@ public:
     void loadFrames(const std::vector<Timestamp> &timestamps, std::vector<std::vector<uint8_t>> &outData,
                     std::vector<nlohmann::json> &outMetadata, const FrameOutput &output);
 
+    // The GPUs loadFrames / loadFramesInto shard their batches over: frame i of a batch is decoded by device
+    // devices[i mod size], each device fed by its own host thread (bound to the GPU's NUMA node) from pinned
+    // staging on that node; the result does not depend on the set.  Default (never called, or an empty list):
+    // the environment -- MCRAW_DEVICES ("all" or "0,1,5"), else MCRAW_DEVICE, else the current HIP device.
+    // This is the many-GPU form of the loop the reference runs frame by frame (example.cpp:187-195).
+    void useDevices(const std::vector<int> &devices);
+    int deviceCount(); // members of the pool in use (creates it)
+
     // JSON of one frame without decoding it (width, height, compressionType ...: what sizes a buffer).
     void loadFrameMetadata(const Timestamp timestamp, nlohmann::json &outMetadata);
 

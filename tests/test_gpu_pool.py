@@ -1,0 +1,129 @@
+"""GPU (-m gpu): the device pool (several GPUs behind one handle, frame i -> member i mod G).  The box has ONE
+GPU: pools of 2 and 3 members are built from repeated device indices, which runs the whole sharded path -- one
+context, one host thread and one set of staging slices per member -- and must give exactly the results of G = 1."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import _libs as L
+import motioncam_decoder_amd as M
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXPORT = os.path.join(ROOT, "motioncam_decoder_amd", "lib", "mcraw_export")
+
+
+def _batch(n):
+    items = []
+    for i in range(n):
+        w, h = ((256, 32), (320, 48), (192, 16))[i % 3]
+        img = L.natural_image_np(w, h, 12, 12.0, 7000 + i)
+        typ = 6 if i % 4 == 3 else 7
+        items.append((typ, img, L.encode7(img) if typ == 7 else L.encode6(img)))
+    return items
+
+
+@pytest.mark.parametrize("devices", [None, [0], [0, 0], [0, 0, 0]])
+def test_pool_results_do_not_depend_on_its_size(devices):
+    pool = M.Pool(devices)
+    try:
+        assert pool.size == (len(devices) if devices else 1) and all(d == 0 for d in pool.devices())
+        items = _batch(11)
+        outs = [np.full(it[1].size + 8, 0xA5A5, np.uint16) for it in items]
+        descs = [(it[2].ctypes.data, it[2].size, it[1].shape[1], it[1].shape[0], it[0], o.ctypes.data, it[1].size)
+                 for it, o in zip(items, outs)]
+        frames = M.Context.make_frames(descs)
+        for use_ticket in (False, True):
+            for o in outs:
+                o[:] = 0xA5A5
+            written, status = pool.wait(pool.decode_batch_async(frames)) if use_ticket else pool.decode_batch(frames)
+            assert status == [0] * len(items) and written == [it[1].size for it in items]
+            for it, o in zip(items, outs):
+                assert np.array_equal(o[: it[1].size].reshape(it[1].shape), it[1]) and (o[it[1].size:] == 0xA5A5).all()
+        # a broken frame is its own business, whichever member gets it
+        bad = items[4][2][: items[4][2].size // 2].copy()
+        descs[4] = (bad.ctypes.data, bad.size) + descs[4][2:]
+        written, status = pool.decode_batch(M.Context.make_frames(descs))
+        assert status[4] != 0 and written[4] == 0
+        assert all(s == 0 for i, s in enumerate(status) if i != 4)
+        # pinned memory from a member's own thread
+        p = pool.host_alloc(pool.size - 1, 1 << 20)
+        assert p
+        C.memset(p, 0x5A, 1 << 20)
+        M.load().mcraw_host_free(p)
+    finally:
+        pool.close()
+
+
+def test_pool_with_post_stage():
+    pool = M.Pool([0, 0])
+    try:
+        items = [it for it in _batch(6) if it[0] == 7]
+        black = [60, 61, 62, 63]
+        outs, descs = [], []
+        for typ, img, buf in items:
+            h, w = img.shape
+            rb = L.post_row_bytes(w, True)
+            o = np.zeros(h * rb, np.uint8)
+            outs.append(o)
+            descs.append((buf.ctypes.data, buf.size, w, h, typ, o.ctypes.data, (h * rb + 1) // 2))
+        pool.set_post(black=black, pack12=True)
+        written, status = pool.decode_batch(M.Context.make_frames(descs))
+        pool.set_post()
+        assert status == [0] * len(items)
+        for (typ, img, buf), o in zip(items, outs):
+            assert np.array_equal(o.reshape(img.shape[0], -1), L.oracle_post(img, black, True))
+    finally:
+        pool.close()
+
+
+@pytest.fixture(scope="module")
+def clip(tmp_path_factory):
+    d = tmp_path_factory.mktemp("poolclip")
+    frames, images = [], {}
+    for i in range(9):
+        w, h = ((640, 480), (1920, 1080), (800, 600))[i % 3]
+        img = L.natural_image_np(w, h, 12, 12.0, 7100 + i)
+        typ = 6 if i % 3 == 2 else 7
+        ts = 1000 * (i + 1)
+        frames.append((ts, typ, w, h, L.encode7(img) if typ == 7 else L.encode6(img)))
+        images[ts] = img
+    return L.write_mcraw(str(d / "clip.mcraw"), frames, []), images
+
+
+@pytest.mark.parametrize("devs", ["0", "0,0", "0,0,0"])
+@pytest.mark.parametrize("pinned", [False, True])
+def test_facade_over_pools_of_several_members(clip, tmp_path, devs, pinned):
+    path, images = clip
+    if not os.path.exists(EXPORT):
+        from motioncam_decoder_amd import build
+        build.build_host()
+    env = dict(os.environ, MCRAW_DEVICES=devs)
+    r = subprocess.run([EXPORT, path, "-o", str(tmp_path)] + (["--pinned"] if pinned else []), capture_output=True, text=True,
+                       timeout=300, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    for i, ts in enumerate(sorted(images)):
+        got = np.fromfile(str(tmp_path / ("frame_%06d.u16" % i)), dtype=np.uint16)
+        assert np.array_equal(got.reshape(images[ts].shape), images[ts]), (devs, pinned, i)
+
+
+def test_failing_chunk_with_later_chunks_in_flight(tmp_path):
+    """loadFramesInto, several chunks, a corrupt frame in the FIRST one: the chunk queued behind it is still
+    waited for before the exception leaves (its ticket is owned before the first is waited for), the tool
+    reports the failure and exits -- no hang, no crash."""
+    frames = []
+    for i in range(12):  # 12 MP frames: about five per 192 MB staging chunk
+        img = L.synth_image(4032, 3024, 12, 1, 12.0, 7200 + i)
+        buf = L.encode7(img)
+        if i == 1:
+            buf = buf[: buf.size // 2].copy()
+        frames.append((1000 * (i + 1), 7, 4032, 3024, buf))
+    path = L.write_mcraw(str(tmp_path / "bad.mcraw"), frames, [])
+    for devs in ("0", "0,0"):
+        r = subprocess.run([EXPORT, path, "-o", str(tmp_path), "--pinned", "--no-write"], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, MCRAW_DEVICES=devs), cwd=str(tmp_path))
+        assert r.returncode != 0
+        assert "Failed to uncompress frame" in (r.stderr + r.stdout)

@@ -34,7 +34,7 @@ def test_facade_exports_reference_api(host_lib):
 def test_facade_has_no_cpu_codec(host_lib):
     # the facade forwards to the C ABI; it must not carry a decoder of its own
     und = subprocess.run(["nm", "-DC", "--undefined-only", host_lib], capture_output=True, text=True, check=True).stdout
-    assert "mcraw_decode7" in und and "mcraw_decode6" in und and "mcraw_decode_batch" in und
+    assert "mcraw_decode7" in und and "mcraw_decode6" in und and "mcraw_pool_decode_batch" in und
     for f in ("Decoder.cpp", "RawData.cpp"):
         src = open(os.path.join(ROOT, "motioncam_decoder_amd", "host", f)).read()
         assert "oracle" not in src.lower() and "simde" not in src.lower()

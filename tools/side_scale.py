@@ -22,7 +22,7 @@ tin = [torch.from_numpy(bufs[i % 4]).to(dev) for i in range(nmax)]
 tout = torch.zeros(nmax * w * h * 2, dtype=torch.uint8, device=dev)
 for n in [int(x) for x in os.environ.get("NS", "1,2,16,64,120,128,180,240,360,480").split(",")]:
     frames = M.Context.make_frames([(tin[i].data_ptr(), tin[i].numel(), w, h, 7, tout.data_ptr() + i * w * h * 2, w * h) for i in range(n)])
-    ctx.decode_batch(frames)
+    ctx.decode_batch(frames, want_status=False); torch.cuda.synchronize()
     for k in M.KERNELS:
         ctx.kernel_ms(k, reset=True)
     reps = 5
