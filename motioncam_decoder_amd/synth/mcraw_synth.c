@@ -117,12 +117,22 @@ int mcraw_synth_pack_block7(uint8_t *out, int bits, const uint16_t v[64])
 /* Side stream: u32 count, then per 64 entries {hbits<<4|ref>>8, ref&255, block}.
  * `vals` has `padded` entries (multiple of 64); `count` is the value written to
  * the count field. */
-static size_t put_side_stream7(uint8_t *out, const uint16_t *vals, size_t padded, uint32_t count)
+static size_t put_side_stream7(uint8_t *out, const uint16_t *vals, size_t padded, uint32_t count, int extra_records)
 {
     size_t o = 0;
     wr_u32le(out, count);
     o += 4;
-    for (size_t r = 0; r < padded; r += 64) {
+    for (size_t r = 0; r < padded + 64 * (size_t)extra_records; r += 64) {
+        if (r >= padded) { /* records behind the ones the frame uses: entries 7, 8, 9, ... (never read by a decoder) */
+            uint16_t res[64];
+            for (int i = 0; i < 64; i++)
+                res[i] = (uint16_t)(i & 7);
+            out[o] = (uint8_t)((3 << 4) | 0);
+            out[o + 1] = 7;
+            o += 2;
+            o += (size_t)mcraw_synth_pack_block7(out + o, 3, res);
+            continue;
+        }
         unsigned mn = 65535, mx = 0;
         for (int i = 0; i < 64; i++) {
             if (vals[r + i] < mn)
@@ -150,14 +160,20 @@ size_t mcraw_synth_bound7(int width, int height)
 {
     size_t encW = ((size_t)width + 63) / 64 * 64, encH = ((size_t)height + 3) / 4 * 4;
     size_t nblk = encW * encH / 64, padded = (nblk + 63) / 64 * 64;
-    return 16 + nblk * 128 + 2 * (4 + padded / 64 * 130) + 64;
+    return 16 + nblk * 128 + 2 * (4 + (padded / 64 + 3) * 130) + 64 + 64;
 }
 
 /* Encode a width x height uint16 Bayer mosaic as a type-7 frame buffer.
  *   min_bits : optional per-block lower bound on `bits` (NULL = natural), to
  *              force storage classes; indexed like the bits side stream.
  *   flags    : bit0 = write the UNROUNDED entry count in the side streams
- *              (real files may; the reference then overflows).
+ *              (real files may; the reference then overflows);
+ *              layouts other writers may produce (the decoder takes every position from the header,
+ *              lib/RawData.cpp:500-524):
+ *              bit1 = the refs stream in front of the bits stream;
+ *              bit2 = unused bytes (0xEE) between payload and streams, between the streams and behind
+ *                     them (13, 5 and 3 bytes: the streams then start on odd addresses);
+ *              bit3 = three more records than the frame uses in each stream, counted in its entry count.
  * Returns bytes written (0 on bad arguments). */
 size_t mcraw_synth_encode7(uint8_t *out, size_t cap, const uint16_t *img, int width, int height,
                            const uint8_t *min_bits, int flags)
@@ -206,13 +222,23 @@ size_t mcraw_synth_encode7(uint8_t *out, size_t cap, const uint16_t *img, int wi
                 refs[m] = (uint16_t)mn;
                 o += (size_t)mcraw_synth_pack_block7(out + o, nb, s);
             }
-    uint32_t count = (flags & 1) ? (uint32_t)nblk : (uint32_t)padded;
+    const int extra = (flags & 8) ? 3 : 0;
+    uint32_t count = ((flags & 1) ? (uint32_t)nblk : (uint32_t)padded) + 64u * (uint32_t)extra;
     wr_u32le(out + 0, (uint32_t)encW);
     wr_u32le(out + 4, (uint32_t)encH);
-    wr_u32le(out + 8, (uint32_t)o);
-    o += put_side_stream7(out + o, bits, padded, count);
-    wr_u32le(out + 12, (uint32_t)o);
-    o += put_side_stream7(out + o, refs, padded, count);
+    if (flags & 4) {
+        memset(out + o, 0xEE, 13);
+        o += 13;
+    }
+    for (int k = 0; k < 2; k++) {
+        const int which = (flags & 2) ? 1 - k : k; /* 0 = bits, 1 = refs */
+        wr_u32le(out + (which ? 12 : 8), (uint32_t)o);
+        o += put_side_stream7(out + o, which ? refs : bits, padded, count, extra);
+        if (flags & 4) {
+            memset(out + o, 0xEE, k ? 3 : 5);
+            o += k ? 3 : 5;
+        }
+    }
     free(bits);
     free(refs);
     return o;
@@ -223,7 +249,7 @@ size_t mcraw_synth_encode7(uint8_t *out, size_t cap, const uint16_t *img, int wi
 size_t mcraw_synth_bound6(int width, int height)
 {
     size_t padded = ((size_t)width + 31) / 32 * 32;
-    return padded / 16 * 34 * (size_t)height + 16;
+    return padded / 16 * 34 * (size_t)height + 16 + 5 * ((size_t)height / 8 + 2);
 }
 
 /* MSB-first bit writer for one 16-sample legacy block. */
@@ -290,7 +316,17 @@ size_t mcraw_synth_encode6(uint8_t *out, size_t cap, const uint16_t *img, int wi
                 o += 2;
                 o += (size_t)pack_block6(out + o, nb, s);
             }
-    if (flags & 1) {
+    if (flags & 2) { /* a trailer of many restart records, one per 8 rows ([u32 BE position][0xFF], RawData_Legacy.cpp:455-469) */
+        out[o++] = 0x00;
+        for (int y = 0; y < height; y += 8) {
+            uint32_t pos = (uint32_t)((size_t)y * 977u);
+            out[o++] = (uint8_t)(pos >> 24);
+            out[o++] = (uint8_t)(pos >> 16);
+            out[o++] = (uint8_t)(pos >> 8);
+            out[o++] = (uint8_t)pos;
+            out[o++] = 0xFF;
+        }
+    } else if (flags & 1) {
         uint32_t pos = (uint32_t)(o / 2);
         out[o++] = 0x00;
         out[o++] = (uint8_t)(pos >> 24);

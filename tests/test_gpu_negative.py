@@ -191,3 +191,67 @@ def test_replanned_frames_in_host_memory_batches(gpu_ctx):
                 want = L.oracle_post(img, black, pack12)
                 assert np.array_equal(o[: h * rb].reshape(h, rb), want), (black, pack12, use_ticket, w, h)
                 assert (o[h * rb:] == 0xA5).all()
+
+
+def _geometry_and_aliased_cases():
+    """(name, type, w, h, buffer, expected image): a frame coded larger than the caller's window, and a frame
+    whose two side streams share bytes -- both decoded by the reference (the header alone says where things are)."""
+    big = L.natural_image_np(320, 24, 12, 12.0, 11)
+    cases = [("window", 7, 200, 16, L.encode7(big), big[:16, :200])]
+    w, h = 256, 16
+    img = np.full((h, w), 5, np.uint16)
+    nblk = (w // 64) * (h // 4) * 4
+    enc = L.encode7(img, np.full(nblk, 5, np.uint8))
+    bits_off = int(np.frombuffer(enc[8:12].tobytes(), np.uint32)[0])
+    nrec, m = (nblk + 63) // 64, 3
+    tail = np.concatenate([_u32(nrec * 64), np.tile(np.array([0, 5], np.uint8), nrec + m + 4)])
+    buf = np.concatenate([enc[:bits_off], tail]).copy()
+    buf[12:16] = _u32(bits_off + 4 + 2 * m)
+    cases.append(("aliased", 7, w, h, buf, img))
+    plain = L.natural_image_np(256, 16, 12, 12.0, 12)
+    cases.append(("plain", 7, 256, 16, L.encode7(plain), plain))
+    return cases
+
+
+def test_status_less_device_batches_are_resolved_by_synchronize(gpu_ctx):
+    """No status requested: frames whose header asks for more than the plan gave them are decoded by
+    mcraw_ctx_synchronize (or when their slot comes round again), not left failed."""
+    import torch
+    dev = torch.device("cuda:0")
+    cases = _geometry_and_aliased_cases()
+    for rounds in (1, 7):  # 7 > the slot ring: the first batches are settled when their slots are taken again
+        keep = []
+        for r in range(rounds):
+            ins, outs, descs = [], [], []
+            for name, typ, w, h, buf, want in cases:
+                ti = torch.from_numpy(buf).to(dev)
+                to = torch.full((w * h * 2 + 16,), 0xA5, dtype=torch.uint8, device=dev)
+                ins.append(ti)
+                outs.append(to)
+                descs.append((ti.data_ptr(), ti.numel(), w, h, typ, to.data_ptr(), w * h))
+            torch.cuda.synchronize()
+            assert gpu_ctx.decode_batch(M.Context.make_frames(descs), want_status=False) is None
+            keep.append((ins, outs))
+        status = gpu_ctx.synchronize(len(cases))
+        assert status == [0] * len(cases), [hex(s) for s in status]
+        torch.cuda.synchronize()
+        for ins, outs in keep:
+            for (name, typ, w, h, buf, want), to in zip(cases, outs):
+                a = to.cpu().numpy()
+                assert np.array_equal(a[: w * h * 2].view(np.uint16).reshape(h, w), want), (rounds, name)
+                assert (a[w * h * 2:] == 0xA5).all()
+
+
+def test_geometry_and_aliased_frames_through_async_host_batches(gpu_ctx):
+    cases = _geometry_and_aliased_cases()
+    outs, descs = [], []
+    for name, typ, w, h, buf, want in cases:
+        o = np.full(w * h + 8, 0xA5A5, np.uint16)
+        outs.append(o)
+        descs.append((buf.ctypes.data, buf.size, w, h, typ, o.ctypes.data, w * h))
+    frames = M.Context.make_frames(descs)
+    t1 = gpu_ctx.decode_batch_async(frames)
+    written, status = gpu_ctx.wait(t1)
+    assert status == [0] * len(cases) and written == [c[2] * c[3] for c in cases]
+    for (name, typ, w, h, buf, want), o in zip(cases, outs):
+        assert np.array_equal(o[: w * h].reshape(h, w), want) and (o[w * h:] == 0xA5A5).all(), name

@@ -81,3 +81,62 @@ def test_frame_checksums_do_not_depend_on_the_gpu_count(gpu_ctx):
                 got[g] = shard.frame_checksum(out[k])
             del t_out
         assert [got[i] for i in range(total)] == want, world
+
+
+def test_config5_at_its_stated_size_120_frames_of_8k_in_one_batch(gpu_ctx):
+    """BASELINE config 5, one rank's share: 120 frames of 7680x4320 12-bit in ONE batch (8 GB of output).  Every
+    frame is compared on the device with the image the encoder was given; sampled frames against the oracle."""
+    import torch
+    import motioncam_decoder_amd as M
+    dev = torch.device("cuda:0")
+    w, h, n, distinct = 7680, 4320, 120, 4
+    imgs = [L.synth_image(w, h, 12, 1, 12.0, 5000 + i) for i in range(distinct)]
+    bufs = [L.encode7(im) for im in imgs]
+    for k in (0, 3):
+        ret, out = L.oracle_decode7(bufs[k], w, h)
+        assert ret == w * h and np.array_equal(out, imgs[k])
+    t_exp = [torch.from_numpy(im.view(np.int16)).to(dev) for im in imgs]
+    t_in = [torch.from_numpy(bufs[i % distinct]).to(dev) for i in range(n)]  # every frame at its own address
+    t_out = torch.zeros(n * w * h, dtype=torch.int16, device=dev)
+    descs = [(t_in[i].data_ptr(), t_in[i].numel(), w, h, 7, t_out.data_ptr() + 2 * i * w * h, w * h) for i in range(n)]
+    written, status = gpu_ctx.decode_batch(M.Context.make_frames(descs))
+    assert status == [0] * n and written == [w * h] * n
+    out = t_out.view(n, h, w)
+    for i in range(n):
+        assert torch.equal(out[i], t_exp[i % distinct]), i
+    # the same batch again without statuses (the path bench.py --config 5 times), then the statuses
+    t_out.zero_()
+    assert gpu_ctx.decode_batch(M.Context.make_frames(descs), want_status=False) is None
+    assert gpu_ctx.synchronize(n) == [0] * n
+    torch.cuda.synchronize()
+    assert all(torch.equal(out[i], t_exp[i % distinct]) for i in (0, 59, 119))
+
+
+def test_config3_host_memory_mode_at_240_frames_every_frame_compared(gpu_ctx):
+    """BASELINE config 3 as stated: 240 UHD 12-bit frames, pinned host buffers in and out, H2D / decode / D2H
+    overlapped on the library's streams -- all 240 outputs compared."""
+    import ctypes as C
+    import motioncam_decoder_amd as M
+    lib = M.load()
+    w, h, n, distinct = 3840, 2160, 240, 6
+    imgs = [L.synth_image(w, h, 12, i % 2, 12.0, 3000 + i) for i in range(distinct)]  # Nat and U alternate
+    bufs = [L.encode7(im) for im in imgs]
+    ins, outs = [], []
+    try:
+        descs = []
+        for i in range(n):
+            b = bufs[i % distinct]
+            pi, po = lib.mcraw_host_alloc(b.size), lib.mcraw_host_alloc(w * h * 2)
+            assert pi and po
+            ins.append(pi)
+            outs.append(po)
+            C.memmove(pi, b.ctypes.data, b.size)
+            descs.append((pi, b.size, w, h, 7, po, w * h))
+        written, status = gpu_ctx.decode_batch(M.Context.make_frames(descs), mem=M.MEM_HOST)
+        assert status == [0] * n and written == [w * h] * n
+        for i in range(n):
+            got = np.ctypeslib.as_array(C.cast(outs[i], C.POINTER(C.c_uint16)), shape=(h, w))
+            assert np.array_equal(got, imgs[i % distinct]), i
+    finally:
+        for p in ins + outs:
+            lib.mcraw_host_free(p)
