@@ -400,13 +400,14 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
 
     // Type-7 frames need no upload: k7_side reads their plans straight from this pinned image and every status
     // word of theirs is written by a plain store.  The legacy kernels take their tables (and zeroed status words) from HBM.
-    if (n6)
+    static const bool upload_plans = std::getenv("MCRAW_PLAN_UPLOAD") != nullptr; // timing experiment: plans through HBM
+    if (n6 || upload_plans)
         HIP_TRY(hipMemcpyAsync(dev, img, L.upload_bytes, hipMemcpyHostToDevice, st));
 
     // ---- launches -----------------------------------------------------------
     if (n7) {
         Work7 W{};
-        W.plans = reinterpret_cast<const Plan7 *>(img + L.plans7); // pinned host memory, device-visible at the same address
+        W.plans = reinterpret_cast<const Plan7 *>((upload_plans ? dev : img) + L.plans7); // pinned host memory, device-visible at the same address
         W.status = reinterpret_cast<int32_t *>(dev + L.status);
         W.frames = reinterpret_cast<Frame7 *>(dev + w_frames);
         W.nstatus = static_cast<uint32_t>(nstatus);
