@@ -155,6 +155,9 @@ int mcraw_pool_ticket_wait(mcraw_pool_ticket *ticket, size_t *written, int32_t *
  * (synchronises). */
 #define MCRAW_PROFILE_ONLY(id) (2 << (id))
 int mcraw_ctx_profile(mcraw_ctx *ctx, int enable);
+/* Bracket only every n-th launch of a profiled kernel (n >= 1; default 1): an event pair costs the stream
+ * several microseconds, a sample of the launches gives the same average duration. */
+int mcraw_ctx_profile_every(mcraw_ctx *ctx, int n);
 int mcraw_ctx_kernel_ms(mcraw_ctx *ctx, int id, double *ms, int *launches, int reset);
 
 /* Optional stage fused behind the decode, for consumers that take the mosaic further on the

@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "mcraw_ctx_create", "mcraw_ctx_destroy", "mcraw_last_error", "mcraw_decode7", "mcraw_decode6",
     "mcraw_decode_batch", "mcraw_ctx_synchronize", "mcraw_ctx_profile", "mcraw_ctx_kernel_ms",
     "mcraw_host_alloc", "mcraw_host_free", "mcraw_ctx_set_post", "mcraw_decode_batch_async", "mcraw_ticket_wait",
-    "mcraw_shard_of", "mcraw_shard_count", "mcraw_pool_create", "mcraw_pool_destroy", "mcraw_pool_last_error",
+    "mcraw_ctx_profile_every", "mcraw_shard_of", "mcraw_shard_count", "mcraw_pool_create", "mcraw_pool_destroy", "mcraw_pool_last_error",
     "mcraw_pool_size", "mcraw_pool_device", "mcraw_pool_numa_cpus", "mcraw_pool_ctx", "mcraw_pool_set_post",
     "mcraw_pool_host_alloc", "mcraw_pool_decode_batch", "mcraw_pool_decode_batch_async", "mcraw_pool_ticket_wait",
 ]
@@ -104,6 +104,8 @@ def load():
     lib.mcraw_ctx_synchronize.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
     lib.mcraw_ctx_profile.restype = C.c_int
     lib.mcraw_ctx_profile.argtypes = [C.c_void_p, C.c_int]
+    lib.mcraw_ctx_profile_every.restype = C.c_int
+    lib.mcraw_ctx_profile_every.argtypes = [C.c_void_p, C.c_int]
     lib.mcraw_ctx_kernel_ms.restype = C.c_int
     lib.mcraw_ctx_kernel_ms.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int]
     lib.mcraw_host_alloc.restype = C.c_void_p
@@ -313,8 +315,9 @@ class Context:
         if rc != 0:
             raise McrawError("mcraw_ctx_set_post failed (%d): %s" % (rc, self._lib.mcraw_last_error().decode()))
 
-    def profile(self, enable=True, only=None):
-        """Bracket kernel launches with events: all kernels, or just the names in `only`."""
+    def profile(self, enable=True, only=None, every=1):
+        """Bracket kernel launches with events: all kernels, or just the names in `only`; every `every`-th launch."""
+        self._lib.mcraw_ctx_profile_every(self._h, max(1, int(every)))
         if only:
             mode = 0
             for name in only:

@@ -123,6 +123,7 @@ struct mcraw_ctx {
     Slot rslot;          // frames planned a second time (always drained before the call returns)
     hipStream_t aux = nullptr; // deferred second plans of batches whose caller stream is not known any more
     uint32_t profile = 0; // bit id: bracket launches of kernel id with events
+    uint32_t profile_every = 1, profile_tick[MCRAW_K_COUNT] = {0}; // ... every n-th launch of it only
     Post post{0, 0, 0};   // fused post-decode stage of the batches to come (mcraw_ctx_set_post)
     KStat kstat[MCRAW_K_COUNT];
     std::vector<hipEvent_t> event_pool;
@@ -173,7 +174,7 @@ struct KTimer { // brackets one launch with events on the launch stream
     hipEvent_t a = nullptr, b = nullptr;
     KTimer(mcraw_ctx *c_, int id_, hipStream_t st_) : c(c_), id(id_), st(st_)
     {
-        if (c->profile & (1u << id)) {
+        if ((c->profile & (1u << id)) && (c->profile_tick[id]++ % c->profile_every) == 0u) {
             a = get_event(c);
             b = get_event(c);
             if (a && b)
@@ -1143,6 +1144,15 @@ int mcraw_ctx_profile(mcraw_ctx *c, int enable)
         return -1;
     std::lock_guard<std::mutex> lk(c->mu);
     c->profile = enable == 1 ? ~0u : static_cast<uint32_t>(enable) >> 1;
+    return 0;
+}
+
+int mcraw_ctx_profile_every(mcraw_ctx *c, int n)
+{
+    if (!c || n < 1)
+        return -1;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->profile_every = static_cast<uint32_t>(n);
     return 0;
 }
 

@@ -157,7 +157,10 @@ __device__ __forceinline__ Unpacked unpack8(const uint8_t *__restrict__ base, ui
 // The workgroup of the bits stream also publishes the frame's real geometry (Geo7) from the frame
 // header (RawData.cpp:500-524, 545-554): everything behind it works from the header, not from
 // the caller's width/height.
-constexpr uint32_t SIDE_T = 512;                            // threads per workgroup
+#ifndef MCRAW_SIDE_T
+#define MCRAW_SIDE_T 512
+#endif
+constexpr uint32_t SIDE_T = MCRAW_SIDE_T;                   // threads per workgroup
 #ifndef MCRAW_SIDE_LPT
 #define MCRAW_SIDE_LPT 4
 #endif
