@@ -99,3 +99,24 @@ def test_container_reader_matches_reference_contract(probe):
             open(p, "wb").write(content)
         rc, out = _probe(exe, p)
         assert rc == 1 and out and out[0].startswith(want), (name, out)
+
+
+def test_reference_container_vocabulary_compiles_and_reads_a_file(tmp_path):
+    """host/include/motioncam/Container.hpp is source compatible with the reference header of that name
+    (lib/include/motioncam/Container.hpp:22-72): a reader written with the reference's type, member, enumerator
+    and constant names (tests/cpp/container_compat.cpp) compiles against it and walks a synthetic file."""
+    import numpy as np
+    import _libs as L
+    exe = str(tmp_path / "container_compat")
+    host = os.path.join(ROOT, "motioncam_decoder_amd", "host")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(host, "include"), "-o", exe,
+                    os.path.join(ROOT, "tests", "cpp", "container_compat.cpp")], check=True)
+    frames = []
+    for i, ts in enumerate((3000, 1000, 2000)):
+        img = L.natural_image_np(128, 8, 12, 12.0, 40 + i)
+        frames.append((ts, 7 if i != 1 else 6, 128, 8, L.encode7(img) if i != 1 else L.encode6(img)))
+    audio = [(111, np.arange(64, dtype=np.int16)), (None, np.arange(64, dtype=np.int16))]
+    path = L.write_mcraw(str(tmp_path / "c.mcraw"), frames, audio)
+    r = subprocess.run([exe, path], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stderr)
+    assert r.stdout.strip() == "frames 3 audio 2 first_ts 1000"
