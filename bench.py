@@ -295,7 +295,7 @@ def cpu_baseline(L, wl, seconds):
                       "%.1f s on %d threads + %.1f s on 1 thread" % (n, wl.w, wl.h, 12, res["all_s"], cores, res["one_s"])}
 
 
-def pcie_inclusive(M, L, ctx, wl, comm, link=None, nframes=240, reps=2, pack12=False):
+def pcie_inclusive(M, L, ctx, wl, comm, link=None, nframes=240, reps=2, pack12=False, bits=None):
     """End-to-end rate when the boundary hands over HOST buffers (never `value`): frames in pinned
     memory -> H2D -> decode -> D2H into pinned memory, sub-batches pipelined on the context's
     streams (mcraw_decode_batch, MCRAW_MEM_HOST).  pack12: with the fused 12-bit strip stage, which
@@ -303,11 +303,12 @@ def pcie_inclusive(M, L, ctx, wl, comm, link=None, nframes=240, reps=2, pack12=F
     lib = M.load()
     d = len(wl.pairs)
     n = min(nframes, wl.frames)
-    row_bytes = L.post_row_bytes(wl.w, pack12)
+    bits = bits or (12 if pack12 else None)
+    row_bytes = L.post_row_bytes(wl.w, bits=bits)
     out_bytes = wl.h * row_bytes
     ins, outs, descs = [], [], []
-    if pack12:
-        ctx.set_post(pack12=True)
+    if bits:
+        ctx.set_post(bits=bits)
     try:
         for i in range(n):
             buf = wl.pairs[i % d][1]
@@ -328,7 +329,7 @@ def pcie_inclusive(M, L, ctx, wl, comm, link=None, nframes=240, reps=2, pack12=F
         t = comm.max([t_local])[0]                 # the job's rate is set by its slowest rank
         ok = all(s == 0 for s in status)
         got = np.ctypeslib.as_array(C.cast(outs[0], C.POINTER(C.c_uint8)), shape=(wl.h, row_bytes))
-        ok = ok and np.array_equal(got, L.oracle_post(wl.pairs[0][0], None, pack12))
+        ok = ok and np.array_equal(got, L.oracle_post(wl.pairs[0][0], None, bits=bits))
         ok = bool(comm.min([1.0 if ok else 0.0])[0] > 0.5)
         in_b = sum(wl.pairs[i % d][1].size for i in range(n))
         world = comm.world
@@ -336,7 +337,7 @@ def pcie_inclusive(M, L, ctx, wl, comm, link=None, nframes=240, reps=2, pack12=F
                "frames_per_s_per_rank": round(n / t, 1), "h2d_GBs_per_rank": round(in_b / t / 1e9, 2),
                "d2h_GBs_per_rank": round(n * out_bytes / t / 1e9, 2), "bit_exact": ok,
                "note": "pinned host buffers in and out; sub-batches flow through upload stream / kernels / download stream; PCIe-bound"
-                       + ("; 12-bit strips out (mcraw_ctx_set_post)" if pack12 else "")
+                       + (("; %d-bit strips out (mcraw_ctx_set_post)" % bits) if bits else "")
                        + ("; all ranks at once" if world > 1 else "")}
         if link:
             # time the two directions need at the rates this link showed with both directions busy
@@ -513,6 +514,8 @@ def main():
             extra["pcie_link"] = link
             extra["pcie_inclusive"] = pcie_inclusive(M, L, ctx, wl, comm, link, nframes=min(240, args.frames))
             extra["pcie_inclusive_pack12"] = pcie_inclusive(M, L, ctx, wl, comm, link, nframes=min(240, args.frames), pack12=True)
+            # what 10-bit footage ships: 1.25 bytes per sample (these 12-bit frames saturate at 1023 on the way, like the oracle's)
+            extra["pcie_inclusive_pack10"] = pcie_inclusive(M, L, ctx, wl, comm, link, nframes=min(240, args.frames), bits=10)
         except Exception as e:
             extra["pcie_inclusive"] = {"error": repr(e)}
 

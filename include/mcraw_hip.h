@@ -173,6 +173,11 @@ int mcraw_ctx_kernel_ms(mcraw_ctx *ctx, int id, double *ms, int *launches, int r
  *                      still counts samples. */
 #define MCRAW_POST_BLACK  1u
 #define MCRAW_POST_PACK12 2u
+/* The same strip form at 10 or 14 bits per sample (5 bytes per 4 samples / 7 bytes per 4 samples; samples above
+ * 1023 / 16383 saturate): pick the width from the container's whiteLevel, so that 10-bit footage crosses the
+ * host link at 1.25 bytes per sample.  At most one of the three PACK flags.  `out` 2-byte aligned. */
+#define MCRAW_POST_PACK10 4u
+#define MCRAW_POST_PACK14 8u
 typedef struct mcraw_post {
     uint32_t flags;
     uint16_t black[4];

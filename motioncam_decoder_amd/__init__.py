@@ -36,7 +36,8 @@ ABI_SYMBOLS = [
     "mcraw_pool_host_alloc", "mcraw_pool_decode_batch", "mcraw_pool_decode_batch_async", "mcraw_pool_ticket_wait",
 ]
 
-POST_BLACK, POST_PACK12 = 1, 2
+POST_BLACK, POST_PACK12, POST_PACK10, POST_PACK14 = 1, 2, 4, 8
+_PACK_FLAG = {16: 0, 12: POST_PACK12, 10: POST_PACK10, 14: POST_PACK14}
 
 
 class Post(C.Structure):
@@ -187,16 +188,16 @@ class Pool:
     def host_alloc(self, member, nbytes):
         return self._lib.mcraw_pool_host_alloc(self._h, member, nbytes)
 
-    def set_post(self, black=None, pack12=False):
-        if black is None and not pack12:
+    def set_post(self, black=None, pack12=False, bits=None):
+        nb = int(bits) if bits else (12 if pack12 else 16)
+        if black is None and nb == 16:
             return self._lib.mcraw_pool_set_post(self._h, None)
         p = Post()
         if black is not None:
             p.flags |= POST_BLACK
             for i in range(4):
                 p.black[i] = int(black[i])
-        if pack12:
-            p.flags |= POST_PACK12
+        p.flags |= _PACK_FLAG[nb]
         return self._lib.mcraw_pool_set_post(self._h, C.byref(p))
 
     def decode_batch(self, frames):
@@ -298,10 +299,12 @@ class Context:
             raise McrawError("mcraw_ctx_synchronize failed (%d): %s" % (rc, self._lib.mcraw_last_error().decode()))
         return list(status)[:nframes]
 
-    def set_post(self, black=None, pack12=False):
+    def set_post(self, black=None, pack12=False, bits=None):
         """Fused post-decode stage of the batches to come: black levels (4 values, CFA order
-        (row & 1) * 2 + (col & 1)) and/or 12-bit strip rows; no arguments = the plain uint16 mosaic."""
-        if black is None and not pack12:
+        (row & 1) * 2 + (col & 1)) and/or strip rows of `bits` = 10, 12 or 14 bits per sample (pack12=True: 12);
+        no arguments = the plain uint16 mosaic."""
+        nb = int(bits) if bits else (12 if pack12 else 16)
+        if black is None and nb == 16:
             rc = self._lib.mcraw_ctx_set_post(self._h, None)
         else:
             p = Post()
@@ -309,8 +312,7 @@ class Context:
                 p.flags |= POST_BLACK
                 for i in range(4):
                     p.black[i] = int(black[i])
-            if pack12:
-                p.flags |= POST_PACK12
+            p.flags |= _PACK_FLAG[nb]
             rc = self._lib.mcraw_ctx_set_post(self._h, C.byref(p))
         if rc != 0:
             raise McrawError("mcraw_ctx_set_post failed (%d): %s" % (rc, self._lib.mcraw_last_error().decode()))

@@ -237,7 +237,9 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         }
         const uint32_t pmode = c->post.mode;
         // vector stores: 16-byte rows pieces of uint16, or 12-byte pieces of a 12-bit strip (dword aligned)
-        const bool fast = (reinterpret_cast<uintptr_t>(out) % ((pmode & POST_PACK12) ? 4 : 16) == 0) && (f.width % 8 == 0);
+        // (10- and 14-bit strips go out as 2-byte aligned pieces: any uint16 pointer will do)
+        const uintptr_t oalign = (pmode & POST_PACK12) ? 4 : (pmode & POST_PACKED) ? 2 : 16;
+        const bool fast = (reinterpret_cast<uintptr_t>(out) % oalign == 0) && (f.width % 8 == 0);
         if (f.type == MCRAW_TYPE_BLOCK) {
             Plan7 p{};
             p.in = in;
@@ -1122,7 +1124,9 @@ int mcraw_ctx_set_post(mcraw_ctx *c, const mcraw_post *post)
         c->post = Post{0, 0, 0};
         return 0;
     }
-    if ((post->flags & ~(MCRAW_POST_BLACK | MCRAW_POST_PACK12)) != 0u) {
+    const uint32_t packs = post->flags & (MCRAW_POST_PACK12 | MCRAW_POST_PACK10 | MCRAW_POST_PACK14);
+    if ((post->flags & ~(MCRAW_POST_BLACK | MCRAW_POST_PACK12 | MCRAW_POST_PACK10 | MCRAW_POST_PACK14)) != 0u ||
+        (packs & (packs - 1u)) != 0u) { // at most one strip width
         g_err = "mcraw: unknown post-stage flags";
         return -1;
     }
@@ -1134,6 +1138,10 @@ int mcraw_ctx_set_post(mcraw_ctx *c, const mcraw_post *post)
     }
     if (post->flags & MCRAW_POST_PACK12)
         p.mode |= POST_PACK12;
+    if (post->flags & MCRAW_POST_PACK10)
+        p.mode |= POST_PACK10;
+    if (post->flags & MCRAW_POST_PACK14)
+        p.mode |= POST_PACK14;
     c->post = p;
     return 0;
 }

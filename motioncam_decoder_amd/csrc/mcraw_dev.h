@@ -139,16 +139,86 @@ __device__ __forceinline__ void post_pack12(const uint32_t p[4], uint32_t o[3])
     o[2] = __builtin_amdgcn_perm(t[3], t[2], 0x04050600u);
 }
 
+// The same for B = 10 or 14 bits per sample: 8 samples -> B bytes of an MSB-first B-bit stream (TIFF/DNG
+// BitsPerSample B, FillOrder 1), samples above 2^B - 1 saturate.  The stream is assembled in four big-endian
+// words (all shifts are compile-time constants) and byte-swapped into memory order.
+template <int B>
+__device__ __forceinline__ void post_pack_be(const uint32_t p[4], uint32_t o[4])
+{
+    constexpr uint32_t MAXV = (1u << B) - 1u;
+    uint32_t s[8];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t c = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(mcraw_u16x2, p[i]),
+                                                                                  __builtin_bit_cast(mcraw_u16x2, MAXV | (MAXV << 16))));
+        s[2 * i] = c & 0xffffu;
+        s[2 * i + 1] = c >> 16;
+    }
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int off = k * B, wi = off >> 5, sh = 32 - (off & 31) - B;
+        if (sh >= 0) {
+            w[wi] |= s[k] << sh;
+        } else {
+            w[wi] |= s[k] >> (-sh);
+            w[wi + 1] |= s[k] << (32 + sh);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        o[i] = __builtin_amdgcn_perm(w[i], w[i], 0x00010203u);
+}
+
+// Bytes [0, nb) of the dwords o[] to dst, the last one masked by `last` (the cropped end of a strip row).
+__device__ __forceinline__ void post_store_bytes(uint8_t *dst, const uint32_t *o, uint32_t nb, uint32_t last, uint32_t maxb)
+{
+    for (uint32_t i = 0; i < maxb; i++)
+        if (i < nb) {
+            uint32_t b = (o[i >> 2] >> (8u * (i & 3u))) & 0xffu;
+            if (i == nb - 1u)
+                b &= last;
+            dst[i] = static_cast<uint8_t>(b);
+        }
+}
+
 // Store 8 samples (columns x..x+7, x % 8 == 0, of which the first `n` exist) of row y in the
 // post-stage layout.  `quick`: rows are dword multiples and the buffer is dword aligned (12-bit
 // form) / 16-byte friendly (16-bit form).
-template <bool NT>
+// PB: bits per output sample, a compile-time property of the kernel instance (16, 12, 10 or 14) so that every
+// instance carries one packing only.
+template <bool NT, int PB>
 __device__ __forceinline__ void post_store8(uint16_t *out, const Post &post, uint32_t width, uint32_t y, uint32_t x,
                                             uint32_t p[4], uint32_t n, bool quick)
 {
     if (post.mode & POST_BLACK)
         post_black(p, post, y);
-    if (post.mode & POST_PACK12) {
+    if (PB == 10 || PB == 14) { // 10 / 14 bytes per 8 samples; rows start on even bytes when width % 8 == 0
+        constexpr uint32_t B = PB == 10 ? 10u : 14u;
+        uint32_t o[4];
+        post_pack_be<(PB == 10 ? 10 : 14)>(p, o);
+        uint8_t *dst = reinterpret_cast<uint8_t *>(out) + static_cast<size_t>(y) * post_row_bytes(width, post.mode) + (x >> 3) * B;
+        if (quick && n == 8u) {
+            typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(2)));
+            typedef uint32_t u32x3_u __attribute__((ext_vector_type(3), aligned(2)));
+            if (PB == 10) {
+                const u32x2_u v = {o[0], o[1]};
+                *reinterpret_cast<u32x2_u *>(dst) = v;
+                *reinterpret_cast<uint16_t *>(dst + 8) = static_cast<uint16_t>(o[2]);
+            } else {
+                const u32x3_u v = {o[0], o[1], o[2]};
+                *reinterpret_cast<u32x3_u *>(dst) = v;
+                *reinterpret_cast<uint16_t *>(dst + 12) = static_cast<uint16_t>(o[3]);
+            }
+        } else { // rows off the 2-byte grid, and the cropped end of a row (a last sample may end inside a byte)
+            const uint32_t bitsn = n * B, nb = (bitsn + 7u) >> 3;
+            post_store_bytes(dst, o, nb, (bitsn & 7u) ? (0xffu << (8u - (bitsn & 7u))) & 0xffu : 0xffu, 14u);
+        }
+        return;
+    }
+    if (PB == 12) {
         uint32_t o[3];
         post_pack12(p, o);
         uint8_t *dst = reinterpret_cast<uint8_t *>(out) + static_cast<size_t>(y) * post_row_bytes(width, post.mode) + (x >> 3) * 12u;

@@ -30,11 +30,20 @@ struct Post {
 };
 constexpr uint32_t POST_BLACK = 1;  // sample = max(sample - black[row & 1][col & 1], 0)
 constexpr uint32_t POST_PACK12 = 2; // rows of min(sample, 4095) packed MSB-first, 3 bytes per 2 samples (TIFF/DNG BitsPerSample 12)
+constexpr uint32_t POST_PACK10 = 4; // ... min(sample, 1023), 5 bytes per 4 samples (BitsPerSample 10)
+constexpr uint32_t POST_PACK14 = 8; // ... min(sample, 16383), 7 bytes per 4 samples (BitsPerSample 14)
+constexpr uint32_t POST_PACKED = POST_PACK12 | POST_PACK10 | POST_PACK14;
+
+// Bits per sample of an output row.
+__host__ __device__ inline uint32_t post_bits(uint32_t mode)
+{
+    return (mode & POST_PACK12) ? 12u : (mode & POST_PACK10) ? 10u : (mode & POST_PACK14) ? 14u : 16u;
+}
 
 // Bytes of one output row of `width` samples.
 __host__ __device__ inline uint32_t post_row_bytes(uint32_t width, uint32_t mode)
 {
-    return (mode & POST_PACK12) ? (width * 12u + 7u) >> 3 : width * 2u;
+    return (width * post_bits(mode) + 7u) >> 3;
 }
 
 // Per-frame plan of the current ("type 7") encoding, written by the host into PINNED HOST memory

@@ -259,7 +259,7 @@ static_assert(ROWS_CAP <= 1024u && ROWS_CAP % 2u == 0u, "the division-free row a
 #define K6_ABL 0 // timing experiments only: 1 no stores, 3 no walk
 #endif
 
-template <bool POST>
+template <int POST> // 0 = the plain mosaic, else bits per sample of the post stage's rows
 __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, const uint32_t *__restrict__ item_base,
                                                int nframes, const Post post)
 {
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
                 o[j] = __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, va[j] | (vb[j] << 16)) + refs);
             if (POST) { // black levels / 12-bit strip rows (mcraw_dev.h); padded columns are cropped
                 if (x < width)
-                    post_store8<true>(out, post, width, y0 + dy, x, o, min(8u, width - x), fast);
+                    post_store8<true, POST>(out, post, width, y0 + dy, x, o, min(8u, width - x), fast);
                 continue;
             }
             // (y0 + dy) * width without a per-lane 32-bit multiply: a wide row (width can exceed 24
@@ -493,10 +493,16 @@ void launch_k6_resolve(const Plan6 *plans, const uint32_t *super_base, int nfram
 void launch_k6_rows(const Plan6 *plans, const uint32_t *item_base, int nframes, uint32_t nitems, const Post &post,
                     hipStream_t st)
 {
-    if (post.mode != 0u)
-        hipLaunchKernelGGL(k6_rows<true>, dim3(nitems), dim3(256), 0, st, plans, item_base, nframes, post);
-    else
-        hipLaunchKernelGGL(k6_rows<false>, dim3(nitems), dim3(256), 0, st, plans, item_base, nframes, post);
+    if (post.mode == 0u) {
+        hipLaunchKernelGGL(k6_rows<0>, dim3(nitems), dim3(256), 0, st, plans, item_base, nframes, post);
+        return;
+    }
+    switch (post_bits(post.mode)) { // one kernel instance per row format
+    case 12: hipLaunchKernelGGL(k6_rows<12>, dim3(nitems), dim3(256), 0, st, plans, item_base, nframes, post); break;
+    case 10: hipLaunchKernelGGL(k6_rows<10>, dim3(nitems), dim3(256), 0, st, plans, item_base, nframes, post); break;
+    case 14: hipLaunchKernelGGL(k6_rows<14>, dim3(nitems), dim3(256), 0, st, plans, item_base, nframes, post); break;
+    default: hipLaunchKernelGGL(k6_rows<16>, dim3(nitems), dim3(256), 0, st, plans, item_base, nframes, post); break;
+    }
 }
 
 } // namespace mcraw

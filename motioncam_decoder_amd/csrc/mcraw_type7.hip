@@ -659,14 +659,14 @@ __device__ __forceinline__ ItemS item_scalars(const Work7 &W, uint32_t item, uin
 
 // Store 8 consecutive pixels (16 B) of row y starting at column x, cropped to `width`
 // (RawData.cpp:598-608 copies `width` pixels of the coded row).
-template <bool NT = false, bool POST = false>
+template <bool NT = false, int POST = 0> // POST: 0 = the plain mosaic, else bits per sample of the post stage's rows
 __device__ __forceinline__ void store_px8(const ItemS &I, const Post &post, uint32_t y, uint32_t x, uint32_t p[4])
 {
     const uint32_t width = static_cast<uint32_t>(I.width);
     if (y >= static_cast<uint32_t>(I.rows) || x >= width)
         return;
     if (POST) { // black levels / 12-bit strip rows (mcraw_dev.h)
-        post_store8<NT>(I.out, post, width, y, x, p, min(8u, width - x), I.fast != 0u);
+        post_store8<NT, POST>(I.out, post, width, y, x, p, min(8u, width - x), I.fast != 0u);
         return;
     }
     uint16_t *dst = I.out + static_cast<size_t>(y) * static_cast<size_t>(width) + x;
@@ -702,7 +702,7 @@ __device__ __forceinline__ void store_px8(const ItemS &I, const Post &post, uint
 //
 // ABL (builds with -DMCRAW_DIAG only, env MCRAW_ABLATE): 0 = product; 1 = no global stores;
 // 2 = no unpack arithmetic; 3 (caller) = no payload loads.
-template <int ABL = 0, bool NT = false, bool POST = false>
+template <int ABL = 0, bool NT = false, int POST = 0>
 __device__ __forceinline__ void item_decode(const ItemS &I, const Post &post, uint32_t tt, uint32_t r, uint32_t k,
                                             const uint8_t *s_pay, const uint32_t *s_blk, const uint16_t *s_ref,
                                             const uint4 *s_tab)
@@ -765,7 +765,7 @@ __device__ __forceinline__ void item_decode(const ItemS &I, const Post &post, ui
 // offset), the wave stages its own span in its own LDS slice, then decodes its 16
 // tiles in four rounds of 64 lanes.  The only workgroup-wide event is the barrier
 // that publishes the shared term table.
-template <int ABL, bool NT, bool POST = false>
+template <int ABL, bool NT, int POST = 0>
 __global__ __launch_bounds__(256) void k7_tiles(const Work7 W, uint32_t total, uint32_t first_frame, uint32_t class_groups)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_pay[4][PAY_LDS];
@@ -855,8 +855,13 @@ void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st)
             if (total == 0u)
                 continue;
             const dim3 grid((total + 3) / 4);
-            if (W.post.mode != 0u) {
-                hipLaunchKernelGGL((k7_tiles<0, true, true>), grid, dim3(256), 0, st, W, total, first, groups);
+            if (W.post.mode != 0u) { // one kernel instance per row format
+                switch (post_bits(W.post.mode)) {
+                case 12: hipLaunchKernelGGL((k7_tiles<0, true, 12>), grid, dim3(256), 0, st, W, total, first, groups); break;
+                case 10: hipLaunchKernelGGL((k7_tiles<0, true, 10>), grid, dim3(256), 0, st, W, total, first, groups); break;
+                case 14: hipLaunchKernelGGL((k7_tiles<0, true, 14>), grid, dim3(256), 0, st, W, total, first, groups); break;
+                default: hipLaunchKernelGGL((k7_tiles<0, true, 16>), grid, dim3(256), 0, st, W, total, first, groups); break;
+                }
                 continue;
             }
 #ifdef MCRAW_DIAG

@@ -376,6 +376,14 @@ void Decoder::loadFramesInto(const std::vector<Timestamp> &timestamps, const std
     loadFramesImpl(timestamps, nullptr, &outBuffers, outMetadata, output);
 }
 
+int Decoder::bitsForWhiteLevel(double whiteLevel)
+{
+    for (int b : {10, 12, 14})
+        if (whiteLevel <= static_cast<double>((1 << b) - 1))
+            return b;
+    return 16;
+}
+
 void Decoder::useDevices(const std::vector<int> &devices)
 {
     mImpl->releaseGpu(); // staging lives on the old members' NUMA nodes
@@ -401,7 +409,7 @@ size_t Decoder::frameBytes(int width, int height, const FrameOutput &output)
 {
     if (width <= 0 || height <= 0)
         return 0;
-    const size_t rowBytes = output.bitsPerSample == 12 ? (static_cast<size_t>(width) * 12 + 7) / 8 : static_cast<size_t>(width) * 2;
+    const size_t rowBytes = (static_cast<size_t>(width) * static_cast<size_t>(output.bitsPerSample) + 7) / 8;
     return rowBytes * static_cast<size_t>(height);
 }
 
@@ -416,8 +424,8 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
     std::vector<std::vector<uint8_t>> &outData = outDataPtr ? *outDataPtr : noVectors;
     const bool direct = outBuffers != nullptr;
     const auto tEnter = std::chrono::steady_clock::now();
-    if (output.bitsPerSample != 16 && output.bitsPerSample != 12)
-        throw IOException("Unsupported bitsPerSample (16 or 12)");
+    if (output.bitsPerSample != 16 && output.bitsPerSample != 14 && output.bitsPerSample != 12 && output.bitsPerSample != 10)
+        throw IOException("Unsupported bitsPerSample (16, 14, 12 or 10)");
     mcraw_post post{};
     if (output.subtractBlackLevel) {
         const nlohmann::json &cm = getContainerMetadata();
@@ -432,6 +440,10 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
     }
     if (output.bitsPerSample == 12)
         post.flags |= MCRAW_POST_PACK12;
+    else if (output.bitsPerSample == 10)
+        post.flags |= MCRAW_POST_PACK10;
+    else if (output.bitsPerSample == 14)
+        post.flags |= MCRAW_POST_PACK14;
     const size_t n = timestamps.size();
     if (!direct)
         outData.resize(n);
@@ -468,7 +480,7 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
         f.height = height;
         f.type = type;
         f.reserved = 0;
-        const size_t rowBytes = output.bitsPerSample == 12 ? (static_cast<size_t>(width) * 12 + 7) / 8 : static_cast<size_t>(width) * 2;
+        const size_t rowBytes = (static_cast<size_t>(width) * static_cast<size_t>(output.bitsPerSample) + 7) / 8;
         outBytes[i] = rowBytes * static_cast<size_t>(height);
         f.out_capacity = (outBytes[i] + 1) / 2; // counted in uint16 units
     }

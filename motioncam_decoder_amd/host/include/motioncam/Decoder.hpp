@@ -70,13 +70,16 @@ public:
     // (mcraw_ctx_set_post) for the consumer example.cpp:55-139 stands for, a DNG writer:
     //   subtractBlackLevel  sample = max(sample - blackLevel[(row & 1) * 2 + (col & 1)], 0), levels from the
     //                       container metadata ("blackLevel", example.cpp:65) -- write BlackLevel 0 then;
-    //   bitsPerSample = 12  rows as 12-bit strips, ceil(width * 12 / 8) bytes each, MSB-first
-    //                       (SetBitsPerSample {12}, example.cpp:116-117), a quarter less to copy and store.
+    //   bitsPerSample = 10 / 12 / 14   rows as strips of that many bits per sample, ceil(width * bits / 8) bytes
+    //                       each, MSB-first (SetBitsPerSample, example.cpp:116-117): a quarter (12) to three
+    //                       eighths (10) less to copy and store.  bitsForWhiteLevel() picks the narrowest form
+    //                       that holds the container's "whiteLevel" (example.cpp:66, :91).
     struct FrameOutput {
         bool subtractBlackLevel;
-        int bitsPerSample; // 16 or 12
+        int bitsPerSample; // 16, 14, 12 or 10
         FrameOutput() : subtractBlackLevel(false), bitsPerSample(16) {}
     };
+    static int bitsForWhiteLevel(double whiteLevel);
     void loadFrames(const std::vector<Timestamp> &timestamps, std::vector<std::vector<uint8_t>> &outData,
                     std::vector<nlohmann::json> &outMetadata, const FrameOutput &output);
 

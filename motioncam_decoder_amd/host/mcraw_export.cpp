@@ -1,13 +1,14 @@
 // mcraw_export -- decode a .mcraw file on the GPU and dump what it holds.
 //
-//   mcraw_export <file.mcraw> [-n frames] [-o outdir] [--single] [--no-write] [--black] [--bits 12] [--pinned]
+//   mcraw_export <file.mcraw> [-n frames] [-o outdir] [--single] [--no-write] [--black] [--bits 10|12|14|auto] [--pinned]
 //
 // Writes outdir/frame_%06d.u16 (width*height uint16 LE, row-major Bayer mosaic) for the
 // first N frames (by timestamp) and outdir/audio.s16 (interleaved PCM), and prints one line
 // per frame with its geometry and a CRC-32 of the pixels.  Frames are decoded as one GPU
 // batch (Decoder::loadFrames); --single uses the per-frame loadFrame() path instead.
-// --black subtracts the container's black levels, --bits 12 writes frame_%06d.p12 (12-bit strip
-// rows) instead: both are done by the stage fused into the GPU decode (Decoder::FrameOutput).
+// --black subtracts the container's black levels, --bits N writes frame_%06d.pN (N-bit strip rows; auto: the
+// narrowest form that holds the container's whiteLevel) instead: both are done by the stage fused into the GPU
+// decode (Decoder::FrameOutput).
 // --pinned decodes into pinned buffers this tool allocates (Decoder::loadFramesInto: no copy-out stage).
 #include <motioncam/Decoder.hpp>
 
@@ -74,10 +75,17 @@ int main(int argc, char **argv)
         else if (!std::strcmp(argv[i], "--black"))
             output.subtractBlackLevel = true;
         else if (!std::strcmp(argv[i], "--bits") && i + 1 < argc)
-            output.bitsPerSample = std::atoi(argv[++i]);
+            output.bitsPerSample = !std::strcmp(argv[i + 1], "auto") ? -1 : std::atoi(argv[i + 1]), i++;
     }
     try {
         motioncam::Decoder decoder(input);
+        if (output.bitsPerSample < 0) { // --bits auto: the narrowest strip form that holds the container's white level
+            const nlohmann::json &cm = decoder.getContainerMetadata();
+            const auto wl = cm.find("whiteLevel");
+            output.bitsPerSample = (cm.is_object() && wl != cm.end() && wl->is_number())
+                                       ? motioncam::Decoder::bitsForWhiteLevel(wl->get<double>()) : 16;
+            std::cout << "bits per sample: " << output.bitsPerSample << std::endl;
+        }
         std::vector<motioncam::Timestamp> frames = decoder.getFrames();
         std::cout << "Found " << frames.size() << " frames" << std::endl;
         if (limit >= 0 && static_cast<size_t>(limit) < frames.size())
@@ -133,7 +141,10 @@ int main(int argc, char **argv)
                   << " frames/s, file read + GPU decode + copy out)" << std::endl;
         for (size_t i = 0; i < frames.size(); i++) {
             char name[64];
-            std::snprintf(name, sizeof(name), output.bitsPerSample == 12 ? "/frame_%06zu.p12" : "/frame_%06zu.u16", i);
+            if (output.bitsPerSample == 16)
+                std::snprintf(name, sizeof(name), "/frame_%06zu.u16", i);
+            else
+                std::snprintf(name, sizeof(name), "/frame_%06zu.p%d", i, output.bitsPerSample);
             if (!nowrite && !writeFile(outdir + name, data[i].data(), data[i].size()))
                 throw motioncam::IOException("Failed to write " + outdir + name);
             const int w = meta[i]["width"], h = meta[i]["height"], t = meta[i]["compressionType"];

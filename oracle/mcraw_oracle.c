@@ -243,10 +243,12 @@ size_t mcraw_oracle_len_used7(const uint8_t *in, size_t len)
 size_t mcraw_oracle_post(uint8_t *out, const uint16_t *img, int width, int height,
                          unsigned flags, const uint16_t black[4])
 {
-    const size_t row_bytes = (flags & 2u) ? ((size_t)width * 12 + 7) / 8 : (size_t)width * 2;
+    /* strip width: flag 2 = 12 bits, 4 = 10 bits, 8 = 14 bits per sample, none = uint16 LE */
+    const unsigned bits = (flags & 2u) ? 12u : (flags & 4u) ? 10u : (flags & 8u) ? 14u : 16u;
+    const size_t row_bytes = ((size_t)width * bits + 7) / 8;
     for (int y = 0; y < height; y++) {
         uint8_t *row = out + (size_t)y * row_bytes;
-        if (flags & 2u)
+        if (bits != 16u)
             memset(row, 0, row_bytes);
         for (int x = 0; x < width; x++) {
             unsigned v = img[(size_t)y * width + x];
@@ -254,17 +256,17 @@ size_t mcraw_oracle_post(uint8_t *out, const uint16_t *img, int width, int heigh
                 unsigned b = black[(y & 1) * 2 + (x & 1)];
                 v = v > b ? v - b : 0;
             }
-            if (flags & 2u) {
-                if (v > 4095)
-                    v = 4095;
-                size_t bit = (size_t)x * 12; /* MSB-first: sample x occupies bits [12x, 12x+12) of the row */
-                if ((bit & 7) == 0) {
-                    row[bit >> 3] = (uint8_t)(v >> 4);
-                    row[(bit >> 3) + 1] |= (uint8_t)((v & 15) << 4);
-                } else {
-                    row[bit >> 3] |= (uint8_t)(v >> 8);
-                    row[(bit >> 3) + 1] = (uint8_t)(v & 255);
-                }
+            if (bits != 16u) {
+                if (v > (1u << bits) - 1u)
+                    v = (1u << bits) - 1u;
+                /* MSB-first: sample x occupies bits [bits*x, bits*x + bits) of the row */
+                size_t bit = (size_t)x * bits;
+                uint32_t t = (uint32_t)v << (24u - bits - (unsigned)(bit & 7)); /* at most 14 + 7 bits: three bytes */
+                row[bit >> 3] |= (uint8_t)(t >> 16);
+                if ((bit >> 3) + 1 < row_bytes)
+                    row[(bit >> 3) + 1] |= (uint8_t)(t >> 8);
+                if ((bit >> 3) + 2 < row_bytes)
+                    row[(bit >> 3) + 2] |= (uint8_t)t;
             } else {
                 row[2 * x] = (uint8_t)(v & 255);
                 row[2 * x + 1] = (uint8_t)(v >> 8);

@@ -183,32 +183,42 @@ def ref_decode6(buf, w, h, **kw):
     return _decode(ref().mcraw_ref_decode6, buf, w, h, **kw)
 
 
-def post_row_bytes(w, pack12):
-    return (w * 12 + 7) // 8 if pack12 else w * 2
+def _strip_bits(pack12, bits):
+    """Bits per sample of a strip row: `bits` (10, 12, 14 or 16/None), or 12 for the older pack12=True."""
+    b = int(bits) if bits else (12 if pack12 else 16)
+    assert b in (10, 12, 14, 16)
+    return b
 
 
-def oracle_post(img, black=None, pack12=False):
+def post_row_bytes(w, pack12=False, bits=None):
+    return (w * _strip_bits(pack12, bits) + 7) // 8
+
+
+def oracle_post(img, black=None, pack12=False, bits=None):
     """The post stage (mcraw_ctx_set_post) applied to a decoded mosaic by the oracle: bytes [h, row_bytes]."""
     img = np.ascontiguousarray(img, dtype=np.uint16)
     h, w = img.shape
-    out = np.zeros((h, post_row_bytes(w, pack12)), dtype=np.uint8)
+    b = _strip_bits(pack12, bits)
+    out = np.zeros((h, post_row_bytes(w, bits=b)), dtype=np.uint8)
     bl = np.ascontiguousarray(black if black is not None else [0, 0, 0, 0], dtype=np.uint16)
-    n = oracle().mcraw_oracle_post(_ptr(out), _ptr(img), w, h, (1 if black is not None else 0) | (2 if pack12 else 0), _ptr(bl))
+    flags = (1 if black is not None else 0) | {16: 0, 12: 2, 10: 4, 14: 8}[b]
+    n = oracle().mcraw_oracle_post(_ptr(out), _ptr(img), w, h, flags, _ptr(bl))
     assert n == out.size
     return out
 
 
-def post_np(img, black=None, pack12=False):
+def post_np(img, black=None, pack12=False, bits=None):
     """Independent numpy statement of the same stage (checks the oracle's)."""
     v = img.astype(np.int64)
     h, w = v.shape
+    nb = _strip_bits(pack12, bits)
     if black is not None:
         b = np.asarray(black, dtype=np.int64).reshape(2, 2)
         v = np.maximum(v - np.tile(b, ((h + 1) // 2, (w + 1) // 2))[:h, :w], 0)
-    if not pack12:
+    if nb == 16:
         return v.astype("<u2").view(np.uint8).reshape(h, w * 2)
-    v = np.minimum(v, 4095)
-    bits = ((v[:, :, None] >> np.arange(11, -1, -1)) & 1).astype(np.uint8).reshape(h, w * 12)
+    v = np.minimum(v, (1 << nb) - 1)
+    bits = ((v[:, :, None] >> np.arange(nb - 1, -1, -1)) & 1).astype(np.uint8).reshape(h, w * nb)
     pad = (-bits.shape[1]) % 8
     if pad:
         bits = np.concatenate([bits, np.zeros((h, pad), np.uint8)], axis=1)

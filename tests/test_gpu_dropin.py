@@ -148,3 +148,15 @@ def test_reference_container_code_with_codec_swapped(container, tmp_path):
     assert len(names) == len(images) + 1
     for name in names:
         assert (a / name).read_bytes() == (b / name).read_bytes(), name
+
+
+def test_export_tool_strip_width_from_white_level(container, tmp_path):
+    """--bits auto: the container says whiteLevel 1023 -> 10-bit strips (1.25 bytes per sample over the link)."""
+    d, path, images, audio = container
+    r = _run([EXPORT, path, "-o", str(tmp_path), "--bits", "auto"], str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    assert "bits per sample: 10" in r.stdout
+    for i, ts in enumerate(sorted(images)):
+        img = images[ts]
+        got = np.fromfile(str(tmp_path / ("frame_%06d.p10" % i)), dtype=np.uint8)
+        assert np.array_equal(got.reshape(img.shape[0], -1), L.oracle_post(img, None, bits=10)), (i, ts)

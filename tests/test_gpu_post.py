@@ -12,14 +12,16 @@ import motioncam_decoder_amd as M
 pytestmark = pytest.mark.gpu
 
 
-def _run(ctx, items, black, pack12, misalign=0, mem=M.MEM_DEVICE):
+def _run(ctx, items, black, pack12, misalign=0, mem=M.MEM_DEVICE, bits=None):
     """items: (type, w, h, buf, img).  Returns the list of output byte arrays [h, row_bytes]."""
     dev = torch.device("cuda:0")
-    ctx.set_post(black=black, pack12=pack12)
+    if bits:
+        pack12 = bits
+    ctx.set_post(black=black, bits=bits if bits else (12 if pack12 else None))
     try:
         keep, descs, outs = [], [], []
         for typ, w, h, buf, img in items:
-            rb = L.post_row_bytes(w, pack12)
+            rb = L.post_row_bytes(w, bits=bits) if bits else L.post_row_bytes(w, pack12)
             cap16 = (h * rb + 1) // 2
             if mem == M.MEM_DEVICE:
                 t_in = torch.from_numpy(np.ascontiguousarray(buf)).to(dev)
@@ -39,7 +41,7 @@ def _run(ctx, items, black, pack12, misalign=0, mem=M.MEM_DEVICE):
         for (typ, w, h, buf, img), o, wr, st in zip(items, outs, written, status):
             assert st == 0 and wr == w * h, (typ, w, h, st, wr)
             a = o.cpu().numpy() if mem == M.MEM_DEVICE else o
-            rb = L.post_row_bytes(w, pack12)
+            rb = L.post_row_bytes(w, bits=bits) if bits else L.post_row_bytes(w, pack12)
             res.append(a[misalign: misalign + h * rb].reshape(h, rb))
             tail = a[misalign + h * rb: misalign + h * rb + 8]
             assert (tail == 0xA5).all(), "wrote past the strip"
@@ -107,7 +109,7 @@ def test_post_capacity_is_counted_in_strip_bytes(gpu_ctx):
 
 def test_unknown_post_flags_are_rejected(gpu_ctx):
     p = M.Post()
-    p.flags = 4
+    p.flags = 16  # (1, 2, 4, 8 are black levels and the three strip widths)
     assert gpu_ctx._lib.mcraw_ctx_set_post(gpu_ctx._h, C.byref(p)) != 0
     assert b"post" in gpu_ctx._lib.mcraw_last_error()
     # and the context still decodes plain mosaics
@@ -115,3 +117,27 @@ def test_unknown_post_flags_are_rejected(gpu_ctx):
     got = _run(gpu_ctx, items, None, False)
     for (typ, w, h, buf, img), g in zip(items, got):
         assert np.array_equal(g.view("<u2"), img)
+
+
+@pytest.mark.parametrize("bits", [10, 14])
+@pytest.mark.parametrize("black", [None, [60, 64, 68, 1000]])
+def test_post_stage_10_and_14_bit_strips(gpu_ctx, bits, black):
+    """MCRAW_POST_PACK10 / PACK14: both codecs, cropped and odd widths (rows that end inside a byte), saturation."""
+    items = _items(SHAPES, 13)
+    got = _run(gpu_ctx, items, black, False, bits=bits)
+    for (typ, w, h, buf, img), g in zip(items, got):
+        want = L.oracle_post(img, black, bits=bits)
+        assert np.array_equal(g, want), (bits, typ, w, h, np.argwhere(g != want)[:3])
+    # 2-byte aligned output addresses and host-memory batches
+    items = _items([(256, 16, 12), (1000, 21, 10)], 14)
+    for mem in (M.MEM_DEVICE, M.MEM_HOST):
+        got = _run(gpu_ctx, items, black, False, misalign=2, mem=mem, bits=bits)
+        for (typ, w, h, buf, img), g in zip(items, got):
+            assert np.array_equal(g, L.oracle_post(img, black, bits=bits)), (bits, typ, w, h, mem)
+
+
+def test_at_most_one_strip_width(gpu_ctx):
+    p = M.Post()
+    p.flags = M.POST_PACK10 | M.POST_PACK12
+    assert gpu_ctx._lib.mcraw_ctx_set_post(gpu_ctx._h, C.byref(p)) != 0
+    gpu_ctx.set_post()

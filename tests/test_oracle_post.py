@@ -28,3 +28,22 @@ def test_oracle_post_matches_numpy(w, h):
         for black in (None, [64, 64, 64, 64], [0, 1, 4095, 65535]):
             for pack12 in (False, True):
                 assert np.array_equal(L.oracle_post(img, black, pack12), L.post_np(img, black, pack12))
+
+
+def test_hand_computed_10_and_14_bit_strips():
+    # 10 bits: 0x3FF, 0x001, 0x200, 0x155 -> 1111111111 0000000001 1000000000 0101010101 = FF C0 18 01 55
+    img = np.array([[0x3FF, 0x001, 0x200, 0x155, 0x7FF]], dtype=np.uint16)  # (0x7FF saturates to 0x3FF)
+    assert L.oracle_post(img, None, bits=10).tolist() == [[0xFF, 0xC0, 0x18, 0x01, 0x55, 0xFF, 0xC0]]
+    # 14 bits: 0x3FFF, 0x0001 -> 11111111111111 00000000000001 + 4 bits of padding = FF FC 00 10
+    img = np.array([[0x3FFF, 0x0001], [0x2AAA, 0xFFFF]], dtype=np.uint16)
+    assert L.oracle_post(img, None, bits=14).tolist() == [[0xFF, 0xFC, 0x00, 0x10], [0xAA, 0xAB, 0xFF, 0xF0]]
+
+
+@pytest.mark.parametrize("w,h", [(2, 2), (8, 2), (13, 5), (77, 3), (1000, 6)])
+def test_oracle_post_10_14_matches_numpy(w, h):
+    rng = np.random.default_rng(w * 131 + h)
+    for nbits in (10, 14, 16):
+        img = rng.integers(0, 1 << nbits, size=(h, w), dtype=np.uint16)
+        for black in (None, [64, 0, 1023, 3]):
+            for bits in (10, 14):
+                assert np.array_equal(L.oracle_post(img, black, bits=bits), L.post_np(img, black, bits=bits)), (nbits, bits)
