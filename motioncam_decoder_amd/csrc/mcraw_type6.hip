@@ -150,7 +150,9 @@ __global__ __launch_bounds__(64) void k6_frame(const Plan6 *__restrict__ plans)
                 s_entry[s] = p | (n << 8);
                 if (p != DEAD) {
                     const uint32_t m = s_map[s * PHASES6 + p];
-                    n += m >> 8;
+                    // entries carry the record index in 24 bits: a stream with more records than that (the frame
+                    // itself has fewer, the host checks) saturates instead of wrapping back into the frame
+                    n = min(n + (m >> 8), 0xFFFFFFu);
                     p = m & 255u;
                 }
             }
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(64) void k6_chunks(const Plan6 *__restrict__ plans,
             s_entry[c] = p | (n << 8);
             if (p != DEAD) {
                 const uint32_t m = s_map[c * PHASES6 + p];
-                n += m >> 8;
+                n = min(n + (m >> 8), 0xFFFFFFu); // (see k6_frame)
                 p = m & 255u;
             }
         }

@@ -255,3 +255,21 @@ def test_geometry_and_aliased_frames_through_async_host_batches(gpu_ctx):
     assert status == [0] * len(cases) and written == [c[2] * c[3] for c in cases]
     for (name, typ, w, h, buf, want), o in zip(cases, outs):
         assert np.array_equal(o[: w * h].reshape(h, w), want) and (o[w * h:] == 0xA5A5).all(), name
+
+
+def test_legacy_stream_with_more_than_2_24_records_does_not_wrap_into_the_frame(gpu_ctx):
+    """A small legacy frame followed by 40 MB of two-byte records (zeros): the chunk entries carry record indices in
+    24 bits; indices past that saturate instead of wrapping, so nothing behind the frame's own records is decoded
+    over its pixels."""
+    import torch
+    dev = torch.device("cuda:0")
+    w, h = 256, 64
+    img = L.natural_image_np(w, h, 10, 4.0, 77)
+    enc = L.encode6(img)
+    buf = np.concatenate([enc, np.zeros(40 << 20, np.uint8)])
+    ret, want = L.oracle_decode6(buf, w, h)
+    assert ret == w * h and np.array_equal(want, img)
+    from _gpu import decode_batch_device
+    written, status, outs = decode_batch_device(gpu_ctx, [(6, w, h, buf)])
+    assert status == [0] and written == [w * h]
+    assert np.array_equal(outs[0], img)
