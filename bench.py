@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (default: the config's)")
     ap.add_argument("--min-seconds", type=float, default=0.5, help="timed rounds cover at least this long")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) legs")
+    ap.add_argument("--dist-backend", default="nccl", help="process-group backend (nccl = RCCL; gloo for rehearsals)")
+    ap.add_argument("--all-on-device0", action="store_true",
+                    help="rehearsal of the multi-rank path on a one-GPU box: every rank decodes on cuda:0 (use with --dist-backend gloo)")
     ap.add_argument("--stub-decode", action="store_true",
                     help="CPU rehearsal of the multi-rank protocol (gloo, no GPU, the step is a sleep): tests only")
     ap.add_argument("--distinct", type=int, default=48, help="distinct synthetic frames generated per rank")
@@ -472,6 +475,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     from motioncam_decoder_amd import benchlib
     # before the first GPU call: this process, and the pinned buffers it will first-touch, next to its GPU
+    if args.all_on_device0:
+        local = 0
     numa = benchlib.bind_to_gpu_numa(local) if world > 1 else None
     import torch
     import torch.distributed as dist_mod
@@ -481,8 +486,11 @@ def main():
     dev = torch.device("cuda", local)
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched by torch.distributed.run
     if use_dist:
-        dist_mod.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
-    comm = benchlib.Comm(dist_mod, dev)
+        if args.dist_backend == "nccl":
+            dist_mod.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        else:
+            dist_mod.init_process_group(args.dist_backend)
+    comm = benchlib.Comm(dist_mod, dev if args.dist_backend == "nccl" else "cpu")
 
     import motioncam_decoder_amd as M
     from motioncam_decoder_amd import build as B

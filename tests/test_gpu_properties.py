@@ -140,3 +140,35 @@ def test_config3_host_memory_mode_at_240_frames_every_frame_compared(gpu_ctx):
     finally:
         for p in ins + outs:
             lib.mcraw_host_free(p)
+
+
+def test_bench_multi_rank_path_on_one_gpu(tmp_path):
+    """The N > 1 path of bench.py on hardware, as far as a one-GPU box allows: two ranks launched the way the driver
+    launches them (torch.distributed.run), both decoding on cuda:0, reductions over gloo instead of RCCL.  Everything
+    else is the real thing: NUMA binding, sharded workloads, timed rounds between barriers, the host-buffer (PCIe)
+    legs on every rank at once, the rank-0 JSON line."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--frames", "24", "--distinct", "4", "--min-seconds", "0.05", "--dist-backend", "gloo", "--all-on-device0",
+           "--cpu-seconds", "0.2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["bit_exact"] is True and d["scaling"] == "weak"
+    assert d["config"]["frames_per_gpu"] == 24
+    assert abs(d["value"] / (2 * 24 * 3840 * 2160 / (d["ms_per_step"] * 1e-3) / 1e6) - 1.0) < 2e-3  # (ms_per_step is rounded)
+    assert d["roofline"]["step_frac"] > 0 and d["roofline"]["frac"] > 0
+    p = d["pcie_inclusive"]
+    assert p["bit_exact"] is True and p["frames_per_rank"] == 24 and abs(p["frames_per_s"] - 2 * p["frames_per_s_per_rank"]) < 1.0
