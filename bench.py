@@ -195,13 +195,17 @@ def link_probe(torch, dev, nbytes=256 << 20, reps=3):
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
 
     def t(fn):
-        fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
+        for _ in range(2):  # the first copies of a fresh pinned buffer run far below the link rate
             fn()
         torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / reps
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return best
 
     def both():
         with torch.cuda.stream(s1):

@@ -78,8 +78,8 @@ def test_header_geometry_differs_from_rounded_size(gpu_ctx):
 
 def test_aliased_side_streams_are_replanned(gpu_ctx):
     # A frame whose bits stream runs past the start of its refs stream (the two chains share
-    # bytes).  The reference follows each chain wherever it goes; the build's extent hint
-    # (bits stream ends at refsOffset) is wrong here, so the frame must be re-planned, not failed.
+    # bytes).  The reference follows each chain wherever it goes, and so does k7_side: a stream's
+    # extent is bounded by the frame's length only, never by where the other stream starts.
     from _gpu import decode_batch_device
     w, h, val = 256, 16, 5
     img = np.full((h, w), val, np.uint16)
