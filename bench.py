@@ -418,7 +418,7 @@ def legacy_leg(torch, ctx, M, L, dev, n=32, w=4000, h=3000, nbits=12, sigma=12.0
         ctx.decode_batch(frames, want_status=False)
     torch.cuda.synchronize()
     t = (time.perf_counter() - t0) / reps
-    kms = {k: round(ctx.kernel_ms(k, reset=True)[0] / reps, 4) for k in ("k6_maps", "k6_resolve", "k6_rows")}
+    kms = {k: round(ctx.kernel_ms(k, reset=True)[0] / reps, 4) for k in ("k6_decode",)}
     byts = sum(bufs[i % 4].size for i in range(n)) + n * w * h * 2
     return {"workload": "%d x %dx%d %d-bit type-6 frames, Nat" % (n, w, h, nbits), "ms_per_batch": round(t * 1e3, 4),
             "mpix_s": round(n * w * h / t / 1e6, 1), "in_plus_out_GBs": round(byts / t / 1e9, 1),

@@ -143,9 +143,8 @@ int mcraw_pool_ticket_wait(mcraw_pool_ticket *ticket, size_t *written, int32_t *
 #define MCRAW_K7_SIDE    0 /* side streams: chain, records, payload offsets (one launch) */
                            /* ids 1 and 2 are retired (former separate chain kernels)  */
 #define MCRAW_K7_TILES   3 /* tile decode (the roofline kernel)   */
-#define MCRAW_K6_MAPS    4 /* legacy: per-chunk transition maps   */
-#define MCRAW_K6_RESOLVE 5 /* legacy: map composition             */
-#define MCRAW_K6_ROWS    6 /* legacy: record decode               */
+                           /* ids 4 and 5 are retired (former legacy map / resolve kernels) */
+#define MCRAW_K6_DECODE  6 /* legacy: the whole decode (one launch) */
 #define MCRAW_K_COUNT    7
 
 /* hipEvent bracketing of kernel launches on the launch stream: 0 = off, 1 = every

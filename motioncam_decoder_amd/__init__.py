@@ -24,7 +24,7 @@ MEM_HOST = 1
 # status bits (include/mcraw_hip.h)
 E_ARGS, E_HEADER, E_TRUNCATED, E_SIDESTREAM, E_CAPACITY, E_DEVICE = 0x1, 0x2, 0x4, 0x8, 0x10, 0x100
 
-KERNELS = {"k7_side": 0, "k7_tiles": 3, "k6_maps": 4, "k6_resolve": 5, "k6_rows": 6}
+KERNELS = {"k7_side": 0, "k7_tiles": 3, "k6_decode": 6}
 
 # every symbol include/mcraw_hip.h declares
 ABI_SYMBOLS = [

@@ -20,11 +20,8 @@
 
 namespace mcraw {
 void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st);
-void launch_k6_maps(const Plan6 *plans, const uint32_t *item_base, int nframes, uint32_t nitems, hipStream_t st);
-void launch_k6_resolve(const Plan6 *plans, const uint32_t *super_base, int nframes, uint32_t nsuper_items,
-                       hipStream_t st);
-void launch_k6_rows(const Plan6 *plans, const uint32_t *item_base, int nframes, uint32_t nitems, const Post &post,
-                    hipStream_t st);
+void launch_k6_decode(const Plan6 *plans, const Look6 &look, uint32_t *tickets, uint32_t epoch, int nframes, uint32_t smax,
+                      const Post &post, hipStream_t st);
 } // namespace mcraw
 
 using namespace mcraw;
@@ -65,6 +62,10 @@ struct Slot {
     Buf dev_in;  // HBM staging of inputs  (MCRAW_MEM_HOST)
     Buf dev_out; // HBM staging of outputs (MCRAW_MEM_HOST)
     Buf status_host; // pinned: statuses copied back
+    // legacy frames: look-back state of k6_decode.  Never cleared after it was allocated: state words carry the epoch
+    // of the launch that wrote them.
+    Buf look;
+    uint32_t look_epoch = 0;
     // Device statuses are kept in plan order (type-7 frames, then legacy frames) so a kernel
     // finds its word from its frame index alone; `order` maps them back to the caller's
     // frame indices and `host_status` holds what the host decided on its own (bad arguments).
@@ -213,7 +214,7 @@ inline size_t carve(size_t &off, size_t bytes)
 struct Layout { // byte offsets inside the slot arena / upload image
     size_t status = 0;                                   // int32[n + 1 + n7]
     size_t plans7 = 0;                                   // Plan7[n7]
-    size_t plans6 = 0, map_base = 0, super_base = 0, row_base = 0;
+    size_t plans6 = 0, tickets = 0;
     size_t upload_bytes = 0;                             // tables end here, workspace follows
     size_t total = 0;
 };
@@ -287,7 +288,6 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
                 continue;
             }
             p.nchunks = static_cast<uint32_t>((f.len + CHUNK6 - 1) / CHUNK6);
-            p.nsuper = (p.nchunks + SUPER6 - 1) / SUPER6;
             p.fast_store = fast ? 1u : 0u;
             B.p6.push_back(p);
             B.idx6.push_back(i);
@@ -338,9 +338,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     L.status = carve(off, sizeof(int32_t) * (nstatus + n7));
     L.plans7 = carve(off, sizeof(Plan7) * n7);
     L.plans6 = carve(off, sizeof(Plan6) * n6);
-    L.map_base = carve(off, sizeof(uint32_t) * (n6 + 1));
-    L.super_base = carve(off, sizeof(uint32_t) * (n6 + 1));
-    L.row_base = carve(off, sizeof(uint32_t) * (n6 + 1));
+    L.tickets = carve(off, sizeof(uint32_t) * TICKET_STRIDE6 * n6); // k6_decode's segment counters: uploaded as zeros
     L.upload_bytes = off;
 
     // type-7 workspace: one stride for every frame (the largest frame's), so the
@@ -352,15 +350,22 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     const size_t w_bits = carve(off, Rmax * 64 * n7);
     const size_t w_refs = carve(off, Rmax * 64 * sizeof(uint16_t) * n7);
     const size_t w_grp = carve(off, sizeof(uint32_t) * (Rmax * ITEM_SPLIT + 1) * n7);
-    std::vector<size_t> w_cmap(n6), w_smap(n6), w_centry(n6), w_sentry(n6);
-    for (int k = 0; k < n6; k++) {
-        const Plan6 &p = B.p6[k];
-        w_cmap[k] = carve(off, sizeof(uint32_t) * PHASES6 * p.nchunks);
-        w_smap[k] = carve(off, sizeof(uint32_t) * PHASES6 * p.nsuper);
-        w_centry[k] = carve(off, sizeof(uint32_t) * p.nchunks);
-        w_sentry[k] = carve(off, sizeof(uint32_t) * p.nsuper);
-    }
+    uint32_t smax = 0; // segments of the longest legacy stream
+    for (const Plan6 &p : B.p6)
+        smax = std::max(smax, (p.nchunks + 4 * ROWS_CH - 1) / (4 * ROWS_CH));
     L.total = off;
+    if (n6) {
+        const size_t need = sizeof(uint64_t) * smax * static_cast<size_t>(n6);
+        if (need > s.look.cap) {
+            if (int rc = ensure(s.look, need, false))
+                return rc;
+            HIP_TRY(hipMemsetAsync(s.look.p, 0, s.look.cap, st)); // epoch 0 = never written
+        }
+        if (++s.look_epoch == 0u) { // (2^32 batches later: start over)
+            HIP_TRY(hipMemsetAsync(s.look.p, 0, s.look.cap, st));
+            s.look_epoch = 1;
+        }
+    }
 
     if (int rc = ensure(s.arena, L.total, false))
         return rc;
@@ -377,29 +382,12 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     if (n7)
         std::memcpy(img + L.plans7, B.p7.data(), sizeof(Plan7) * n7);
 
-    uint32_t *map_base = reinterpret_cast<uint32_t *>(img + L.map_base);
-    uint32_t *super_base = reinterpret_cast<uint32_t *>(img + L.super_base);
-    uint32_t *row_base = reinterpret_cast<uint32_t *>(img + L.row_base);
-    uint32_t nmap = 0, nsup = 0, nrow = 0;
-    for (int k = 0; k < n6; k++) {
-        Plan6 &p = B.p6[k];
-        p.cmap = reinterpret_cast<uint32_t *>(dev + w_cmap[k]);
-        p.smap = reinterpret_cast<uint32_t *>(dev + w_smap[k]);
-        p.centry = reinterpret_cast<uint32_t *>(dev + w_centry[k]);
-        p.sentry = reinterpret_cast<uint32_t *>(dev + w_sentry[k]);
-        p.status = reinterpret_cast<int32_t *>(dev + L.status) + 2 * n7 + k;
-        map_base[k] = nmap;
-        super_base[k] = nsup;
-        row_base[k] = nrow;
-        nmap += (p.nchunks + 11) / 12; // k6_maps: 12 chunks per workgroup
-        nsup += p.nsuper;
-        nrow += (p.nchunks + 4 * ROWS_CH - 1) / (4 * ROWS_CH); // k6_rows: ROWS_CH chunks per wave, 4 waves
-    }
-    map_base[n6] = nmap;
-    super_base[n6] = nsup;
-    row_base[n6] = nrow;
-    if (n6)
+    for (int k = 0; k < n6; k++)
+        B.p6[k].status = reinterpret_cast<int32_t *>(dev + L.status) + 2 * n7 + k;
+    if (n6) {
         std::memcpy(img + L.plans6, B.p6.data(), sizeof(Plan6) * n6);
+        std::memset(img + L.tickets, 0, sizeof(uint32_t) * TICKET_STRIDE6 * n6);
+    }
 
     // Type-7 frames need no upload: k7_side reads their plans straight from this pinned image and every status
     // word of theirs is written by a plain store.  The legacy kernels take their tables (and zeroed status words) from HBM.
@@ -432,18 +420,10 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     }
     if (n6) {
         const Plan6 *dp = reinterpret_cast<const Plan6 *>(dev + L.plans6);
-        {
-            KTimer t(c, MCRAW_K6_MAPS, st);
-            launch_k6_maps(dp, reinterpret_cast<const uint32_t *>(dev + L.map_base), n6, nmap, st);
-        }
-        {
-            KTimer t(c, MCRAW_K6_RESOLVE, st);
-            launch_k6_resolve(dp, reinterpret_cast<const uint32_t *>(dev + L.super_base), n6, nsup, st);
-        }
-        {
-            KTimer t(c, MCRAW_K6_ROWS, st);
-            launch_k6_rows(dp, reinterpret_cast<const uint32_t *>(dev + L.row_base), n6, nrow, c->post, st);
-        }
+        Look6 lk;
+        lk.res = static_cast<uint64_t *>(s.look.p);
+        KTimer t(c, MCRAW_K6_DECODE, st);
+        launch_k6_decode(dp, lk, reinterpret_cast<uint32_t *>(dev + L.tickets), s.look_epoch, n6, smax, c->post, st);
     }
     HIP_TRY(hipGetLastError());
     *status_off = L.status;
@@ -981,6 +961,7 @@ void mcraw_ctx_destroy(mcraw_ctx *c)
         if (s.pinned.p) (void)hipHostFree(s.pinned.p);
         if (s.status_host.p) (void)hipHostFree(s.status_host.p);
         if (s.arena.p) (void)hipFree(s.arena.p);
+        if (s.look.p) (void)hipFree(s.look.p);
         if (s.dev_in.p) (void)hipFree(s.dev_in.p);
         if (s.dev_out.p) (void)hipFree(s.dev_out.p);
         if (s.done) (void)hipEventDestroy(s.done);

@@ -112,18 +112,22 @@ struct Plan6 {
     uint32_t recs_per_row; // 2 * padded / 32
     uint32_t nrec;         // height * recs_per_row
     uint32_t nchunks;      // ceil(len / CHUNK6)
-    uint32_t nsuper;       // ceil(nchunks / SUPER6)
     uint32_t fast_store;
-    uint32_t *cmap;        // [nchunks][17] per-chunk transition map  (exit phase | count)
-    uint32_t *smap;        // [nsuper][17]  per-super-chunk map
-    uint32_t *centry;      // [nchunks]     resolved entry of every chunk (phase | first record)
-    uint32_t *sentry;      // [nsuper]      resolved entry of every super-chunk
     int32_t *status;
 };
 
 constexpr int CHUNK6 = 1024; // bytes of legacy stream per transition-map chunk
-constexpr int SUPER6 = 64;   // chunks per super-chunk
-constexpr int ROWS_CH = 4;   // chunks per wave of k6_rows
+constexpr int TICKET_STRIDE6 = 64; // uint32 words between the segment ticket counters of two legacy frames (256 bytes)
+constexpr int ROWS_CH = 4;   // chunks per unpacking wave of k6_decode; four such waves per workgroup = per SEGMENT
 constexpr int PHASES6 = 17;  // entry offsets 0,2,..,32 (record stride <= 34, all even)
+
+// Look-back state of the legacy frames' segments (k6_decode), in a buffer that lives as long as its slot and is never
+// cleared: every 64-bit word carries the epoch of the launch that wrote it in its high half (a poll of 64
+// predecessors reads four cache lines):
+//   res[frame * smax + segment] = state << 30 | records << 5 | phase at which the segment's last chunk is entered;
+//   state 1: records of this segment alone, 2: records of the frame up to the end of this segment
+struct Look6 {
+    uint64_t *res;
+};
 
 } // namespace mcraw

@@ -8,14 +8,14 @@
 // transition maps: record strides are even and <= 34 bytes, so a fixed 1 KiB
 // chunk of the stream can be entered at only 17 offsets ("phases" 0,2,..,32).
 //
-//   k6_maps    per chunk: table of record strides, then per phase a walk over it to the chunk end
-//              -> (exit phase, records started)
-//   k6_super   compose 64 chunk maps into one super-chunk map
-//   k6_frame   follow the true phase over the super-chunks   -> entry of every super-chunk
-//   k6_chunks  follow it over a super-chunk's 64 chunks      -> entry of every chunk
-//   k6_rows    per 4 chunks: lanes list the records of one chunk each from its true entry, then
-//              all lanes unpack them (MSB-first bitstreams, RawData_Legacy.cpp:38-370), add the
-//              references, interleave even/odd columns (:483-486) and crop the padded row (:490)
+// One kernel, one pass over the stream (k6_decode): a workgroup stages 16 chunks, walks all 17 phases of
+// each (and of the chunk in front of them) over a byte table of record strides -> per chunk and phase the exit
+// phase and the records started; finds where the TRUE chain enters its chunks -- the map of the chunk in front of a
+// chunk almost always sends all 17 phases to one exit, because a wrong chain reads payload bytes as headers and
+// falls onto the true one within a few hundred bytes -- and the index of its first record by decoupled look-back
+// over the frame's earlier workgroups; lists the records of its chunks from those entries and unpacks them
+// (MSB-first bitstreams, RawData_Legacy.cpp:38-370), adds the references, interleaves even/odd columns (:483-486)
+// and crops the padded row (:490).
 #include "mcraw_dev.h"
 
 #include "../../include/mcraw_hip.h"
@@ -27,10 +27,7 @@ constexpr uint32_t DEAD = 31; // phase value: the chain ended (a record crossed 
 // Payload bytes of a record whose header nibble is `b` (RawData_Legacy.cpp:13-32).
 __device__ __forceinline__ uint32_t len6_of(uint32_t b) { return b <= 10u ? 2u * b : 32u; }
 
-// ------------------------------------------------------------------ k6_maps
-constexpr int MAP_CH_PER_WAVE = 3;           // 3 x 17 phases = 51 of 64 lanes
-constexpr uint32_t HALF6 = CHUNK6 / 2;       // even byte positions ("half positions") per chunk
-constexpr uint32_t TAB6 = HALF6 + 32;        // stride table per chunk, padded so a finished lane still reads LDS it owns
+constexpr uint32_t HALF6 = CHUNK6 / 2; // even byte positions ("half positions") per chunk
 
 // Stride of the record whose header byte is `b`, in half positions: (2 + LEN)/2 = 1 + bits for
 // bits <= 10, 17 above (RawData_Legacy.cpp:13-32).  Four header bytes per call, one per byte lane.
@@ -42,170 +39,22 @@ __device__ __forceinline__ uint32_t stride4(uint32_t hdr4)
     return (big & 0x11111111u) | (~big & (x + 0x01010101u));
 }
 
-// One wave per 3 chunks.  All 64 lanes first turn the chunk bytes into a table of record strides
-// (one byte per even position -- the only places a header can sit); then lane (chunk, phase)
-// follows the table from its entry to the chunk end: 1 LDS read + 3 VALU per record instead of
-// decoding the header at every step of all 17 walks.
-__global__ __launch_bounds__(256) void k6_maps(const Plan6 *__restrict__ plans, const uint32_t *__restrict__ item_base,
-                                               int nframes)
+// Look-back state words are 64 bits: the launch's epoch in the high half (the state buffer is never cleared: words
+// of earlier launches carry older epochs and read as "not there yet"), the payload in the low half.  Every word is
+// complete in itself, so publishing one is a single relaxed store at device scope and needs no fence.
+constexpr uint32_t RES_AGG = 1u, RES_PREFIX = 2u; // Look6::res payload: state << 30 | records << 5 | exit phase
+constexpr uint32_t SPIN6 = 1u << 20;              // polls before a workgroup gives the frame up (never seen; a hang is worse)
+
+__device__ __forceinline__ void look_put(uint64_t *w, uint32_t epoch, uint32_t v)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_tab[4][MAP_CH_PER_WAVE * TAB6];
-
-    const int f = find_frame(blockIdx.x, item_base, nframes);
-    const Plan6 *P = plans + f;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t c0 = ((blockIdx.x - item_base[f]) * 4u + wave) * MAP_CH_PER_WAVE;
-    const uint32_t nchunks = P->nchunks, len = P->len;
-    if (c0 >= nchunks)
-        return;
-    const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
-
-    // 3 KiB of stream for this wave (reads past `len` give 0); 16 bytes -> 8 strides per lane
-    uint2 *tab2 = reinterpret_cast<uint2 *>(s_tab[wave]);
-#pragma unroll
-    for (int q = 0; q < MAP_CH_PER_WAVE; q++) {
-        const uint4 v = ld_b128(rs, (c0 + q) * CHUNK6 + lane * 16u);
-        // header candidates are bytes 0 and 2 of every dword
-        const uint32_t lo = stride4(__builtin_amdgcn_perm(v.y, v.x, 0x06040200u));
-        const uint32_t hi = stride4(__builtin_amdgcn_perm(v.w, v.z, 0x06040200u));
-        tab2[q * (TAB6 / 8u) + lane] = make_uint2(lo, hi);
-    }
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
-
-    const uint32_t sub = lane / PHASES6, ph = lane - sub * PHASES6;
-    const uint32_t c = c0 + sub;
-    if (sub >= MAP_CH_PER_WAVE || c >= nchunks)
-        return;
-    const uint8_t *tab = s_tab[wave] + sub * TAB6;
-    const uint32_t cs = c * CHUNK6;
-    // RawData_Legacy.cpp:387-388,398-399: a record must end before len-1, i.e. the record at half
-    // position q with stride d is the chain's end when cs + 2*(q + d) >= len
-    const uint32_t limq = len > cs ? (len - cs + 1u) >> 1 : 0u;
-    uint32_t q = ph, count = 0;
-    if (limq > HALF6 + 17u) { // no record of this chunk can reach `len`
-        const uint8_t *pp = tab + q, *const pe = tab + HALF6;
-        while (pp < pe) {
-            pp += *pp;
-            count++;
-        }
-        q = static_cast<uint32_t>(pp - tab);
-    } else {
-        while (q < HALF6) {
-            const uint32_t nq = q + tab[q];
-            if (nq >= limq)
-                break;
-            q = nq;
-            count++;
-        }
-    }
-    const uint32_t exitph = q < HALF6 ? DEAD : q - HALF6;
-    P->cmap[c * PHASES6 + ph] = exitph | (count << 8);
+    __hip_atomic_store(w, (static_cast<uint64_t>(epoch) << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-
-// ------------------------------------------------------------------ k6_super
-__global__ __launch_bounds__(64) void k6_super(const Plan6 *__restrict__ plans, const uint32_t *__restrict__ super_base,
-                                               int nframes)
+__device__ __forceinline__ bool look_get(const uint64_t *w, uint32_t epoch, uint32_t *v)
 {
-    __shared__ uint32_t s_map[SUPER6 * PHASES6];
-    const int f = find_frame(blockIdx.x, super_base, nframes);
-    const Plan6 *P = plans + f;
-    const uint32_t sc = blockIdx.x - super_base[f];
-    const uint32_t first = sc * SUPER6;
-    const uint32_t cnt = min(static_cast<uint32_t>(SUPER6), P->nchunks - first);
-    const uint32_t lane = threadIdx.x;
-    const uint32_t *src = P->cmap + static_cast<size_t>(first) * PHASES6;
-    for (uint32_t i = lane; i < cnt * PHASES6; i += 64u)
-        s_map[i] = src[i];
-    __syncthreads();
-    if (lane >= PHASES6)
-        return;
-    uint32_t p = lane, n = 0;
-    for (uint32_t c = 0; c < cnt && p != DEAD; c++) {
-        const uint32_t m = s_map[c * PHASES6 + p];
-        n += m >> 8;
-        p = m & 255u;
-    }
-    P->smap[sc * PHASES6 + lane] = p | (n << 8);
+    const uint64_t x = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *v = static_cast<uint32_t>(x);
+    return static_cast<uint32_t>(x >> 32) == epoch;
 }
-
-// ------------------------------------------------------------------ k6_frame
-constexpr int FRAME_PIECE = 512; // super-chunk maps staged per pass
-
-__global__ __launch_bounds__(64) void k6_frame(const Plan6 *__restrict__ plans)
-{
-    __shared__ uint32_t s_map[FRAME_PIECE * PHASES6];
-    __shared__ uint32_t s_entry[FRAME_PIECE];
-    const Plan6 *P = plans + blockIdx.x;
-    const uint32_t lane = threadIdx.x, nsuper = P->nsuper;
-    uint32_t p = 0, n = 0; // the stream starts with a record at byte 0 (RawData_Legacy.cpp:476)
-    for (uint32_t base = 0; base < nsuper; base += FRAME_PIECE) {
-        const uint32_t cnt = min(static_cast<uint32_t>(FRAME_PIECE), nsuper - base);
-        const uint32_t *src = P->smap + static_cast<size_t>(base) * PHASES6;
-        for (uint32_t i = lane; i < cnt * PHASES6; i += 64u)
-            s_map[i] = src[i];
-        __syncthreads();
-        if (lane == 0) {
-            for (uint32_t s = 0; s < cnt; s++) {
-                s_entry[s] = p | (n << 8);
-                if (p != DEAD) {
-                    const uint32_t m = s_map[s * PHASES6 + p];
-                    // entries carry the record index in 24 bits: a stream with more records than that (the frame
-                    // itself has fewer, the host checks) saturates instead of wrapping back into the frame
-                    n = min(n + (m >> 8), 0xFFFFFFu);
-                    p = m & 255u;
-                }
-            }
-        }
-        __syncthreads();
-        for (uint32_t i = lane; i < cnt; i += 64u)
-            P->sentry[base + i] = s_entry[i];
-        p = __shfl(p, 0, 64);
-        n = __shfl(n, 0, 64);
-        __syncthreads();
-    }
-    // fewer records than height * recs_per_row inside `len`: the reference would
-    // skip the rest and return stale rows (RawData_Legacy.cpp:387-388)
-    if (lane == 0 && n < P->nrec)
-        atomicOr(P->status, MCRAW_E_TRUNCATED);
-}
-
-// ------------------------------------------------------------------ k6_chunks
-__global__ __launch_bounds__(64) void k6_chunks(const Plan6 *__restrict__ plans, const uint32_t *__restrict__ super_base,
-                                                int nframes)
-{
-    __shared__ uint32_t s_map[SUPER6 * PHASES6];
-    __shared__ uint32_t s_entry[SUPER6];
-    const int f = find_frame(blockIdx.x, super_base, nframes);
-    const Plan6 *P = plans + f;
-    if (*P->status != 0)
-        return;
-    const uint32_t sc = blockIdx.x - super_base[f];
-    const uint32_t first = sc * SUPER6;
-    const uint32_t cnt = min(static_cast<uint32_t>(SUPER6), P->nchunks - first);
-    const uint32_t lane = threadIdx.x;
-    const uint32_t *src = P->cmap + static_cast<size_t>(first) * PHASES6;
-    for (uint32_t i = lane; i < cnt * PHASES6; i += 64u)
-        s_map[i] = src[i];
-    __syncthreads();
-    if (lane == 0) {
-        const uint32_t e = P->sentry[sc];
-        uint32_t p = e & 255u, n = e >> 8;
-        for (uint32_t c = 0; c < cnt; c++) {
-            s_entry[c] = p | (n << 8);
-            if (p != DEAD) {
-                const uint32_t m = s_map[c * PHASES6 + p];
-                n = min(n + (m >> 8), 0xFFFFFFu); // (see k6_frame)
-                p = m & 255u;
-            }
-        }
-    }
-    __syncthreads();
-    if (lane < cnt)
-        P->centry[first + lane] = s_entry[lane];
-}
-
-// ------------------------------------------------------------------ k6_rows
 
 // Samples 4*qt..4*qt+3 of the record at byte `ro` of the staged stream, reference NOT yet added;
 // *ref receives the header's 12-bit reference (RawData_Legacy.cpp:372-375).  The payload is an
@@ -237,58 +86,338 @@ __device__ __forceinline__ void quad6(const uint8_t *__restrict__ bytes, uint32_
     v[3] = __builtin_amdgcn_ubfe(static_cast<uint32_t>(W >> ((64u - 4u * sb) & 63u)), 0u, sb);
 }
 
-// One wave per ROWS_CH consecutive chunks (4 KiB of stream), four waves per workgroup.  Lanes walk
-// one chunk each from its resolved entry and note where every record starts; the records of the wave
-// form one contiguous index range, so the list is flat.  Then ALL lanes unpack, four lanes per record
-// PAIR: a lane owns samples 4q..4q+3 of the even-column record and of the odd-column record = 8
-// consecutive pixels = one 16-byte store; 8 lanes fill a 128-byte line.
+// Unpacking: one wave per ROWS_CH consecutive chunks (4 KiB of stream), four such waves per workgroup.  Lanes
+// list where every record of the wave's chunks starts (a quarter chunk per lane, from where the true chain crosses
+// into it); the records of the wave form one contiguous index range, so the list is flat.  Then ALL lanes unpack,
+// four lanes per record PAIR: a lane owns samples 4q..4q+3 of the even-column record and of the odd-column record =
+// 8 consecutive pixels = one 16-byte store; 8 lanes fill a 128-byte line.
 //
 // A wave owns the pairs whose EVEN record starts in its chunks.  When its range ends on an even
 // record, the odd partner starts right behind it, at most 32 bytes into the next wave's first chunk and
-// inside this wave's staged slack (STAGE); when its range starts on an odd record, that record belongs
+// inside the staged slack; when its range starts on an odd record, that record belongs
 // to the previous wave's last pair.  So every pair is decoded whole, by one lane quartet.
 //
-// (A wave-uniform walk of ONE chunk per wave spent 64 lanes on a scalar chain and made this kernel
-// issue-bound; more chunks per wave spread the walk over more lanes but cost LDS, and 4 measured best.)
-// The list holds one entry per record PAIR -- the position of the even record; the odd one starts where
-// the even one ends, which the unpacking lane knows from the even record's header -- so a round covers
-// 1024 records in 1 KiB of LDS: all data but runs of 2-byte records stays on the single-round path
-// (4-byte records, 1-bit residuals of a nearly flat frame, are 1024 per wave).
+// The list has two layouts: every record (up to ROWS_CAP / 2 per wave), or one entry per record PAIR -- the
+// position of the even record; the odd one starts where the even one ends, which the unpacking lane knows from
+// the even record's header -- so a round covers 1024 records in 1 KiB of LDS: all data but runs of 2-byte
+// records stays on the single-round path (4-byte records, 1-bit residuals of a nearly flat frame, are 1024 per wave).
 constexpr uint32_t ROWS_CAP = 256u * ROWS_CH; // records per round (typical: ~70 per chunk; worst case 512 per chunk -> 2 rounds)
-static_assert(ROWS_CAP <= 1024u && ROWS_CAP % 2u == 0u, "the division-free row arithmetic in k6_rows assumes at most 512 pairs per round");
+static_assert(ROWS_CAP <= 1024u && ROWS_CAP % 2u == 0u, "the division-free row arithmetic of the unpack assumes at most 512 pairs per round");
 
 #ifndef K6_ABL
 #define K6_ABL 0 // timing experiments only: 1 no stores, 3 no walk
 #endif
 
+// ------------------------------------------------------------------ k6_decode
+constexpr uint32_t DEC_CH = 4 * ROWS_CH;  // chunks per workgroup: four unpacking waves
+constexpr uint32_t DEC_T = 320;           // ... and a fifth wave: (DEC_CH + 1) * 17 = 289 map walks need five
+constexpr uint32_t TAB8 = HALF6 + 32;     // byte walk table of a chunk: strides, then 32 zeros
+static_assert((DEC_CH + 1) * PHASES6 <= DEC_T, "one thread per (chunk, phase)");
+
+#ifdef MCRAW_DIAG // phase stamps of every workgroup (timing experiments only; not in the product library)
+constexpr int K6_PROF_WG = 1 << 16;
+__device__ uint32_t g_k6_prof[K6_PROF_WG][16];
+#define K6_STAMP(slot, who)                                                                                            \
+    do {                                                                                                               \
+        if (threadIdx.x == (who) && blockIdx.x < K6_PROF_WG) {                                                         \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                              \
+            g_k6_prof[blockIdx.x][slot] = static_cast<uint32_t>(now_ - stamp_);                                        \
+            stamp_ = now_;                                                                                             \
+        }                                                                                                              \
+    } while (0)
+#define K6_COUNT(slot, v) (blockIdx.x < K6_PROF_WG ? (void)(g_k6_prof[blockIdx.x][slot] = static_cast<uint32_t>(v)) : (void)0)
+#else
+#define K6_STAMP(slot, who)
+#define K6_COUNT(slot, v)
+#endif
+
+// Workgroup b works on frame b % nframes (a segment's predecessors then started long before it) and takes its
+// segment -- DEC_CH chunks -- from the frame's ticket counter: the segments it may have to wait on were all taken by
+// workgroups that are running or done, whatever order the hardware starts workgroups in.  (One counter per frame,
+// each in its own 256 bytes: one counter for the batch serialised the launch -- 31 000 device-scope atomics on one
+// address took 0.37 ms.)  Five waves: 17 x 17 map walks need 289 threads; the fifth wave then resolves the entries
+// while the other four wait, and leaves; those four unpack.
 template <int POST> // 0 = the plain mosaic, else bits per sample of the post stage's rows
-__global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, const uint32_t *__restrict__ item_base,
-                                               int nframes, const Post post)
+__global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ plans, const Look6 look,
+                                                   uint32_t *__restrict__ tickets, uint32_t epoch, uint32_t nframes,
+                                                   uint32_t smax, const Post post)
 {
-    constexpr uint32_t STAGE = ROWS_CH * CHUNK6 + 64 + 16; // + the reach of a record that starts 32 bytes past the chunks
-    __shared__ __attribute__((aligned(16))) uint8_t s_bytes[4][STAGE];
+    // the segment's stream: its DEC_CH chunks and the reach of a record that starts 32 bytes past them (the chunk in
+    // front of them, whose map tells where the segment is entered, only becomes a walk table)
+    constexpr uint32_t OWN = DEC_CH * CHUNK6, SLACK = 64 + 32;
+    constexpr uint32_t NPIECE = (CHUNK6 + OWN + SLACK) / 16; // 16-byte pieces, piece 0 at stream offset (cfirst - 1) * CHUNK6
+    constexpr uint32_t NROUND = (NPIECE + DEC_T - 1) / DEC_T;
+    __shared__ __attribute__((aligned(16))) uint8_t s_own[OWN + SLACK];
+    // walk tables of the DEC_CH + 1 chunks; dead once the maps are built: the record lists take their place
+    __shared__ __attribute__((aligned(16))) uint8_t s_tab[(DEC_CH + 1) * TAB8];
+    // [chunk][entry phase]: exit phase | records << 5, and the same where the walk crosses the chunk's quarters
+    __shared__ uint16_t s_cmap[(DEC_CH + 1) * PHASES6];
+    __shared__ uint16_t s_qmap[(DEC_CH + 1) * 3 * PHASES6];
+    __shared__ uint32_t s_ent[DEC_CH + 1];  // entry of my chunks and of the one behind them: phase | first record << 8
+    __shared__ uint32_t s_ent4[DEC_CH * 4]; // ... of every quarter of my chunks
+    __shared__ uint32_t s_exits[DEC_CH + 1]; // per chunk: the set of exit phases its 17 walks reach, one bit each
+    __shared__ uint32_t s_pairmode[4];
+    __shared__ uint32_t s_ticket;
     // the list of a round, one of two layouts: every record r at [r - wlo] (up to ROWS_CAP / 2 records: the
     // common case, one LDS read gives both records of a pair), or one entry per PAIR at [(r - wlo) / 2]
     // holding the even record only (up to ROWS_CAP records; the unpacking lane finds the odd one behind it)
-    __shared__ __attribute__((aligned(4))) uint16_t s_pos[4][ROWS_CAP / 2 + 2];
-    __shared__ uint32_t s_pairmode[4];
-    __shared__ uint32_t s_ent[4 * ROWS_CH];
+    typedef uint16_t PosList[ROWS_CAP / 2 + 2];
+    static_assert(sizeof(PosList) * 4 <= sizeof(s_tab), "the lists live where the walk tables were");
+    PosList *const s_pos = reinterpret_cast<PosList *>(s_tab);
 
-    // workgroups run over the batch BACKWARDS: k6_maps has just streamed the whole input through the
-    // Infinity Cache front to back, so its tail -- what a backward pass touches first -- is still there
-    const uint32_t bid = gridDim.x - 1u - blockIdx.x;
-    const int f = find_frame(bid, item_base, nframes);
+#ifdef MCRAW_DIAG
+    unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+    if (threadIdx.x == 0 && blockIdx.x < K6_PROF_WG)
+        g_k6_prof[blockIdx.x][6] = static_cast<uint32_t>(stamp_);
+#endif
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t f = blockIdx.x % nframes;
+    if (tid == 0)
+        s_ticket = atomicAdd(tickets + f * TICKET_STRIDE6, 1u);
     const Plan6 *P = plans + f;
-    if (*P->status != 0)
-        return; // whole workgroup
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t nchunks = P->nchunks, nrec = P->nrec, len = P->len;
-    const uint32_t c0 = ((bid - item_base[f]) * 4u + wave) * ROWS_CH;
-    const bool have = c0 < nchunks;
+    const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
+    // the ticket takes a round trip to the frame's counter: start loading what it will almost certainly say
+    // (workgroups start in order), and load again if it says otherwise
+    uint32_t seg = blockIdx.x / nframes;
+    uint4 v[NROUND];
+    auto fetch = [&]() { // piece i at stream offset (seg * DEC_CH - 1) * CHUNK6 + 16 i; past `len`: reads 0
+#pragma unroll
+        for (uint32_t r = 0; r < NROUND; r++) {
+            const uint32_t i = tid + r * DEC_T;
+            v[r] = (seg || i >= CHUNK6 / 16u) ? ld_b128(rs, seg * (DEC_CH * CHUNK6) - CHUNK6 + i * 16u) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    fetch();
+    __syncthreads();
+    K6_STAMP(0, 0);
+    K6_STAMP(8, 256);
+    if (s_ticket != seg) {
+        seg = s_ticket;
+        fetch();
+    }
+    const uint32_t cfirst = seg * DEC_CH;
+    if (cfirst >= nchunks)
+        return; // whole workgroup
+
+    // ---- stage the stream and turn it into the walk tables (one byte per even position: the record stride in half
+    // positions; 32 zeros behind every chunk, where a walk that has left the chunk stays)
+#pragma unroll
+    for (uint32_t r = 0; r < NROUND; r++) {
+        const uint32_t i = tid + r * DEC_T;
+        if (i < NPIECE && (seg || i >= CHUNK6 / 16u)) {
+            if (i >= CHUNK6 / 16u)
+                *reinterpret_cast<uint4 *>(s_own + (i - CHUNK6 / 16u) * 16u) = v[r];
+            if (i < (DEC_CH + 1u) * (CHUNK6 / 16u)) {
+                // header candidates are bytes 0 and 2 of every dword
+                const uint32_t lo = stride4(__builtin_amdgcn_perm(v[r].y, v[r].x, 0x06040200u));
+                const uint32_t hi = stride4(__builtin_amdgcn_perm(v[r].w, v[r].z, 0x06040200u));
+                const uint32_t k = i / (CHUNK6 / 16u), j = i % (CHUNK6 / 16u);
+                *reinterpret_cast<uint2 *>(s_tab + k * TAB8 + j * 8u) = make_uint2(lo, hi);
+            }
+        }
+    }
+    if (tid < (DEC_CH + 1u) * 2u)
+        *reinterpret_cast<uint4 *>(s_tab + (tid >> 1) * TAB8 + HALF6 + (tid & 1u) * 16u) = make_uint4(0u, 0u, 0u, 0u);
+    if (tid <= DEC_CH)
+        s_exits[tid] = 0u;
+    __syncthreads();
+    K6_STAMP(1, 0);
+    K6_STAMP(9, 256);
+
+    // ---- transition maps: thread (chunk k, phase) walks the table from its phase to the chunk's end, quarter by
+    // quarter, and notes where it crosses into each (the true chain's crossings are where the list walk starts, four
+    // lanes per chunk).  A step is one LDS read and a few VALU instructions with nothing to branch on per lane.
+    if (tid < (DEC_CH + 1u) * PHASES6) {
+        const uint32_t k = tid / PHASES6, ph = tid - k * PHASES6;
+        const uint32_t c = cfirst + k - 1u; // (k = 0: the chunk in front of the segment)
+        if ((k || seg) && c < nchunks) {
+            const uint32_t cs = c * CHUNK6;
+            // RawData_Legacy.cpp:387-388,398-399: a record must end before len-1, i.e. the record at half
+            // position q with stride d is the chain's end when cs + 2*(q + d) >= len
+            const uint32_t limq = len > cs ? (len - cs + 1u) >> 1 : 0u;
+            uint16_t *const qm = s_qmap + k * 3u * PHASES6 + ph;
+            uint32_t q, count = 0;
+            if (limq > HALF6 + 17u) { // no record of this chunk can reach `len`
+                uint32_t A = k * TAB8 + ph;
+#pragma unroll
+                for (uint32_t j = 1; j <= 4u; j++) {
+                    const uint32_t bound = k * TAB8 + j * (HALF6 / 4u);
+                    do {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            const bool in = A < bound;
+                            const uint32_t t = s_tab[A];
+                            count += in ? 1u : 0u;
+                            A += in ? t : 0u;
+                        }
+                    } while (__any(A < bound));
+                    if (j < 4u)
+                        qm[(j - 1u) * PHASES6] = static_cast<uint16_t>((A - bound) | (count << 5));
+                }
+                q = A - k * TAB8;
+            } else {
+                const uint8_t *tab = s_tab + k * TAB8;
+                uint32_t jn = 1; // next quarter to cross
+                q = ph;
+                while (q < HALF6) {
+                    const uint32_t nq = q + tab[q];
+                    if (nq >= limq)
+                        break;
+                    q = nq;
+                    count++;
+                    while (jn < 4u && q >= jn * (HALF6 / 4u)) {
+                        qm[(jn - 1u) * PHASES6] = static_cast<uint16_t>((q - jn * (HALF6 / 4u)) | (count << 5));
+                        jn++;
+                    }
+                }
+                for (; jn < 4u; jn++) // the chain ends in front of these
+                    qm[(jn - 1u) * PHASES6] = static_cast<uint16_t>(DEAD);
+            }
+            const uint32_t ex = q < HALF6 ? DEAD : q - HALF6;
+            s_cmap[k * PHASES6 + ph] = static_cast<uint16_t>(ex | (count << 5));
+            atomicOr(&s_exits[k], 1u << ex);
+        }
+    }
+    __syncthreads();
+    K6_STAMP(2, 0);
+    K6_STAMP(10, 256);
+
+    // ---- entries of my chunks (wave DEC_T / 64 - 1; the others wait at the barrier below)
+    const uint32_t cnt = min(static_cast<uint32_t>(DEC_CH), nchunks - cfirst);
+    if (wave == DEC_T / 64u - 1u) {
+        uint64_t *const res = look.res + static_cast<size_t>(f) * smax + seg; // mine; res[-k]: k segments before me
+        uint32_t spins = 0, w = 0;
+        bool lost = false;
+        // Entry phase of chunk j (lane j; lane cnt: of the chunk behind the segment): the map of the chunk in front
+        // of it almost always sends all 17 phases to ONE exit (a wrong chain reads payload bytes as headers and falls
+        // onto the true one within a few hundred bytes), so every lane knows its own at once; a lane whose map is
+        // not unanimous takes the entry of the chunk in front through that map -- lane 0 from the previous segment.
+        uint32_t myp = DEAD;
+        bool known = false;
+        if (lane <= cnt) {
+            if (lane == 0u && seg == 0u) {
+                myp = 0u; // the stream starts with a record at byte 0 (RawData_Legacy.cpp:476)
+                known = true;
+            } else {
+                const uint32_t xs = s_exits[lane]; // (chunk k = lane is the one in front of chunk j = lane)
+                myp = xs ? static_cast<uint32_t>(__builtin_ctz(xs)) : DEAD;
+                known = (xs & (xs - 1u)) == 0u; // one exit for all 17 phases
+            }
+        } else {
+            known = true;
+        }
+        if (!__builtin_amdgcn_readfirstlane(known ? 1u : 0u)) { // lane 0: ask the previous segment
+            for (;;) { // (uniform: every lane reads the same word)
+                if (look_get(res - 1, epoch, &w) && (w >> 30) != 0u)
+                    break;
+                if (++spins > SPIN6) {
+                    lost = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            const uint32_t lp = w & 31u; // phase at which the previous segment's last chunk is entered
+            if (lane == 0u) {
+                myp = (lost || lp == DEAD) ? DEAD : s_cmap[lp] & 31u;
+                known = true;
+            }
+        }
+        while (__ballot(!known)) { // (rare; at most cnt rounds)
+            const uint32_t pp = __shfl_up(myp, 1, 64);
+            const bool pk = __shfl_up(known ? 1u : 0u, 1, 64) != 0u;
+            if (!known && pk) {
+                myp = pp == DEAD ? DEAD : s_cmap[lane * PHASES6 + pp] & 31u;
+                known = true;
+            }
+        }
+        K6_STAMP(11, 256);
+        // records of my chunk along the true chain, and in front of it within the segment
+        const uint32_t mine = (lane < cnt && myp != DEAD) ? s_cmap[(lane + 1u) * PHASES6 + myp] >> 5 : 0u;
+        uint32_t incl = mine;
+#pragma unroll
+        for (int d = 1; d < 32; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d, 64);
+            incl += lane >= static_cast<uint32_t>(d) ? o : 0u;
+        }
+        const uint32_t myn = incl - mine;
+        const uint32_t total = __shfl(incl, 31, 64); // (lanes >= cnt add nothing)
+        const uint32_t lastp = __shfl(myp, static_cast<int>(cnt) - 1, 64);
+        K6_STAMP(12, 256);
+        // first record index: records of the frame's earlier segments, 64 of them per poll
+        uint32_t base = 0;
+        if (seg) {
+            if (lane == 0)
+                look_put(res, epoch, (RES_AGG << 30) | (total << 5) | lastp);
+            int32_t jn = static_cast<int32_t>(seg) - 1; // nearest segment of the window (lane 0)
+            while (!lost) {
+                const int32_t k = jn - static_cast<int32_t>(lane);
+                w = RES_AGG << 30; // segments "before the frame": nothing, and never reached (segment 0 has a prefix)
+                const bool ok = k < 0 || (look_get(res - seg + k, epoch, &w) && (w >> 30) != 0u);
+                const uint64_t okm = __ballot(ok), pm = __ballot(ok && (w >> 30) == RES_PREFIX);
+                const uint32_t np = pm ? static_cast<uint32_t>(__builtin_ctzll(pm)) : 64u; // lanes in front of the first prefix
+                const uint64_t need = np >= 64u ? ~0ull : ((1ull << np) | ((1ull << np) - 1ull));
+                if ((okm & need) != need) { // not all published yet
+                    if (++spins > SPIN6)
+                        lost = true;
+                    __builtin_amdgcn_s_sleep(2);
+                    continue;
+                }
+                uint32_t add = lane <= np ? (w >> 5) & 0xFFFFFFu : 0u;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1)
+                    add += __shfl_xor(add, d, 64);
+                base = min(base + add, 0xFFFFFFu);
+                if (np < 64u)
+                    break;
+                jn -= 64;
+            }
+        }
+        K6_STAMP(13, 256);
+        K6_COUNT(14, 1);
+        K6_COUNT(15, spins);
+        if (lost) { // (a predecessor never published: fail the frame rather than wait for ever)
+            if (lane == 0)
+                atomicOr(P->status, MCRAW_E_DEVICE);
+            myp = DEAD;
+        }
+        // entries carry the record index in 24 bits: a stream with more records than that (the frame itself has
+        // fewer, the host checks) saturates instead of wrapping back into the frame
+        const uint32_t endn = min(base + total, 0xFFFFFFu);
+        if (lane == 0)
+            look_put(res, epoch, (RES_PREFIX << 30) | (endn << 5) | (lost ? DEAD : lastp));
+        const uint32_t myi = min(base + myn, 0xFFFFFFu);
+        if (lane <= DEC_CH)
+            s_ent[lane] = lane <= cnt ? (myp | (myi << 8)) : DEAD;
+        // ... and of the quarters of my chunks, from the crossings the true chain's walker noted
+        if (lane < DEC_CH) {
+            const uint16_t *qm = s_qmap + (lane + 1u) * 3u * PHASES6 + myp;
+            s_ent4[lane * 4u] = lane < cnt ? (myp | (myi << 8)) : DEAD;
+#pragma unroll
+            for (uint32_t j = 0; j < 3u; j++) {
+                uint32_t eq = DEAD;
+                if (lane < cnt && myp != DEAD) {
+                    const uint32_t x = qm[j * PHASES6];
+                    eq = (x & 31u) == DEAD ? DEAD : ((x & 31u) | (min(myi + (x >> 5), 0xFFFFFFu) << 8));
+                }
+                s_ent4[lane * 4u + 1u + j] = eq;
+            }
+        }
+        // fewer records than height * recs_per_row inside `len`: the reference would
+        // skip the rest and return stale rows (RawData_Legacy.cpp:387-388)
+        if (lane == 0 && cfirst + cnt >= nchunks && endn < nrec && !lost)
+            atomicOr(P->status, MCRAW_E_TRUNCATED);
+    }
+    __syncthreads();
+    K6_STAMP(3, 0);
+    const bool helper = wave >= 4u; // (has no chunks of its own: it only keeps the workgroup's barriers company)
+
+    const uint32_t c0 = cfirst + (helper ? DEC_CH : wave * ROWS_CH);
+    const bool have = !helper && c0 < nchunks;
     // entries of my chunks (lane j) and of the chunk after them (lane ROWS_CH)
     uint32_t e = DEAD;
     if (have && lane <= ROWS_CH && c0 + lane < nchunks)
-        e = P->centry[c0 + lane];
+        e = s_ent[wave * ROWS_CH + lane];
     const uint32_t e0 = __builtin_amdgcn_readfirstlane(e);
     const uint32_t enext = __shfl(e, ROWS_CH, 64);
     const bool inner = c0 + ROWS_CH < nchunks && (enext & 255u) != DEAD && (enext >> 8) <= nrec;
@@ -301,22 +430,13 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
     const bool live = have && (e0 & 255u) != DEAD && R0 < R1;
     const uint32_t N = live ? R1 - R0 : 0u;
 
-    const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
     const uint32_t cs0 = c0 * CHUNK6;
-    if (live) {
-        uint4 *dst = reinterpret_cast<uint4 *>(s_bytes[wave]);
-#pragma unroll
-        for (uint32_t q = 0; q < (STAGE / 16 + 63) / 64; q++)
-            if (lane + 64u * q < STAGE / 16)
-                dst[lane + 64u * q] = ld_b128(rs, cs0 + (lane + 64u * q) * 16u);
-        if (lane < ROWS_CH)
-            s_ent[wave * ROWS_CH + lane] = e;
-    }
+    constexpr uint32_t STAGE = ROWS_CH * CHUNK6 + 64 + 16; // what a wave may touch: its chunks + the reach of a record 32 bytes past them
     // lean: every chunk of this wave runs to its end, the next entry bounds the last one, no record can
     // reach `len`, and the records fit one round of the list
-    const bool lean = live && inner && N <= ROWS_CAP && cs0 + STAGE < len;
+    const bool lean = helper || (live && inner && N <= ROWS_CAP && cs0 + STAGE < len);
     const bool pairmode = N > ROWS_CAP / 2u; // which list layout this wave's single round uses
-    if (lane == 0)
+    if (lane == 0 && !helper)
         s_pairmode[wave] = pairmode ? 1u : 0u;
     // When that holds for all four waves (everywhere but at the ends of a frame and in runs of tiny
     // records), ONE wave walks the 16 chunks of the workgroup, a lane each: a walk keeps a wave busy for
@@ -324,7 +444,8 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
     // would spend four times the issue slots on it.
     const bool coop = __syncthreads_and(lean) != 0;
 
-    const uint8_t *bytes = s_bytes[wave];
+    const uint8_t *bytes = s_own + (helper ? 0u : wave) * (ROWS_CH * CHUNK6);
+    // (the walk tables are dead: from here on their LDS holds the record lists)
     const uint32_t width = static_cast<uint32_t>(P->width);
     const bool fast = P->fast_store != 0u;
     uint16_t *const out = P->out;
@@ -397,24 +518,28 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
     };
 
     if (coop) {
-        if (K6_ABL != 3 && wave == 0u && lane < 4u * ROWS_CH) {
-            const uint32_t w = lane / ROWS_CH, j = lane - w * ROWS_CH; // chunk j of wave w
-            const uint32_t ej = s_ent[lane], first = ((s_ent[w * ROWS_CH] >> 8) + 1u) & ~1u;
-            const uint8_t *base = s_bytes[w];
-            const uint8_t *p = base + j * CHUNK6 + 2u * (ej & 255u), *const pe = base + (j + 1u) * CHUNK6;
+        if (helper)
+            return;
+        if (K6_ABL != 3 && lane < 4u * ROWS_CH) {
+            // lane = (chunk j, quarter r) of my wave: a quarter chunk each, from where the true chain crosses into it
+            const uint32_t w = wave, j = lane >> 2, r = lane & 3u;
+            const uint32_t ej = s_ent4[w * (4u * ROWS_CH) + lane], first = R0;
+            const uint8_t *base = s_own + w * (ROWS_CH * CHUNK6);
+            const uint8_t *p = base + j * CHUNK6 + r * (CHUNK6 / 4u) + 2u * (ej & 255u);
+            const uint8_t *const pe = base + j * CHUNK6 + (r + 1u) * (CHUNK6 / 4u);
             uint32_t idx = ej >> 8;
             if (s_pairmode[w]) {
                 // an odd first record belongs to the previous wave's last pair: never listed
                 while (p < pe) { // the stride decode, and a store for every second record
                     const uint32_t hb = static_cast<uint32_t>(*p) >> 4;
-                    if ((idx & 1u) == 0u)
+                    if ((idx & 1u) == 0u && idx >= first)
                         s_pos[w][(idx - first) >> 1] = static_cast<uint16_t>(p - base);
                     idx++;
                     p += 2u + len6_of(hb);
                 }
             } else {
                 uint16_t *lp = s_pos[w] + static_cast<int32_t>(idx - first); // [-1] for an odd first record:
-                if (idx < first) {                                             // skipped, see above
+                if (idx < first && p < pe) {                                   // skipped, see above
                     p += 2u + len6_of(static_cast<uint32_t>(*p) >> 4);
                     lp++;
                 }
@@ -423,14 +548,21 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
                     *lp++ = static_cast<uint16_t>(p - base);
                     p += 2u + len6_of(hb);
                 }
-                // the walk of a wave's last chunk stops on the next wave's first record: the partner of my
+                // the walk of a wave's last quarter stops on the next wave's first record: the partner of my
                 // last record when my range ends on an even one (lp is then at an odd list index)
-                if (j == ROWS_CH - 1u && ((lp - s_pos[w]) & 1))
+                if (j == ROWS_CH - 1u && r == 3u && ((lp - s_pos[w]) & 1))
                     *lp = static_cast<uint16_t>(p - base);
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        K6_STAMP(4, 0);
         unpack_round(R0, R1, pairmode);
+        K6_STAMP(5, 0);
+#ifdef MCRAW_DIAG
+        if (threadIdx.x == 0 && blockIdx.x < K6_PROF_WG)
+            g_k6_prof[blockIdx.x][7] = static_cast<uint32_t>(stamp_);
+#endif
         return;
     }
     if (!live)
@@ -479,31 +611,33 @@ __global__ __launch_bounds__(256) void k6_rows(const Plan6 *__restrict__ plans, 
 
 // ------------------------------------------------------------------ launchers
 
-void launch_k6_maps(const Plan6 *plans, const uint32_t *item_base, int nframes, uint32_t nitems, hipStream_t st)
+#ifdef MCRAW_DIAG
+extern "C" void mcraw_diag_k6_prof(uint32_t *out, int nwg, int reset)
 {
-    hipLaunchKernelGGL(k6_maps, dim3(nitems), dim3(256), 0, st, plans, item_base, nframes);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k6_prof), sizeof(uint32_t) * 16 * nwg);
+    if (reset) {
+        void *p = nullptr;
+        (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_k6_prof));
+        (void)hipMemset(p, 0, sizeof(g_k6_prof));
+    }
 }
+#endif
 
-void launch_k6_resolve(const Plan6 *plans, const uint32_t *super_base, int nframes, uint32_t nsuper_items,
-                       hipStream_t st)
+void launch_k6_decode(const Plan6 *plans, const Look6 &look, uint32_t *tickets, uint32_t epoch, int nframes, uint32_t smax,
+                      const Post &post, hipStream_t st)
 {
-    hipLaunchKernelGGL(k6_super, dim3(nsuper_items), dim3(64), 0, st, plans, super_base, nframes);
-    hipLaunchKernelGGL(k6_frame, dim3(nframes), dim3(64), 0, st, plans);
-    hipLaunchKernelGGL(k6_chunks, dim3(nsuper_items), dim3(64), 0, st, plans, super_base, nframes);
-}
-
-void launch_k6_rows(const Plan6 *plans, const uint32_t *item_base, int nframes, uint32_t nitems, const Post &post,
-                    hipStream_t st)
-{
+    const dim3 grid(smax * static_cast<uint32_t>(nframes)), block(DEC_T);
+    const uint32_t nf = static_cast<uint32_t>(nframes);
     if (post.mode == 0u) {
-        hipLaunchKernelGGL(k6_rows<0>, dim3(nitems), dim3(256), 0, st, plans, item_base, nframes, post);
+        hipLaunchKernelGGL(k6_decode<0>, grid, block, 0, st, plans, look, tickets, epoch, nf, smax, post);
         return;
     }
     switch (post_bits(post.mode)) { // one kernel instance per row format
-    case 12: hipLaunchKernelGGL(k6_rows<12>, dim3(nitems), dim3(256), 0, st, plans, item_base, nframes, post); break;
-    case 10: hipLaunchKernelGGL(k6_rows<10>, dim3(nitems), dim3(256), 0, st, plans, item_base, nframes, post); break;
-    case 14: hipLaunchKernelGGL(k6_rows<14>, dim3(nitems), dim3(256), 0, st, plans, item_base, nframes, post); break;
-    default: hipLaunchKernelGGL(k6_rows<16>, dim3(nitems), dim3(256), 0, st, plans, item_base, nframes, post); break;
+    case 12: hipLaunchKernelGGL(k6_decode<12>, grid, block, 0, st, plans, look, tickets, epoch, nf, smax, post); break;
+    case 10: hipLaunchKernelGGL(k6_decode<10>, grid, block, 0, st, plans, look, tickets, epoch, nf, smax, post); break;
+    case 14: hipLaunchKernelGGL(k6_decode<14>, grid, block, 0, st, plans, look, tickets, epoch, nf, smax, post); break;
+    default: hipLaunchKernelGGL(k6_decode<16>, grid, block, 0, st, plans, look, tickets, epoch, nf, smax, post); break;
     }
 }
 

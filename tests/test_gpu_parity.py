@@ -160,7 +160,7 @@ def test_side_streams_at_odd_offsets(gpu_ctx, pads):
 
 
 def test_flat_frames_densest_chains(gpu_ctx):
-    # constant images: every legacy record is 2 bytes (512 records per KiB chunk -> k6_rows lists its
+    # constant images: every legacy record is 2 bytes (512 records per KiB chunk -> k6_decode lists its
     # 8-chunk window in several rounds), every type-7 block is 0 bytes (empty payload spans) and the
     # side streams are runs of 2-byte records
     items, expect = [], []
@@ -183,7 +183,7 @@ def test_flat_and_textured_bands_mix_dense_and_sparse_chunks(gpu_ctx):
     # bands of constant rows between bands of noise: the side streams alternate between runs of
     # 2-byte records (dense chunks, listed by pointer doubling) and ordinary records (sparse chunks,
     # grouped four to a work item), so groups that hold both kinds occur; likewise the legacy chain
-    # alternates between 2-byte and long records inside one k6_rows window
+    # alternates between 2-byte and long records inside one k6_decode window
     rng = np.random.default_rng(77)
     items, expect = [], []
     for (w, h, band) in ((2048, 192, 24), (1024, 1536, 512), (1000, 150, 10)):

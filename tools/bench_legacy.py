@@ -28,7 +28,7 @@ def main():
         descs = [(tin[i].data_ptr(), tin[i].numel(), w, h, 6, tout.data_ptr() + i * w * h * 2, w * h) for i in range(n)]
         frames = M.Context.make_frames(descs)
         written, status = ctx.decode_batch(frames)
-        assert all(s == 0 for s in status)
+        assert os.environ.get('MCRAW_NOCHECK') or all(s == 0 for s in status)
         got = tout[: w * h * 2].cpu().numpy().view(np.uint16).reshape(h, w)
         assert os.environ.get('MCRAW_NOCHECK') or np.array_equal(got, imgs[0])
         for k in M.KERNELS:
@@ -40,7 +40,7 @@ def main():
             ctx.decode_batch(frames, want_status=False)
         torch.cuda.synchronize()
         t = (time.perf_counter() - t0) / reps
-        kms = {k: round(ctx.kernel_ms(k, reset=True)[0] / reps, 4) for k in ("k6_maps", "k6_resolve", "k6_rows")}
+        kms = {k: round(ctx.kernel_ms(k, reset=True)[0] / reps, 4) for k in ("k6_decode",)}
         byts = sum(b.size for b in bufs) * n // 4 + n * w * h * 2
         res[name] = {"ms_per_batch": round(t * 1e3, 3), "mpix_s": round(n * w * h / t / 1e6, 1),
                      "gbs_in_plus_out": round(byts / t / 1e9, 1), "bpp": round(8 * bufs[0].size / (w * h), 2), "kernels_ms": kms}

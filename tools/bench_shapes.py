@@ -2,7 +2,7 @@
 """Throughput over image content that real footage has and the synthetic bench does not: clipped
 regions, letterboxing, low light, stripes, dead pixels, flat frames -- both encodings, UHD.  A data shape
 that takes a slow path shows up here (flat legacy frames did: 0.78 ms per 32 frames before the bulk
-listing of 2-byte records in k6_rows, 0.25 ms after)."""
+listing of 2-byte records in the legacy unpack, 0.25 ms after)."""
 import json
 import os
 import sys

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Phase breakdown of k6_decode summed over all workgroups, from a library built with -DMCRAW_DIAG (tools/k6_prof.sh)."""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np
+import torch
+import _libs as L
+import motioncam_decoder_amd as M
+
+w, h, n = 4000, 3000, int(os.environ.get("N", "32"))
+dev = torch.device("cuda:0")
+imgs = [L.synth_image(w, h, 12, 1, 12.0, 6000 + i) for i in range(4)]
+bufs = [L.encode6(im) for im in imgs]
+tin = [torch.from_numpy(bufs[i % 4]).to(dev) for i in range(n)]
+tout = torch.zeros(n * w * h * 2, dtype=torch.uint8, device=dev)
+frames = M.Context.make_frames([(tin[i].data_ptr(), tin[i].numel(), w, h, 6, tout.data_ptr() + i * w * h * 2, w * h) for i in range(n)])
+ctx = M.Context(0)
+lib = M.load()
+written, status = ctx.decode_batch(frames)
+assert all(s == 0 for s in status)
+NWG = 1 << 16
+prof = np.zeros((NWG, 16), np.uint32)
+pp = prof.ctypes.data_as(C.POINTER(C.c_uint32))
+lib.mcraw_diag_k6_prof(pp, NWG, 1)
+ctx.profile(True)
+reps = 5
+for _ in range(reps):
+    ctx.decode_batch(frames, want_status=False)
+torch.cuda.synchronize()
+lib.mcraw_diag_k6_prof(pp, NWG, 1)   # stamps of the last launch
+live = prof[:, 14] == 1
+P = prof[live].astype(np.float64)
+names = {0: "w0 ticket", 1: "w0 load+table", 2: "w0 maps", 3: "w0 wait resolve", 4: "w0 list walk", 5: "w0 unpack",
+         8: "w4 ticket", 9: "w4 load+table", 10: "w4 maps", 11: "w4 entry phase", 12: "w4 chain", 13: "w4 window"}
+for i, nm in names.items():
+    print("%-18s mean %8.0f  p50 %8.0f  p90 %8.0f ticks" % (nm, P[:, i].mean(), np.median(P[:, i]), np.percentile(P[:, i], 90)))
+print("workgroups", live.sum(), "lifetime mean", P[:, 0:6].sum(axis=1).mean(), "spins/wg", P[:, 15].mean(), "max", P[:, 15].max())
+Q = P[P[:, 7] > 0]; t0 = Q[:, 6].min(); span = ((Q[:, 7] - t0) % 2**32).max()
+print("kernel span ticks", span, "-> concurrency", P[:, 0:6].sum() / span, "wgs in flight; tick rate MHz ~", span / (ctx.kernel_ms("k6_decode")[0] / reps * 1e3))
+print("ms/launch", ctx.kernel_ms("k6_decode")[0] / reps)

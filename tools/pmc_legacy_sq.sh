@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pl_sq
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS -d /tmp/pl_sq -- python3 $R/tools/bench_legacy.py > /tmp/pl_sq.log 2>&1
 rm -rf /tmp/pl_sq2
-rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS -d /tmp/pl_sq2 -- python3 $R/tools/bench_legacy.py > /tmp/pl_sq2.log 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS -d /tmp/pl_sq2 -- python3 $R/tools/bench_legacy.py > /tmp/pl_sq2.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 for d in ("/tmp/pl_sq", "/tmp/pl_sq2"):
