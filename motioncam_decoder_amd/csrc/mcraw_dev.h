@@ -172,6 +172,16 @@ __device__ __forceinline__ void post_pack_be(const uint32_t p[4], uint32_t o[4])
         o[i] = __builtin_amdgcn_perm(w[i], w[i], 0x00010203u);
 }
 
+// The output buffers are global memory, but a pointer that a kernel loads from a table is generic to the compiler,
+// which then emits FLAT stores: those also count on the LDS counter, so every wait for an LDS read waits for the
+// stores in front of it as well.  gptr<V>(p) is p as a pointer to V in the global address space.
+#define MCRAW_GLOBAL __attribute__((address_space(1)))
+template <class V, class T>
+__device__ __forceinline__ MCRAW_GLOBAL V *gptr(T *p)
+{
+    return (MCRAW_GLOBAL V *)p;
+}
+
 // Bytes [0, nb) of the dwords o[] to dst, the last one masked by `last` (the cropped end of a strip row).
 __device__ __forceinline__ void post_store_bytes(uint8_t *dst, const uint32_t *o, uint32_t nb, uint32_t last, uint32_t maxb)
 {
@@ -180,7 +190,7 @@ __device__ __forceinline__ void post_store_bytes(uint8_t *dst, const uint32_t *o
             uint32_t b = (o[i >> 2] >> (8u * (i & 3u))) & 0xffu;
             if (i == nb - 1u)
                 b &= last;
-            dst[i] = static_cast<uint8_t>(b);
+            gptr<uint8_t>(dst)[i] = static_cast<uint8_t>(b);
         }
 }
 
@@ -205,12 +215,12 @@ __device__ __forceinline__ void post_store8(uint16_t *out, const Post &post, uin
             typedef uint32_t u32x3_u __attribute__((ext_vector_type(3), aligned(2)));
             if (PB == 10) {
                 const u32x2_u v = {o[0], o[1]};
-                *reinterpret_cast<u32x2_u *>(dst) = v;
-                *reinterpret_cast<uint16_t *>(dst + 8) = static_cast<uint16_t>(o[2]);
+                *gptr<u32x2_u>(dst) = v;
+                *gptr<uint16_t>(dst + 8) = static_cast<uint16_t>(o[2]);
             } else {
                 const u32x3_u v = {o[0], o[1], o[2]};
-                *reinterpret_cast<u32x3_u *>(dst) = v;
-                *reinterpret_cast<uint16_t *>(dst + 12) = static_cast<uint16_t>(o[3]);
+                *gptr<u32x3_u>(dst) = v;
+                *gptr<uint16_t>(dst + 12) = static_cast<uint16_t>(o[3]);
             }
         } else { // rows off the 2-byte grid, and the cropped end of a row (a last sample may end inside a byte)
             const uint32_t bitsn = n * B, nb = (bitsn + 7u) >> 3;
@@ -226,13 +236,13 @@ __device__ __forceinline__ void post_store8(uint16_t *out, const Post &post, uin
             typedef uint32_t u32x3 __attribute__((ext_vector_type(3), aligned(4)));
             const u32x3 v = {o[0], o[1], o[2]};
             if (NT)
-                __builtin_nontemporal_store(v, reinterpret_cast<u32x3 *>(dst));
+                __builtin_nontemporal_store(v, gptr<u32x3>(dst));
             else
-                *reinterpret_cast<u32x3 *>(dst) = v;
+                *gptr<u32x3>(dst) = v;
         } else if (n == 8u) { // a strip row off the dword grid: one unaligned 12-byte store
             typedef uint32_t u32x3_u __attribute__((ext_vector_type(3), aligned(1)));
             const u32x3_u v = {o[0], o[1], o[2]};
-            *reinterpret_cast<u32x3_u *>(dst) = v;
+            *gptr<u32x3_u>(dst) = v;
         } else { // the cropped end of a row: bytes; an odd last sample owns the high nibble of its second byte
             const uint32_t nb = (n * 12u + 7u) >> 3;
 #pragma unroll
@@ -241,7 +251,7 @@ __device__ __forceinline__ void post_store8(uint16_t *out, const Post &post, uin
                     uint32_t b = (o[i >> 2] >> (8u * (i & 3u))) & 0xffu;
                     if ((n & 1u) && i == nb - 1u)
                         b &= 0xf0u;
-                    dst[i] = static_cast<uint8_t>(b);
+                    gptr<uint8_t>(dst)[i] = static_cast<uint8_t>(b);
                 }
         }
         return;
@@ -251,18 +261,18 @@ __device__ __forceinline__ void post_store8(uint16_t *out, const Post &post, uin
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         const u32x4 v = {p[0], p[1], p[2], p[3]};
         if (NT)
-            __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst));
+            __builtin_nontemporal_store(v, gptr<u32x4>(dst));
         else
-            *reinterpret_cast<u32x4 *>(dst) = v;
+            *gptr<u32x4>(dst) = v;
     } else if (n == 8u) { // rows off the 16-byte grid: one unaligned 16-byte store
         typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(2)));
         const u32x4_u v = {p[0], p[1], p[2], p[3]};
-        *reinterpret_cast<u32x4_u *>(dst) = v;
+        *gptr<u32x4_u>(dst) = v;
     } else {
 #pragma unroll
         for (uint32_t i = 0; i < 8u; i++)
             if (i < n)
-                dst[i] = static_cast<uint16_t>(p[i >> 1] >> (16u * (i & 1u)));
+                gptr<uint16_t>(dst)[i] = static_cast<uint16_t>(p[i >> 1] >> (16u * (i & 1u)));
     }
 }
 

@@ -156,8 +156,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     __shared__ uint32_t s_ent[DEC_CH + 1];  // entry of my chunks and of the one behind them: phase | first record << 8
     __shared__ uint32_t s_ent4[DEC_CH * 4]; // ... of every quarter of my chunks
     __shared__ uint32_t s_exits[DEC_CH + 1]; // per chunk: the set of exit phases its 17 walks reach, one bit each
-    __shared__ uint32_t s_pairmode[4];
-    __shared__ uint32_t s_ticket;
+    __shared__ uint32_t s_ticket, s_coop;
     // the list of a round, one of two layouts: every record r at [r - wlo] (up to ROWS_CAP / 2 records: the
     // common case, one LDS read gives both records of a pair), or one entry per PAIR at [(r - wlo) / 2]
     // holding the even record only (up to ROWS_CAP records; the unpacking lane finds the odd one behind it)
@@ -285,6 +284,32 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
 
     // ---- entries of my chunks (wave DEC_T / 64 - 1; the others wait at the barrier below)
     const uint32_t cnt = min(static_cast<uint32_t>(DEC_CH), nchunks - cfirst);
+    // What unpacking wave w has to do, from the entries in s_ent (valid once the fifth wave has written them).
+    struct Range6 {
+        uint32_t R0, R1, N; // records it decodes: the pairs whose even record starts in its chunks
+        bool live;          // the chain reaches its chunks and there are pairs for it
+        bool lean;          // every chunk runs to its end, the next entry bounds the last one, no record can reach `len`,
+                            // and the records fit one round of the list
+        bool pairmode;      // which list layout its single round uses
+    };
+    auto ent_of = [&](uint32_t j) { return cfirst + j < nchunks ? s_ent[j] : DEAD; }; // (no entry behind the last chunk)
+    auto range_of = [&](uint32_t w) {
+        constexpr uint32_t STAGE = ROWS_CH * CHUNK6 + 64 + 16; // what a wave may touch: its chunks + the reach of a record 32 bytes past them
+        const uint32_t c0 = cfirst + w * ROWS_CH;
+        const uint32_t e0 = ent_of(w * ROWS_CH), enext = ent_of(w * ROWS_CH + ROWS_CH);
+        const bool inner = c0 + ROWS_CH < nchunks && (enext & 255u) != DEAD && (enext >> 8) <= nrec;
+        // records that start in the wave's chunks: [I0, Iend); nrec is even (two records per 32 columns)
+        const uint32_t I0 = e0 >> 8;
+        const uint32_t Iend = min(nrec, (c0 + ROWS_CH < nchunks) ? (enext >> 8) : nrec);
+        Range6 g;
+        g.R0 = (I0 + 1u) & ~1u;
+        g.R1 = (Iend + 1u) & ~1u;
+        g.live = c0 < nchunks && (e0 & 255u) != DEAD && g.R0 < g.R1;
+        g.N = g.live ? g.R1 - g.R0 : 0u;
+        g.lean = g.live && inner && g.N <= ROWS_CAP && c0 * CHUNK6 + STAGE < len;
+        g.pairmode = g.N > ROWS_CAP / 2u;
+        return g;
+    };
     if (wave == DEC_T / 64u - 1u) {
         uint64_t *const res = look.res + static_cast<size_t>(f) * smax + seg; // mine; res[-k]: k segments before me
         uint32_t spins = 0, w = 0;
@@ -407,44 +432,66 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         // skip the rest and return stale rows (RawData_Legacy.cpp:387-388)
         if (lane == 0 && cfirst + cnt >= nchunks && endn < nrec && !lost)
             atomicOr(P->status, MCRAW_E_TRUNCATED);
+
+        // ---- the record lists of the four unpacking waves, when every one of them is on the lean path (everywhere
+        // but at the ends of a frame and in runs of tiny records): lane = (wave w, chunk j, quarter r) lists a quarter
+        // chunk from where the true chain crosses into it -- 18 dependent steps instead of a chunk's 70, on ONE wave
+        // (a walk costs a wave its issue slots whatever the number of walking lanes).  The walk tables are dead by now:
+        // their LDS holds the lists.
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t uw = lane / (4u * ROWS_CH), j = (lane >> 2) & (ROWS_CH - 1u), r = lane & 3u;
+        const Range6 rg = range_of(uw);
+        const bool coop = __ballot(!rg.lean) == 0ull;
+        if (lane == 0)
+            s_coop = coop ? 1u : 0u;
+        if (K6_ABL != 3 && coop) {
+            const uint32_t ej = s_ent4[lane], first = rg.R0;
+            const uint8_t *base = s_own + uw * (ROWS_CH * CHUNK6);
+            const uint8_t *p = base + j * CHUNK6 + r * (CHUNK6 / 4u) + 2u * (ej & 255u);
+            const uint8_t *const pe = base + j * CHUNK6 + (r + 1u) * (CHUNK6 / 4u);
+            uint32_t idx = ej >> 8;
+            if (rg.pairmode) {
+                // an odd first record belongs to the previous wave's last pair: never listed
+                while (p < pe) { // the stride decode, and a store for every second record
+                    const uint32_t hb = static_cast<uint32_t>(*p) >> 4;
+                    if ((idx & 1u) == 0u && idx >= first)
+                        s_pos[uw][(idx - first) >> 1] = static_cast<uint16_t>(p - base);
+                    idx++;
+                    p += 2u + len6_of(hb);
+                }
+            } else {
+                uint16_t *lp = s_pos[uw] + static_cast<int32_t>(idx - first); // [-1] for an odd first record:
+                if (idx < first && p < pe) {                                   // skipped, see above
+                    p += 2u + len6_of(static_cast<uint32_t>(*p) >> 4);
+                    lp++;
+                }
+                while (p < pe) { // nothing but the stride decode in the loop
+                    const uint32_t hb = static_cast<uint32_t>(*p) >> 4;
+                    *lp++ = static_cast<uint16_t>(p - base);
+                    p += 2u + len6_of(hb);
+                }
+                // the walk of a wave's last quarter stops on the next wave's first record: the partner of my
+                // last record when my range ends on an even one (lp is then at an odd list index)
+                if (j == ROWS_CH - 1u && r == 3u && ((lp - s_pos[uw]) & 1))
+                    *lp = static_cast<uint16_t>(p - base);
+            }
+        }
     }
     __syncthreads();
     K6_STAMP(3, 0);
-    const bool helper = wave >= 4u; // (has no chunks of its own: it only keeps the workgroup's barriers company)
+    if (wave >= 4u)
+        return; // (the fifth wave has no chunks of its own)
 
-    const uint32_t c0 = cfirst + (helper ? DEC_CH : wave * ROWS_CH);
-    const bool have = !helper && c0 < nchunks;
-    // entries of my chunks (lane j) and of the chunk after them (lane ROWS_CH)
-    uint32_t e = DEAD;
-    if (have && lane <= ROWS_CH && c0 + lane < nchunks)
-        e = s_ent[wave * ROWS_CH + lane];
-    const uint32_t e0 = __builtin_amdgcn_readfirstlane(e);
-    const uint32_t enext = __shfl(e, ROWS_CH, 64);
-    const bool inner = c0 + ROWS_CH < nchunks && (enext & 255u) != DEAD && (enext >> 8) <= nrec;
-    // records that start in my chunks: [I0, Iend); nrec is even (two records per 32 columns)
-    const uint32_t I0 = e0 >> 8;
-    const uint32_t Iend = min(nrec, (c0 + ROWS_CH < nchunks) ? (enext >> 8) : nrec);
-    // records I decode: the pairs whose even record is among them
-    const uint32_t R0 = (I0 + 1u) & ~1u, R1 = (Iend + 1u) & ~1u;
-    // live: the chain reaches this wave's chunks and there are pairs for it
-    const bool live = have && (e0 & 255u) != DEAD && R0 < R1;
-    const uint32_t N = live ? R1 - R0 : 0u;
+    const Range6 mine = range_of(wave);
+    const uint32_t c0 = cfirst + wave * ROWS_CH, cs0 = c0 * CHUNK6;
+    const uint32_t R0 = mine.R0, R1 = mine.R1, N = mine.N;
+    const bool live = mine.live, pairmode = mine.pairmode;
+    // entries of my chunks (lane j) and of the chunk after them (lane ROWS_CH): the general path walks from them
+    const uint32_t e = lane <= ROWS_CH ? ent_of(wave * ROWS_CH + lane) : DEAD;
+    const bool coop = s_coop != 0u;
 
-    const uint32_t cs0 = c0 * CHUNK6;
-    constexpr uint32_t STAGE = ROWS_CH * CHUNK6 + 64 + 16; // what a wave may touch: its chunks + the reach of a record 32 bytes past them
-    // lean: every chunk of this wave runs to its end, the next entry bounds the last one, no record can
-    // reach `len`, and the records fit one round of the list
-    const bool lean = helper || (live && inner && N <= ROWS_CAP && cs0 + STAGE < len);
-    const bool pairmode = N > ROWS_CAP / 2u; // which list layout this wave's single round uses
-    if (lane == 0 && !helper)
-        s_pairmode[wave] = pairmode ? 1u : 0u;
-    // When that holds for all four waves (everywhere but at the ends of a frame and in runs of tiny
-    // records), ONE wave walks the 16 chunks of the workgroup, a lane each: a walk keeps a wave busy for
-    // ~70 dependent steps whatever the number of walking lanes, so four waves walking four chunks each
-    // would spend four times the issue slots on it.
-    const bool coop = __syncthreads_and(lean) != 0;
-
-    const uint8_t *bytes = s_own + (helper ? 0u : wave) * (ROWS_CH * CHUNK6);
+    const uint8_t *bytes = s_own + wave * (ROWS_CH * CHUNK6);
     // (the walk tables are dead: from here on their LDS holds the record lists)
     const uint32_t width = static_cast<uint32_t>(P->width);
     const bool fast = P->fast_store != 0u;
@@ -503,59 +550,21 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                     px[0] = 1;
             } else if (fast && x + 8u <= width) {
                 const u32x4 v = {o[0], o[1], o[2], o[3]};
-                __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(px));
+                __builtin_nontemporal_store(v, gptr<u32x4>(px));
             } else if (x + 8u <= width) { // rows off the 16-byte grid: still one (unaligned) 16-byte store
                 typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(2)));
                 const u32x4_u v = {o[0], o[1], o[2], o[3]};
-                *reinterpret_cast<u32x4_u *>(px) = v;
+                *gptr<u32x4_u>(px) = v;
             } else {
 #pragma unroll
                 for (uint32_t j = 0; j < 8u; j++) // padded columns are cropped (RawData_Legacy.cpp:490)
                     if (x + j < width)
-                        px[j] = static_cast<uint16_t>(o[j >> 1] >> (16u * (j & 1u)));
+                        gptr<uint16_t>(px)[j] = static_cast<uint16_t>(o[j >> 1] >> (16u * (j & 1u)));
             }
         }
     };
 
     if (coop) {
-        if (helper)
-            return;
-        if (K6_ABL != 3 && lane < 4u * ROWS_CH) {
-            // lane = (chunk j, quarter r) of my wave: a quarter chunk each, from where the true chain crosses into it
-            const uint32_t w = wave, j = lane >> 2, r = lane & 3u;
-            const uint32_t ej = s_ent4[w * (4u * ROWS_CH) + lane], first = R0;
-            const uint8_t *base = s_own + w * (ROWS_CH * CHUNK6);
-            const uint8_t *p = base + j * CHUNK6 + r * (CHUNK6 / 4u) + 2u * (ej & 255u);
-            const uint8_t *const pe = base + j * CHUNK6 + (r + 1u) * (CHUNK6 / 4u);
-            uint32_t idx = ej >> 8;
-            if (s_pairmode[w]) {
-                // an odd first record belongs to the previous wave's last pair: never listed
-                while (p < pe) { // the stride decode, and a store for every second record
-                    const uint32_t hb = static_cast<uint32_t>(*p) >> 4;
-                    if ((idx & 1u) == 0u && idx >= first)
-                        s_pos[w][(idx - first) >> 1] = static_cast<uint16_t>(p - base);
-                    idx++;
-                    p += 2u + len6_of(hb);
-                }
-            } else {
-                uint16_t *lp = s_pos[w] + static_cast<int32_t>(idx - first); // [-1] for an odd first record:
-                if (idx < first && p < pe) {                                   // skipped, see above
-                    p += 2u + len6_of(static_cast<uint32_t>(*p) >> 4);
-                    lp++;
-                }
-                while (p < pe) { // nothing but the stride decode in the loop
-                    const uint32_t hb = static_cast<uint32_t>(*p) >> 4;
-                    *lp++ = static_cast<uint16_t>(p - base);
-                    p += 2u + len6_of(hb);
-                }
-                // the walk of a wave's last quarter stops on the next wave's first record: the partner of my
-                // last record when my range ends on an even one (lp is then at an odd list index)
-                if (j == ROWS_CH - 1u && r == 3u && ((lp - s_pos[w]) & 1))
-                    *lp = static_cast<uint16_t>(p - base);
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
         K6_STAMP(4, 0);
         unpack_round(R0, R1, pairmode);
         K6_STAMP(5, 0);

@@ -674,22 +674,22 @@ __device__ __forceinline__ void store_px8(const ItemS &I, const Post &post, uint
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         const u32x4 v = {p[0], p[1], p[2], p[3]};
         if (NT)
-            __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst));
+            __builtin_nontemporal_store(v, gptr<u32x4>(dst));
         else
-            *reinterpret_cast<u32x4 *>(dst) = v;
+            *gptr<u32x4>(dst) = v;
     } else if (x + 8u <= width) {
         // a row that does not start on a 16-byte boundary (width % 8 != 0, or an odd output address):
         // still one 16-byte store -- global memory takes it at any 2-byte alignment -- instead of eight
         // 2-byte ones
         typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(2)));
         const u32x4_u v = {p[0], p[1], p[2], p[3]};
-        *reinterpret_cast<u32x4_u *>(dst) = v;
+        *gptr<u32x4_u>(dst) = v;
     } else { // the cropped end of a row: element stores
         const uint32_t n = width - x;
 #pragma unroll
         for (uint32_t i = 0; i < 8u; i++)
             if (i < n)
-                dst[i] = static_cast<uint16_t>(p[i >> 1] >> (16u * (i & 1u)));
+                gptr<uint16_t>(dst)[i] = static_cast<uint16_t>(p[i >> 1] >> (16u * (i & 1u)));
     }
 }
 
