@@ -111,7 +111,10 @@ static_assert(ROWS_CAP <= 1024u && ROWS_CAP % 2u == 0u, "the division-free row a
 // ------------------------------------------------------------------ k6_decode
 constexpr uint32_t DEC_CH = 4 * ROWS_CH;  // chunks per workgroup: four unpacking waves
 constexpr uint32_t DEC_T = 320;           // ... and a fifth wave: (DEC_CH + 1) * 17 = 289 map walks need five
-constexpr uint32_t TAB8 = HALF6 + 32;     // byte walk table of a chunk: strides, then 32 zeros
+constexpr uint32_t RUN6 = 16;              // table entry at the first of sixteen 2-byte records in a row: jump over them (no record has this stride)
+constexpr uint32_t QTAB = HALF6 / 4 + 32;  // byte walk table of a quarter chunk: 128 strides, then 32 zeros
+constexpr uint32_t TABQ = 4 * QTAB + 32;  // ... of a chunk (+ 32: the tables of neighbouring chunks, which one wave walks at about the same
+                                          // positions, start 8 LDS banks apart)
 static_assert((DEC_CH + 1) * PHASES6 <= DEC_T, "one thread per (chunk, phase)");
 
 #ifdef MCRAW_DIAG // phase stamps of every workgroup (timing experiments only; not in the product library)
@@ -148,20 +151,21 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     constexpr uint32_t NPIECE = (CHUNK6 + OWN + SLACK) / 16; // 16-byte pieces, piece 0 at stream offset (cfirst - 1) * CHUNK6
     constexpr uint32_t NROUND = (NPIECE + DEC_T - 1) / DEC_T;
     __shared__ __attribute__((aligned(16))) uint8_t s_own[OWN + SLACK];
-    // walk tables of the DEC_CH + 1 chunks; dead once the maps are built: the record lists take their place
-    __shared__ __attribute__((aligned(16))) uint8_t s_tab[(DEC_CH + 1) * TAB8];
-    // [chunk][entry phase]: exit phase | records << 5, and the same where the walk crosses the chunk's quarters
-    __shared__ uint16_t s_cmap[(DEC_CH + 1) * PHASES6];
-    __shared__ uint16_t s_qmap[(DEC_CH + 1) * 3 * PHASES6];
+    // walk tables of the DEC_CH + 1 chunks, a quarter chunk at a time: 128 strides, then 32 zeros where a walk that
+    // has left the quarter stays; dead once the records are counted: the record lists take their place
+    __shared__ __attribute__((aligned(16))) uint8_t s_tab[(DEC_CH + 1) * TABQ];
+    __shared__ uint8_t s_qx[(DEC_CH + 1) * 4 * PHASES6]; // [chunk][quarter][entry phase] = phase at which the quarter is left
+    __shared__ uint8_t s_cx[(DEC_CH + 1) * PHASES6];     // [chunk][entry phase] = exit phase: the four composed
     __shared__ uint32_t s_ent[DEC_CH + 1];  // entry of my chunks and of the one behind them: phase | first record << 8
     __shared__ uint32_t s_ent4[DEC_CH * 4]; // ... of every quarter of my chunks
     __shared__ uint32_t s_exits[DEC_CH + 1]; // per chunk: the set of exit phases its 17 walks reach, one bit each
-    __shared__ uint32_t s_ticket, s_coop;
+    __shared__ uint32_t s_ticket, s_coop, s_runs;
     // the list of a round, one of two layouts: every record r at [r - wlo] (up to ROWS_CAP / 2 records: the
     // common case, one LDS read gives both records of a pair), or one entry per PAIR at [(r - wlo) / 2]
     // holding the even record only (up to ROWS_CAP records; the unpacking lane finds the odd one behind it)
     typedef uint16_t PosList[ROWS_CAP / 2 + 2];
     static_assert(sizeof(PosList) * 4 <= sizeof(s_tab), "the lists live where the walk tables were");
+    static_assert((DEC_CH + 1) * TABQ < 65536u, "table addresses fit the walkers' 16 bits");
     PosList *const s_pos = reinterpret_cast<PosList *>(s_tab);
 
 #ifdef MCRAW_DIAG
@@ -171,8 +175,10 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
 #endif
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const uint32_t f = blockIdx.x % nframes;
-    if (tid == 0)
+    if (tid == 0) {
+        s_runs = 0u;
         s_ticket = atomicAdd(tickets + f * TICKET_STRIDE6, 1u);
+    }
     const Plan6 *P = plans + f;
     const uint32_t nchunks = P->nchunks, nrec = P->nrec, len = P->len;
     const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
@@ -204,83 +210,93 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
 #pragma unroll
     for (uint32_t r = 0; r < NROUND; r++) {
         const uint32_t i = tid + r * DEC_T;
+        uint32_t lo = 0, hi = 0;
+        uint8_t *dst = nullptr;
+        bool ones = false;
         if (i < NPIECE && (seg || i >= CHUNK6 / 16u)) {
             if (i >= CHUNK6 / 16u)
                 *reinterpret_cast<uint4 *>(s_own + (i - CHUNK6 / 16u) * 16u) = v[r];
             if (i < (DEC_CH + 1u) * (CHUNK6 / 16u)) {
                 // header candidates are bytes 0 and 2 of every dword
-                const uint32_t lo = stride4(__builtin_amdgcn_perm(v[r].y, v[r].x, 0x06040200u));
-                const uint32_t hi = stride4(__builtin_amdgcn_perm(v[r].w, v[r].z, 0x06040200u));
+                lo = stride4(__builtin_amdgcn_perm(v[r].y, v[r].x, 0x06040200u));
+                hi = stride4(__builtin_amdgcn_perm(v[r].w, v[r].z, 0x06040200u));
                 const uint32_t k = i / (CHUNK6 / 16u), j = i % (CHUNK6 / 16u);
-                *reinterpret_cast<uint2 *>(s_tab + k * TAB8 + j * 8u) = make_uint2(lo, hi);
+                // RawData_Legacy.cpp:387-388,398-399: a record must end before len-1, i.e. the record at half position
+                // q of its chunk with stride d is the chain's end when cs + 2*(q + d) >= len: its stride becomes 0,
+                // the walk stays in front of it
+                const uint32_t cs = (cfirst + k - 1u) * CHUNK6;
+                const uint32_t limq = len > cs ? (len - cs + 1u) >> 1 : 0u;
+                if (limq <= HALF6 + 17u) {
+#pragma unroll
+                    for (uint32_t u = 0; u < 8u; u++) {
+                        uint32_t &wd = u < 4u ? lo : hi;
+                        const uint32_t sh = 8u * (u & 3u);
+                        if (j * 8u + u + ((wd >> sh) & 255u) >= limq)
+                            wd &= ~(255u << sh);
+                    }
+                }
+                // sixteen 2-byte records in a row (a flat or clipped image region would otherwise cost a step per record,
+                // 128 per quarter): a walk that arrives at the first one jumps over all sixteen.  No record has that
+                // stride, so the entry also tells the record count what it stands for.
+                ones = limq > HALF6 + 17u && lo == 0x01010101u && hi == 0x01010101u;
+                dst = s_tab + k * TABQ + (j >> 4) * QTAB + (j & 15u) * 8u;
             }
         }
+        // (pieces i and i + 1 sit in neighbouring lanes; an even piece and its successor share a quarter)
+        const bool next_ones = __shfl_down(ones ? 1u : 0u, 1, 64) != 0u;
+        if (ones && next_ones && (i & 1u) == 0u && (tid & 63u) != 63u) {
+            lo = 0x01010100u | RUN6;
+            s_runs = 1u;
+        }
+        if (dst)
+            *reinterpret_cast<uint2 *>(dst) = make_uint2(lo, hi);
     }
-    if (tid < (DEC_CH + 1u) * 2u)
-        *reinterpret_cast<uint4 *>(s_tab + (tid >> 1) * TAB8 + HALF6 + (tid & 1u) * 16u) = make_uint4(0u, 0u, 0u, 0u);
+    if (tid < (DEC_CH + 1u) * 8u) // 32 zeros behind every quarter
+        *reinterpret_cast<uint4 *>(s_tab + (tid >> 3) * TABQ + ((tid >> 1) & 3u) * QTAB + HALF6 / 4u + (tid & 1u) * 16u) =
+            make_uint4(0u, 0u, 0u, 0u);
     if (tid <= DEC_CH)
         s_exits[tid] = 0u;
     __syncthreads();
     K6_STAMP(1, 0);
     K6_STAMP(9, 256);
 
-    // ---- transition maps: thread (chunk k, phase) walks the table from its phase to the chunk's end, quarter by
-    // quarter, and notes where it crosses into each (the true chain's crossings are where the list walk starts, four
-    // lanes per chunk).  A step is one LDS read and a few VALU instructions with nothing to branch on per lane.
-    if (tid < (DEC_CH + 1u) * PHASES6) {
-        const uint32_t k = tid / PHASES6, ph = tid - k * PHASES6;
-        const uint32_t c = cfirst + k - 1u; // (k = 0: the chunk in front of the segment)
-        if ((k || seg) && c < nchunks) {
-            const uint32_t cs = c * CHUNK6;
-            // RawData_Legacy.cpp:387-388,398-399: a record must end before len-1, i.e. the record at half
-            // position q with stride d is the chain's end when cs + 2*(q + d) >= len
-            const uint32_t limq = len > cs ? (len - cs + 1u) >> 1 : 0u;
-            uint16_t *const qm = s_qmap + k * 3u * PHASES6 + ph;
-            uint32_t q, count = 0;
-            if (limq > HALF6 + 17u) { // no record of this chunk can reach `len`
-                uint32_t A = k * TAB8 + ph;
+    // ---- transition maps, phases only: thread (chunk k, phase) walks the four quarters of its chunk, each from its
+    // phase, side by side -- a step is one LDS read and one addition per walk, four independent walks in flight -- and
+    // notes at which phase each is left; three lookups then compose the chunk's map from the quarters'.
+    const bool mapper = tid < (DEC_CH + 1u) * PHASES6;
+    const uint32_t mk = tid / PHASES6, mph = tid - mk * PHASES6; // (mk = 0: the chunk in front of the segment)
+    const bool mapped = mapper && (mk || seg) && cfirst + mk - 1u < nchunks;
+    if (mapped) {
+        const uint32_t q0 = mk * TABQ + mph;
+        uint32_t A0 = q0, A1 = q0 + QTAB, A2 = q0 + 2u * QTAB, A3 = q0 + 3u * QTAB;
+        const uint32_t end0 = mk * TABQ + HALF6 / 4u; // (end of quarter r: end0 + r * QTAB)
+        uint32_t moved;
+        do { // until no walk of the wave moved any more: each has left its quarter, or stands in front of the chain's
+             // last record (stride 0)
 #pragma unroll
-                for (uint32_t j = 1; j <= 4u; j++) {
-                    const uint32_t bound = k * TAB8 + j * (HALF6 / 4u);
-                    do {
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            const bool in = A < bound;
-                            const uint32_t t = s_tab[A];
-                            count += in ? 1u : 0u;
-                            A += in ? t : 0u;
-                        }
-                    } while (__any(A < bound));
-                    if (j < 4u)
-                        qm[(j - 1u) * PHASES6] = static_cast<uint16_t>((A - bound) | (count << 5));
-                }
-                q = A - k * TAB8;
-            } else {
-                const uint8_t *tab = s_tab + k * TAB8;
-                uint32_t jn = 1; // next quarter to cross
-                q = ph;
-                while (q < HALF6) {
-                    const uint32_t nq = q + tab[q];
-                    if (nq >= limq)
-                        break;
-                    q = nq;
-                    count++;
-                    while (jn < 4u && q >= jn * (HALF6 / 4u)) {
-                        qm[(jn - 1u) * PHASES6] = static_cast<uint16_t>((q - jn * (HALF6 / 4u)) | (count << 5));
-                        jn++;
-                    }
-                }
-                for (; jn < 4u; jn++) // the chain ends in front of these
-                    qm[(jn - 1u) * PHASES6] = static_cast<uint16_t>(DEAD);
+            for (int u = 0; u < 2; u++) {
+                const uint32_t t0 = s_tab[A0], t1 = s_tab[A1], t2 = s_tab[A2], t3 = s_tab[A3];
+                A0 += t0, A1 += t1, A2 += t2, A3 += t3;
+                moved = t0 | t1 | t2 | t3;
             }
-            const uint32_t ex = q < HALF6 ? DEAD : q - HALF6;
-            s_cmap[k * PHASES6 + ph] = static_cast<uint16_t>(ex | (count << 5));
-            atomicOr(&s_exits[k], 1u << ex);
-        }
+        } while (__any(moved != 0u));
+        uint8_t *qx = s_qx + mk * 4u * PHASES6 + mph;
+        qx[0] = static_cast<uint8_t>(A0 < end0 ? DEAD : A0 - end0);
+        qx[PHASES6] = static_cast<uint8_t>(A1 < end0 + QTAB ? DEAD : A1 - (end0 + QTAB));
+        qx[2 * PHASES6] = static_cast<uint8_t>(A2 < end0 + 2u * QTAB ? DEAD : A2 - (end0 + 2u * QTAB));
+        qx[3 * PHASES6] = static_cast<uint8_t>(A3 < end0 + 3u * QTAB ? DEAD : A3 - (end0 + 3u * QTAB));
     }
     __syncthreads();
-    K6_STAMP(2, 0);
-    K6_STAMP(10, 256);
+    if (mapped) {
+        const uint8_t *qx = s_qx + mk * 4u * PHASES6;
+        uint32_t x = mph;
+#pragma unroll
+        for (uint32_t r = 0; r < 4u; r++)
+            x = x == DEAD ? DEAD : qx[r * PHASES6 + x];
+        s_cx[mk * PHASES6 + mph] = static_cast<uint8_t>(x);
+        atomicOr(&s_exits[mk], 1u << x);
+    }
+    __syncthreads();
 
     // ---- entries of my chunks (wave DEC_T / 64 - 1; the others wait at the barrier below)
     const uint32_t cnt = min(static_cast<uint32_t>(DEC_CH), nchunks - cfirst);
@@ -344,7 +360,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
             }
             const uint32_t lp = w & 31u; // phase at which the previous segment's last chunk is entered
             if (lane == 0u) {
-                myp = (lost || lp == DEAD) ? DEAD : s_cmap[lp] & 31u;
+                myp = (lost || lp == DEAD) ? DEAD : s_cx[lp];
                 known = true;
             }
         }
@@ -352,23 +368,60 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
             const uint32_t pp = __shfl_up(myp, 1, 64);
             const bool pk = __shfl_up(known ? 1u : 0u, 1, 64) != 0u;
             if (!known && pk) {
-                myp = pp == DEAD ? DEAD : s_cmap[lane * PHASES6 + pp] & 31u;
+                myp = pp == DEAD ? DEAD : s_cx[lane * PHASES6 + pp];
                 known = true;
             }
         }
-        K6_STAMP(11, 256);
-        // records of my chunk along the true chain, and in front of it within the segment
-        const uint32_t mine = (lane < cnt && myp != DEAD) ? s_cmap[(lane + 1u) * PHASES6 + myp] >> 5 : 0u;
-        uint32_t incl = mine;
+        const uint32_t lastp = __shfl(myp, static_cast<int>(cnt) - 1, 64);
+
+        // ---- the true chain, a quarter chunk per lane (chunk j = lane / 4, quarter r = lane % 4): where it crosses into
+        // the quarter (its chunk's entry through the quarters in front), then how many records it starts there
+        const uint32_t uj = lane >> 2, ur = lane & 3u;
+        const uint32_t cph = __shfl(myp, static_cast<int>(uj), 64);             // entry phase of my chunk
+        const uint32_t aph = __shfl(myp, static_cast<int>(DEC_CH), 64);         // ... of the chunk behind a full segment
+        uint32_t qp = cph;
+        {
+            const uint8_t *qx = s_qx + (uj + 1u) * 4u * PHASES6;
 #pragma unroll
-        for (int d = 1; d < 32; d <<= 1) {
+            for (uint32_t r = 0; r < 3u; r++)
+                if (r < ur)
+                    qp = qp == DEAD ? DEAD : qx[r * PHASES6 + qp];
+        }
+        if (uj >= cnt)
+            qp = DEAD;
+        uint32_t qn = 0;
+        {
+            uint32_t A = (uj + 1u) * TABQ + ur * QTAB + (qp == DEAD ? HALF6 / 4u : qp); // (DEAD: starts on the zeros)
+            uint32_t t;
+            if (s_runs) { // (some walk of this segment may meet a jump over sixteen records)
+                do {
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        t = s_tab[A];
+                        qn += t == RUN6 ? RUN6 : (t ? 1u : 0u);
+                        A += t;
+                    }
+                } while (__any(t != 0u));
+            } else {
+                do {
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        t = s_tab[A];
+                        qn += t ? 1u : 0u;
+                        A += t;
+                    }
+                } while (__any(t != 0u));
+            }
+        }
+        // records in front of my quarter within the segment, and those of the whole segment
+        uint32_t incl = qn;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
             const uint32_t o = __shfl_up(incl, d, 64);
             incl += lane >= static_cast<uint32_t>(d) ? o : 0u;
         }
-        const uint32_t myn = incl - mine;
-        const uint32_t total = __shfl(incl, 31, 64); // (lanes >= cnt add nothing)
-        const uint32_t lastp = __shfl(myp, static_cast<int>(cnt) - 1, 64);
-        K6_STAMP(12, 256);
+        const uint32_t qfirst = incl - qn;
+        const uint32_t total = __shfl(incl, 63, 64); // (quarters behind the stream add nothing)
         // first record index: records of the frame's earlier segments, 64 of them per poll
         uint32_t base = 0;
         if (seg) {
@@ -398,36 +451,22 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                 jn -= 64;
             }
         }
-        K6_STAMP(13, 256);
-        K6_COUNT(14, 1);
-        K6_COUNT(15, spins);
         if (lost) { // (a predecessor never published: fail the frame rather than wait for ever)
             if (lane == 0)
                 atomicOr(P->status, MCRAW_E_DEVICE);
-            myp = DEAD;
+            qp = DEAD;
         }
         // entries carry the record index in 24 bits: a stream with more records than that (the frame itself has
         // fewer, the host checks) saturates instead of wrapping back into the frame
         const uint32_t endn = min(base + total, 0xFFFFFFu);
         if (lane == 0)
             look_put(res, epoch, (RES_PREFIX << 30) | (endn << 5) | (lost ? DEAD : lastp));
-        const uint32_t myi = min(base + myn, 0xFFFFFFu);
-        if (lane <= DEC_CH)
-            s_ent[lane] = lane <= cnt ? (myp | (myi << 8)) : DEAD;
-        // ... and of the quarters of my chunks, from the crossings the true chain's walker noted
-        if (lane < DEC_CH) {
-            const uint16_t *qm = s_qmap + (lane + 1u) * 3u * PHASES6 + myp;
-            s_ent4[lane * 4u] = lane < cnt ? (myp | (myi << 8)) : DEAD;
-#pragma unroll
-            for (uint32_t j = 0; j < 3u; j++) {
-                uint32_t eq = DEAD;
-                if (lane < cnt && myp != DEAD) {
-                    const uint32_t x = qm[j * PHASES6];
-                    eq = (x & 31u) == DEAD ? DEAD : ((x & 31u) | (min(myi + (x >> 5), 0xFFFFFFu) << 8));
-                }
-                s_ent4[lane * 4u + 1u + j] = eq;
-            }
-        }
+        const uint32_t qi = min(base + qfirst, 0xFFFFFFu); // index of my quarter's first record
+        s_ent4[lane] = qp | (qi << 8);
+        if (ur == 0u)
+            s_ent[uj] = uj <= cnt && !lost ? (cph | (qi << 8)) : DEAD;
+        if (lane == 0) // ... and of the chunk behind a full segment
+            s_ent[DEC_CH] = cnt == DEC_CH && !lost ? (aph | (endn << 8)) : DEAD;
         // fewer records than height * recs_per_row inside `len`: the reference would
         // skip the rest and return stale rows (RawData_Legacy.cpp:387-388)
         if (lane == 0 && cfirst + cnt >= nchunks && endn < nrec && !lost)
@@ -454,6 +493,19 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
             if (rg.pairmode) {
                 // an odd first record belongs to the previous wave's last pair: never listed
                 while (p < pe) { // the stride decode, and a store for every second record
+                    // eight 2-byte records fill an aligned 16-byte line whose even bytes all have a zero high nibble:
+                    // one LDS read then lists four pairs instead of one record
+                    if (((p - base) & 15u) == 0u && (idx & 1u) == 0u && idx >= first && p + 16 <= pe) {
+                        const uint4 q = *reinterpret_cast<const uint4 *>(p);
+                        if (((q.x | q.y | q.z | q.w) & 0x00F000F0u) == 0u) {
+#pragma unroll
+                            for (uint32_t k = 0; k < 4u; k++)
+                                s_pos[uw][((idx - first) >> 1) + k] = static_cast<uint16_t>(p - base + 4u * k);
+                            p += 16;
+                            idx += 8u;
+                            continue;
+                        }
+                    }
                     const uint32_t hb = static_cast<uint32_t>(*p) >> 4;
                     if ((idx & 1u) == 0u && idx >= first)
                         s_pos[uw][(idx - first) >> 1] = static_cast<uint16_t>(p - base);
