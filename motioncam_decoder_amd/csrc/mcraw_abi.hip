@@ -20,8 +20,8 @@
 
 namespace mcraw {
 void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st);
-void launch_k6_decode(const Plan6 *plans, const Look6 &look, uint32_t *tickets, uint32_t epoch, int nframes, uint32_t smax,
-                      const Post &post, hipStream_t st);
+void launch_k6_decode(const Plan6 *plans, const uint32_t *wg_tab, uint32_t stage0, uint32_t nwg, const Look6 &look,
+                      uint32_t *tickets, uint32_t epoch, int nframes, uint32_t smax, const Post &post, hipStream_t st);
 } // namespace mcraw
 
 using namespace mcraw;
@@ -214,7 +214,7 @@ inline size_t carve(size_t &off, size_t bytes)
 struct Layout { // byte offsets inside the slot arena / upload image
     size_t status = 0;                                   // int32[n + 1 + n7]
     size_t plans7 = 0;                                   // Plan7[n7]
-    size_t plans6 = 0, tickets = 0;
+    size_t plans6 = 0, tickets = 0, wg_tab = 0;
     size_t upload_bytes = 0;                             // tables end here, workspace follows
     size_t total = 0;
 };
@@ -339,6 +339,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     L.plans7 = carve(off, sizeof(Plan7) * n7);
     L.plans6 = carve(off, sizeof(Plan6) * n6);
     L.tickets = carve(off, sizeof(uint32_t) * TICKET_STRIDE6 * n6); // k6_decode's segment counters: uploaded as zeros
+    L.wg_tab = carve(off, sizeof(uint32_t) * (3 * n6 + 1));         // ... and the order its workgroups take the frames in
     L.upload_bytes = off;
 
     // type-7 workspace: one stride for every frame (the largest frame's), so the
@@ -350,9 +351,29 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     const size_t w_bits = carve(off, Rmax * 64 * n7);
     const size_t w_refs = carve(off, Rmax * 64 * sizeof(uint16_t) * n7);
     const size_t w_grp = carve(off, sizeof(uint32_t) * (Rmax * ITEM_SPLIT + 1) * n7);
+    // k6_decode goes over the legacy frames round by round (round r: segment r of every frame that has one): the
+    // frames by falling number of segments; stage t = the rounds in which all but the t smallest frames are in play
     uint32_t smax = 0; // segments of the longest legacy stream
-    for (const Plan6 &p : B.p6)
-        smax = std::max(smax, (p.nchunks + 4 * ROWS_CH - 1) / (4 * ROWS_CH));
+    std::vector<uint32_t> wg_tab(3 * n6 + 1, 0);
+    {
+        std::vector<uint32_t> nseg(n6), order(n6);
+        for (int k = 0; k < n6; k++) {
+            nseg[k] = (B.p6[k].nchunks + 4 * ROWS_CH - 1) / (4 * ROWS_CH);
+            order[k] = static_cast<uint32_t>(k);
+            smax = std::max(smax, nseg[k]);
+        }
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return nseg[a] > nseg[b]; });
+        uint32_t lo = 0, base = 0;
+        for (int t = 0; t < n6; t++) {
+            const uint32_t hi = nseg[order[n6 - 1 - t]]; // the smallest frame still in play leaves after this round
+            wg_tab[t] = base;
+            wg_tab[n6 + 1 + t] = lo;
+            wg_tab[2 * n6 + 1 + t] = order[t];
+            base += static_cast<uint32_t>(n6 - t) * (hi - lo);
+            lo = hi;
+        }
+        wg_tab[n6] = base; // = segments of all frames
+    }
     L.total = off;
     if (n6) {
         const size_t need = sizeof(uint64_t) * smax * static_cast<size_t>(n6);
@@ -385,6 +406,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     for (int k = 0; k < n6; k++)
         B.p6[k].status = reinterpret_cast<int32_t *>(dev + L.status) + 2 * n7 + k;
     if (n6) {
+        std::memcpy(img + L.wg_tab, wg_tab.data(), sizeof(uint32_t) * wg_tab.size());
         std::memcpy(img + L.plans6, B.p6.data(), sizeof(Plan6) * n6);
         std::memset(img + L.tickets, 0, sizeof(uint32_t) * TICKET_STRIDE6 * n6);
     }
@@ -423,7 +445,8 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         Look6 lk;
         lk.res = static_cast<uint64_t *>(s.look.p);
         KTimer t(c, MCRAW_K6_DECODE, st);
-        launch_k6_decode(dp, lk, reinterpret_cast<uint32_t *>(dev + L.tickets), s.look_epoch, n6, smax, c->post, st);
+        launch_k6_decode(dp, reinterpret_cast<const uint32_t *>(dev + L.wg_tab), n6 > 1 ? wg_tab[1] : wg_tab[n6], wg_tab[n6], lk,
+                         reinterpret_cast<uint32_t *>(dev + L.tickets), s.look_epoch, n6, smax, c->post, st);
     }
     HIP_TRY(hipGetLastError());
     *status_off = L.status;

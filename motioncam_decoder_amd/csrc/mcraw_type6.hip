@@ -134,16 +134,16 @@ __device__ uint32_t g_k6_prof[K6_PROF_WG][16];
 #define K6_COUNT(slot, v)
 #endif
 
-// Workgroup b works on frame b % nframes (a segment's predecessors then started long before it) and takes its
-// segment -- DEC_CH chunks -- from the frame's ticket counter: the segments it may have to wait on were all taken by
+// A workgroup works on ONE frame (the launch interleaves the frames: a segment's predecessors then started long before
+// it) and takes its segment -- DEC_CH chunks -- from the frame's ticket counter: the segments it may have to wait on were all taken by
 // workgroups that are running or done, whatever order the hardware starts workgroups in.  (One counter per frame,
 // each in its own 256 bytes: one counter for the batch serialised the launch -- 31 000 device-scope atomics on one
 // address took 0.37 ms.)  Five waves: 17 x 17 map walks need 289 threads; the fifth wave then resolves the entries
 // while the other four wait, and leaves; those four unpack.
 template <int POST> // 0 = the plain mosaic, else bits per sample of the post stage's rows
-__global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ plans, const Look6 look,
-                                                   uint32_t *__restrict__ tickets, uint32_t epoch, uint32_t nframes,
-                                                   uint32_t smax, const Post post)
+__global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ plans, const uint32_t *__restrict__ wg_tab,
+                                                   uint32_t stage0, const Look6 look, uint32_t *__restrict__ tickets,
+                                                   uint32_t epoch, uint32_t nframes, uint32_t smax, const Post post)
 {
     // the segment's stream: its DEC_CH chunks and the reach of a record that starts 32 bytes past them (the chunk in
     // front of them, whose map tells where the segment is entered, only becomes a walk table)
@@ -174,7 +174,15 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         g_k6_prof[blockIdx.x][6] = static_cast<uint32_t>(stamp_);
 #endif
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    const uint32_t f = blockIdx.x % nframes;
+    // Which frame this workgroup works on, and the segment it will most likely be given: the launch goes over the
+    // frames round by round -- round r = segment r of every frame that has one --, so a frame's segments start in order
+    // and far apart, and no workgroup is launched for nothing however the frames' sizes differ (the host's table: the
+    // frames by falling size; stage t = the rounds in which all but the t smallest are still in play).
+    // (the rounds that every frame takes part in need no table: most batches hold frames of one size)
+    const bool all_in = blockIdx.x < stage0;
+    const uint32_t stage = all_in ? 0u : static_cast<uint32_t>(find_frame(blockIdx.x, wg_tab, static_cast<int>(nframes)));
+    const uint32_t inplay = nframes - stage, wrel = all_in ? blockIdx.x : blockIdx.x - wg_tab[stage];
+    const uint32_t f = all_in ? wrel % inplay : wg_tab[2u * nframes + 1u + wrel % inplay];
     if (tid == 0) {
         s_runs = 0u;
         s_ticket = atomicAdd(tickets + f * TICKET_STRIDE6, 1u);
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
     // the ticket takes a round trip to the frame's counter: start loading what it will almost certainly say
     // (workgroups start in order), and load again if it says otherwise
-    uint32_t seg = blockIdx.x / nframes;
+    uint32_t seg = (all_in ? 0u : wg_tab[nframes + 1u + stage]) + wrel / inplay;
     uint4 v[NROUND];
     auto fetch = [&]() { // piece i at stream offset (seg * DEC_CH - 1) * CHUNK6 + 16 i; past `len`: reads 0
 #pragma unroll
@@ -685,20 +693,25 @@ extern "C" void mcraw_diag_k6_prof(uint32_t *out, int nwg, int reset)
 }
 #endif
 
-void launch_k6_decode(const Plan6 *plans, const Look6 &look, uint32_t *tickets, uint32_t epoch, int nframes, uint32_t smax,
-                      const Post &post, hipStream_t st)
+// wg_tab (3 * nframes + 1 words, see k6_decode): [0, nframes]: first workgroup of every stage; then the stages' first
+// rounds; then the frames by falling number of segments.  `stage0`: workgroups of the rounds every frame takes part in
+// (= wg_tab[1]); `nwg`: segments of all frames together.
+void launch_k6_decode(const Plan6 *plans, const uint32_t *wg_tab, uint32_t stage0, uint32_t nwg, const Look6 &look,
+                      uint32_t *tickets, uint32_t epoch, int nframes, uint32_t smax, const Post &post, hipStream_t st)
 {
-    const dim3 grid(smax * static_cast<uint32_t>(nframes)), block(DEC_T);
+    if (!nwg)
+        return;
+    const dim3 grid(nwg), block(DEC_T);
     const uint32_t nf = static_cast<uint32_t>(nframes);
     if (post.mode == 0u) {
-        hipLaunchKernelGGL(k6_decode<0>, grid, block, 0, st, plans, look, tickets, epoch, nf, smax, post);
+        hipLaunchKernelGGL(k6_decode<0>, grid, block, 0, st, plans, wg_tab, stage0, look, tickets, epoch, nf, smax, post);
         return;
     }
     switch (post_bits(post.mode)) { // one kernel instance per row format
-    case 12: hipLaunchKernelGGL(k6_decode<12>, grid, block, 0, st, plans, look, tickets, epoch, nf, smax, post); break;
-    case 10: hipLaunchKernelGGL(k6_decode<10>, grid, block, 0, st, plans, look, tickets, epoch, nf, smax, post); break;
-    case 14: hipLaunchKernelGGL(k6_decode<14>, grid, block, 0, st, plans, look, tickets, epoch, nf, smax, post); break;
-    default: hipLaunchKernelGGL(k6_decode<16>, grid, block, 0, st, plans, look, tickets, epoch, nf, smax, post); break;
+    case 12: hipLaunchKernelGGL(k6_decode<12>, grid, block, 0, st, plans, wg_tab, stage0, look, tickets, epoch, nf, smax, post); break;
+    case 10: hipLaunchKernelGGL(k6_decode<10>, grid, block, 0, st, plans, wg_tab, stage0, look, tickets, epoch, nf, smax, post); break;
+    case 14: hipLaunchKernelGGL(k6_decode<14>, grid, block, 0, st, plans, wg_tab, stage0, look, tickets, epoch, nf, smax, post); break;
+    default: hipLaunchKernelGGL(k6_decode<16>, grid, block, 0, st, plans, wg_tab, stage0, look, tickets, epoch, nf, smax, post); break;
     }
 }
 
