@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import _libs as L
+import motioncam_decoder_amd as M
 
 pytestmark = pytest.mark.gpu
 
@@ -293,3 +294,64 @@ def test_frames_decoded_in_place_from_a_file_image_in_hbm(gpu_ctx, tmp_path):
     for (ts, typ, w, h), o, wr, st in zip(specs, outs, written, status):
         assert st == 0 and wr == w * h, (ts, typ, st)
         assert np.array_equal(o.cpu().numpy().view(np.uint16).reshape(h, w), images[ts]), ts
+
+
+def test_legacy_batch_of_very_different_stream_lengths(gpu_ctx):
+    # k6_decode launches one workgroup per 16 KiB segment, round by round over the frames sorted by size: a batch of a
+    # one-chunk frame, a few-segment frame and many-segment frames (the rounds in which only the largest frames are still
+    # in play), decoded twice (the second batch finds the look-back state of the first: older epoch, must read as empty)
+    rng = np.random.default_rng(4242)
+    shapes = ((64, 4, 10), (4000, 3000, 12), (320, 200, 12), (1920, 1080, 14), (1000, 37, 10), (4032, 3024, 10), (96, 8, 16))
+    items, expect = [], []
+    for k, (w, h, nb) in enumerate(shapes):
+        img = L.natural_image_np(w, h, min(nb, 14), 12.0, 900 + k) if k % 2 else rng.integers(0, 1 << nb, size=(h, w), dtype=np.uint16)
+        buf = L.encode6(img)
+        ret, out = L.oracle_decode6(buf, w, h)
+        assert ret == w * h and np.array_equal(out, img)
+        items.append((6, w, h, buf))
+        expect.append((ret, out))
+    _check(gpu_ctx, items, expect)
+    _check(gpu_ctx, items[::-1], expect[::-1])
+
+
+def test_legacy_streams_whose_chunk_maps_are_never_unanimous(gpu_ctx):
+    # Uniform 16-bit samples: every record is raw (stride 34) and the payload is noise, and -- the harder case -- a
+    # frame of ONE record size whose payload repeats the header pattern, so that all 17 phases of a chunk are chains of
+    # their own that never meet: no chunk map is unanimous, every segment has to take its entry phase from the
+    # segment in front of it (k6_decode's look-back carries it)
+    rng = np.random.default_rng(99)
+    items, expect = [], []
+    w, h = 1920, 270
+    img = rng.integers(0, 65536, size=(h, w), dtype=np.uint16)
+    buf = L.encode6(img)
+    ret, out = L.oracle_decode6(buf, w, h)
+    assert ret == w * h and np.array_equal(out, img)
+    items.append((6, w, h, buf))
+    expect.append((ret, out))
+    # payload bytes that read as headers of the same record size: the constant 0xBFFF is coded with the reference 0xFFF
+    # and raw residuals 0xB000, so every even byte of the stream -- the headers' 0xFF and the payload's 0xB0 -- has a
+    # nibble >= 11 = "raw record, 34 bytes"
+    img2 = np.full((h, w), 0xBFFF, np.uint16)
+    buf2 = L.encode6(img2)
+    assert all((int(b) >> 4) >= 11 for b in buf2[0:4096:2])
+    ret2, out2 = L.oracle_decode6(buf2, w, h)
+    assert ret2 == w * h and np.array_equal(out2, img2)
+    items.append((6, w, h, buf2))
+    expect.append((ret2, out2))
+    _check(gpu_ctx, items, expect)
+
+
+def test_legacy_stream_cut_inside_a_late_segment(gpu_ctx):
+    # a many-segment stream that ends in the middle of a record far from its start: the chain dies there, every later
+    # chunk is entered by nothing, the frame fails as truncated and its neighbours decode
+    from _gpu import decode_batch_device
+    w, h = 1920, 540
+    img = L.natural_image_np(w, h, 12, 12.0, 31)
+    good = L.encode6(img)
+    cut = good[: (good.size * 2 // 3) | 1].copy()
+    ret, _ = L.oracle_decode6(cut, w, h)
+    assert ret == 0
+    written, status, outs = decode_batch_device(gpu_ctx, [(6, w, h, good), (6, w, h, cut), (6, w, h, good)])
+    assert status[0] == 0 and status[2] == 0 and written[0] == w * h and written[2] == w * h
+    assert np.array_equal(outs[0], img) and np.array_equal(outs[2], img)
+    assert status[1] & M.E_TRUNCATED and written[1] == 0
