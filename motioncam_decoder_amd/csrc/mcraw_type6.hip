@@ -295,6 +295,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         qx[3 * PHASES6] = static_cast<uint8_t>(A3 < end0 + 3u * QTAB ? DEAD : A3 - (end0 + 3u * QTAB));
     }
     __syncthreads();
+    K6_STAMP(2, 0);
     if (mapped) {
         const uint8_t *qx = s_qx + mk * 4u * PHASES6;
         uint32_t x = mph;
@@ -381,6 +382,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
             }
         }
         const uint32_t lastp = __shfl(myp, static_cast<int>(cnt) - 1, 64);
+        K6_STAMP(10, 256);
 
         // ---- the true chain, a quarter chunk per lane (chunk j = lane / 4, quarter r = lane % 4): where it crosses into
         // the quarter (its chunk's entry through the quarters in front), then how many records it starts there
@@ -421,6 +423,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                 } while (__any(t != 0u));
             }
         }
+        K6_STAMP(11, 256);
         // records in front of my quarter within the segment, and those of the whole segment
         uint32_t incl = qn;
 #pragma unroll
@@ -459,6 +462,9 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                 jn -= 64;
             }
         }
+        K6_STAMP(12, 256);
+        K6_COUNT(14, 1);
+        K6_COUNT(15, spins);
         if (lost) { // (a predecessor never published: fail the frame rather than wait for ever)
             if (lane == 0)
                 atomicOr(P->status, MCRAW_E_DEVICE);
@@ -537,6 +543,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                     *lp = static_cast<uint16_t>(p - base);
             }
         }
+        K6_STAMP(13, 256);
     }
     __syncthreads();
     K6_STAMP(3, 0);

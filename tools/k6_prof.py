@@ -35,10 +35,10 @@ torch.cuda.synchronize()
 lib.mcraw_diag_k6_prof(pp, NWG, 1)   # stamps of the last launch
 live = prof[:, 14] == 1
 P = prof[live].astype(np.float64)
-names = {0: "w0 ticket", 1: "w0 load+table", 2: "w0 maps", 3: "w0 wait resolve", 4: "w0 list walk", 5: "w0 unpack",
-         8: "w4 ticket", 9: "w4 load+table", 10: "w4 maps", 11: "w4 entry phase", 12: "w4 chain", 13: "w4 window"}
+names = {0: "w0 ticket+load", 1: "w0 stage+table", 2: "w0 map walks", 3: "w0 compose + wait for wave 4", 4: "w0 (lists ready)", 5: "w0 unpack",
+         8: "w4 ticket+load", 9: "w4 stage+table", 10: "w4 maps+compose+entry", 11: "w4 crossings+counts", 12: "w4 scan+look-back", 13: "w4 entries+lists"}
 for i, nm in names.items():
-    print("%-18s mean %8.0f  p50 %8.0f  p90 %8.0f ticks" % (nm, P[:, i].mean(), np.median(P[:, i]), np.percentile(P[:, i], 90)))
+    print("%-30s mean %8.0f  p50 %8.0f  p90 %8.0f ticks" % (nm, P[:, i].mean(), np.median(P[:, i]), np.percentile(P[:, i], 90)))
 print("workgroups", live.sum(), "lifetime mean", P[:, 0:6].sum(axis=1).mean(), "spins/wg", P[:, 15].mean(), "max", P[:, 15].max())
 Q = P[P[:, 7] > 0]; t0 = Q[:, 6].min(); span = ((Q[:, 7] - t0) % 2**32).max()
 print("kernel span ticks", span, "-> concurrency", P[:, 0:6].sum() / span, "wgs in flight; tick rate MHz ~", span / (ctx.kernel_ms("k6_decode")[0] / reps * 1e3))
