@@ -420,9 +420,23 @@ def legacy_leg(torch, ctx, M, L, dev, n=32, w=4000, h=3000, nbits=12, sigma=12.0
     t = (time.perf_counter() - t0) / reps
     kms = {k: round(ctx.kernel_ms(k, reset=True)[0] / reps, 4) for k in ("k6_decode",)}
     byts = sum(bufs[i % 4].size for i in range(n)) + n * w * h * 2
-    return {"workload": "%d x %dx%d %d-bit type-6 frames, Nat" % (n, w, h, nbits), "ms_per_batch": round(t * 1e3, 4),
-            "mpix_s": round(n * w * h / t / 1e6, 1), "in_plus_out_GBs": round(byts / t / 1e9, 1),
-            "input_bpp": round(8.0 * bufs[0].size / (w * h), 2), "kernels_ms": kms, "bit_exact": bool(ok)}
+    out = {"workload": "%d x %dx%d %d-bit type-6 frames, Nat" % (n, w, h, nbits), "ms_per_batch": round(t * 1e3, 4),
+           "mpix_s": round(n * w * h / t / 1e6, 1), "in_plus_out_GBs": round(byts / t / 1e9, 1),
+           "input_bpp": round(8.0 * bufs[0].size / (w * h), 2), "kernels_ms": kms, "bit_exact": bool(ok)}
+    # the same roofline figures as for the bench line: the batch (wall) and its one kernel against the HBM peak, and the
+    # HBM traffic of that kernel from the committed counter passes (tools/pmc_legacy.sh; not measured in this run)
+    out["step_frac"] = round(byts / t / 1e9 / 8000.0, 4)
+    if kms["k6_decode"] > 0:
+        out["frac"] = round(byts / (kms["k6_decode"] * 1e-3) / 1e9 / 8000.0, 4)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_legacy_traffic.json")) as f:
+            tj = json.load(f)
+        out["traffic"] = tj["total_bytes_per_batch"]
+        out["algorithmic_bytes_per_batch"] = byts
+        out["traffic_source"] = "profiles/r02_legacy_traffic.json (rocprofv3 --pmc passes of tools/bench_legacy.py, committed; not measured in this run)"
+    except Exception:
+        pass
+    return out
 
 
 def traffic_from_profile(workload_key):
