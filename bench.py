@@ -587,6 +587,8 @@ def main():
             "data": "synthetic: %d seeded distinct frames per rank (own encoder), replicated to %d frames at distinct "
                     "HBM addresses; inputs resident in HBM before the timed region" % (len(wl.pairs), args.frames),
             "bit_exact": results[args.dist]["ok"],
+            "bit_exact_scope": "sanity flag: sampled output frames of the timed buffers equal the images the encoder was given; "
+                               "parity against the oracle / reference is what tests/ -m gpu checks",
             "frames_per_s": round(world * args.frames / (s["st"]["median"] * 1e-3), 1),
             "config": {"workload": wname, "baseline_config": args.config, "frames_per_gpu": args.frames, "width": args.width,
                        "height": args.height, "bits": args.nbits, "encoding": 7, "input_bpp": round(s["bpp"], 2),
