@@ -131,7 +131,10 @@ __device__ __forceinline__ void post_pack12(const uint32_t p[4], uint32_t o[3])
     for (int i = 0; i < 4; i++) {
         const uint32_t c = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(mcraw_u16x2, p[i]),
                                                                                   __builtin_bit_cast(mcraw_u16x2, 0x0FFF0FFFu)));
-        t[i] = ((c << 12) & 0x00FFF000u) | (c >> 16);
+        // a << 12 | b in two instructions: the low half of c times 4096 plus its high half (v_mad_u32_u16 reads halves)
+        uint32_t ti;
+        asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(ti) : "v"(c), "s"(4096u), "v"(c >> 16));
+        t[i] = ti;
     }
     // memory order: t0.b2 t0.b1 t0.b0 | t1.b2 t1.b1 t1.b0 | ...
     o[0] = __builtin_amdgcn_perm(t[1], t[0], 0x06000102u);
