@@ -376,7 +376,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     }
     L.total = off;
     if (n6) {
-        const size_t need = sizeof(uint64_t) * smax * static_cast<size_t>(n6);
+        const size_t need = sizeof(uint64_t) * 5 * smax * static_cast<size_t>(n6); // res, ex, hm[3] per segment
         if (need > s.look.cap) {
             if (int rc = ensure(s.look, need, false))
                 return rc;
@@ -444,6 +444,8 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         const Plan6 *dp = reinterpret_cast<const Plan6 *>(dev + L.plans6);
         Look6 lk;
         lk.res = static_cast<uint64_t *>(s.look.p);
+        lk.ex = lk.res + static_cast<size_t>(smax) * n6;
+        lk.hm = lk.ex + static_cast<size_t>(smax) * n6;
         KTimer t(c, MCRAW_K6_DECODE, st);
         launch_k6_decode(dp, reinterpret_cast<const uint32_t *>(dev + L.wg_tab), n6 > 1 ? wg_tab[1] : wg_tab[n6], wg_tab[n6], lk,
                          reinterpret_cast<uint32_t *>(dev + L.tickets), s.look_epoch, n6, smax, c->post, st);

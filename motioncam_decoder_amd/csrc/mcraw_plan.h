@@ -123,11 +123,14 @@ constexpr int PHASES6 = 17;  // entry offsets 0,2,..,32 (record stride <= 34, al
 
 // Look-back state of the legacy frames' segments (k6_decode), in a buffer that lives as long as its slot and is never
 // cleared: every 64-bit word carries the epoch of the launch that wrote it in its high half (a poll of 64
-// predecessors reads four cache lines):
-//   res[frame * smax + segment] = state << 30 | records << 5 | phase at which the segment's last chunk is entered;
-//   state 1: records of this segment alone, 2: records of the frame up to the end of this segment
+// predecessors reads four cache lines of an array).  Per segment (index frame * smax + segment):
+//   res  state << 30 | records << 5 | exit phase: state 1 = records of this segment alone, 2 = records of the frame up to
+//        the end of this segment; exit phase = the phase at which the NEXT segment's first chunk is entered
+//   ex   the same exit phase said earlier, before the segment knows its own entry: kind << 30 | phase, kind 1 = a phase
+//        (one of the segment's chunk maps is unanimous), 2 = it depends on the segment's entry: the map is in hm
+//   hm   [3] that map, entry phase -> exit phase, six 5-bit phases per word
 struct Look6 {
-    uint64_t *res;
+    uint64_t *res, *ex, *hm;
 };
 
 } // namespace mcraw

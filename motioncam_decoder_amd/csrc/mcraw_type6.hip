@@ -43,6 +43,7 @@ __device__ __forceinline__ uint32_t stride4(uint32_t hdr4)
 // of earlier launches carry older epochs and read as "not there yet"), the payload in the low half.  Every word is
 // complete in itself, so publishing one is a single relaxed store at device scope and needs no fence.
 constexpr uint32_t RES_AGG = 1u, RES_PREFIX = 2u; // Look6::res payload: state << 30 | records << 5 | exit phase
+constexpr uint32_t EX_PHASE = 1u, EX_MAP = 2u;    // Look6::ex payload: kind << 30 | exit phase (kind 1)
 constexpr uint32_t SPIN6 = 1u << 20;              // polls before a workgroup gives the frame up (never seen; a hang is worse)
 
 __device__ __forceinline__ void look_put(uint64_t *w, uint32_t epoch, uint32_t v)
@@ -336,13 +337,14 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         return g;
     };
     if (wave == DEC_T / 64u - 1u) {
-        uint64_t *const res = look.res + static_cast<size_t>(f) * smax + seg; // mine; res[-k]: k segments before me
+        const size_t lme = static_cast<size_t>(f) * smax + seg;
+        uint64_t *const res = look.res + lme; // mine; res[-k]: k segments before me
         uint32_t spins = 0, w = 0;
         bool lost = false;
         // Entry phase of chunk j (lane j; lane cnt: of the chunk behind the segment): the map of the chunk in front
         // of it almost always sends all 17 phases to ONE exit (a wrong chain reads payload bytes as headers and falls
         // onto the true one within a few hundred bytes), so every lane knows its own at once; a lane whose map is
-        // not unanimous takes the entry of the chunk in front through that map -- lane 0 from the previous segment.
+        // not unanimous takes the entry of the chunk in front through that map.
         uint32_t myp = DEAD;
         bool known = false;
         if (lane <= cnt) {
@@ -357,31 +359,103 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         } else {
             known = true;
         }
-        if (!__builtin_amdgcn_readfirstlane(known ? 1u : 0u)) { // lane 0: ask the previous segment
-            for (;;) { // (uniform: every lane reads the same word)
-                if (look_get(res - 1, epoch, &w) && (w >> 30) != 0u)
-                    break;
-                if (++spins > SPIN6) {
-                    lost = true;
-                    break;
+        auto propagate = [&]() { // (rare; at most cnt rounds)
+            for (;;) {
+                const uint32_t pp = __shfl_up(myp, 1, 64);
+                const uint32_t kk = __shfl_up(known ? 1u : 0u, 1, 64); // (every lane takes part in the shuffle)
+                const bool pk = lane != 0u && kk != 0u;
+                const bool now = !known && pk;
+                if (now) {
+                    myp = pp == DEAD ? DEAD : s_cx[lane * PHASES6 + pp];
+                    known = true;
                 }
-                __builtin_amdgcn_s_sleep(2);
+                if (__ballot(now) == 0ull)
+                    break;
             }
-            const uint32_t lp = w & 31u; // phase at which the previous segment's last chunk is entered
+        };
+        propagate();
+        // What the NEXT segment is entered at, said as early as it can be said: a phase when one of my chunks' maps is
+        // unanimous (whatever I am entered at myself), else -- a stream whose every chunk keeps its 17 chains apart --
+        // the map from my entry phase to it, for my successors to go through while I still wait for mine.
+        const bool full = cnt == DEC_CH;
+        const bool exit_known = __shfl(known ? 1u : 0u, static_cast<int>(DEC_CH), 64) != 0u;
+        if (full && exit_known) {
+            const uint32_t xp = __shfl(myp, static_cast<int>(DEC_CH), 64);
+            if (lane == 0)
+                look_put(look.ex + lme, epoch, (EX_PHASE << 30) | xp);
+        } else if (full) {
+            uint32_t x = lane < PHASES6 ? lane : DEAD;
+            for (uint32_t k = 1; k <= DEC_CH; k++)
+                x = x == DEAD ? DEAD : s_cx[k * PHASES6 + x];
+            uint32_t hw = 0;
+#pragma unroll
+            for (uint32_t e = 0; e < 6u; e++) {
+                const uint32_t src = lane * 6u + e;
+                const uint32_t xe = __shfl(x, static_cast<int>(src & 63u), 64);
+                hw |= (src < PHASES6 ? xe : DEAD) << (5u * e);
+            }
+            if (lane < 3u)
+                look_put(look.hm + 3u * lme + lane, epoch, hw);
+            if (lane == 0)
+                look_put(look.ex + lme, epoch, EX_MAP << 30);
+        }
+        if (!__builtin_amdgcn_readfirstlane(known ? 1u : 0u)) {
+            // Lane 0 does not know the segment's own entry: the nearest segment in front whose exit is known -- it has
+            // resolved and published its records, or said a phase above --, and from there through the maps of the
+            // segments in between (64 segments per poll; the frame itself is entered at phase 0).
+            uint32_t ep = DEAD;
+            bool got = false;
+            while (!got && !lost) {
+                const int32_t k = static_cast<int32_t>(seg) - 1 - static_cast<int32_t>(lane); // segment of this lane
+                bool kn = false, mp = false;
+                uint32_t ph = DEAD, h0 = 0, h1 = 0, h2 = 0;
+                if (k == -1) {
+                    kn = true;
+                    ph = 0u;
+                } else if (k >= 0) {
+                    uint32_t vr = 0, vx = 0;
+                    const size_t ks = lme - seg + static_cast<uint32_t>(k);
+                    const bool rok = look_get(look.res + ks, epoch, &vr) && (vr >> 30) != 0u;
+                    const bool xok = look_get(look.ex + ks, epoch, &vx);
+                    if (rok) {
+                        kn = true;
+                        ph = vr & 31u;
+                    } else if (xok && (vx >> 30) == EX_PHASE) {
+                        kn = true;
+                        ph = vx & 31u;
+                    } else if (xok && (vx >> 30) == EX_MAP) {
+                        const bool m0 = look_get(look.hm + 3u * ks, epoch, &h0), m1 = look_get(look.hm + 3u * ks + 1u, epoch, &h1),
+                                   m2 = look_get(look.hm + 3u * ks + 2u, epoch, &h2);
+                        mp = m0 && m1 && m2;
+                    }
+                }
+                const uint64_t km = __ballot(kn), mm = __ballot(mp);
+                const uint32_t i0 = km ? static_cast<uint32_t>(__builtin_ctzll(km)) : 64u;
+                const uint64_t front = i0 >= 64u ? ~0ull : (1ull << i0) - 1ull; // the segments between that one and me
+                if (i0 < 64u && (mm & front) == front) {
+                    uint32_t p = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ph), static_cast<int>(i0)));
+                    for (uint32_t t = i0; t-- > 0u && p != DEAD;) {
+                        const uint32_t w0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(h0), static_cast<int>(t)));
+                        const uint32_t w1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(h1), static_cast<int>(t)));
+                        const uint32_t w2 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(h2), static_cast<int>(t)));
+                        const uint32_t hw = p < 6u ? w0 : p < 12u ? w1 : w2;
+                        p = (hw >> (5u * (p % 6u))) & 31u;
+                    }
+                    ep = p;
+                    got = true;
+                } else {
+                    if (++spins > SPIN6)
+                        lost = true;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
             if (lane == 0u) {
-                myp = (lost || lp == DEAD) ? DEAD : s_cx[lp];
+                myp = lost ? DEAD : ep;
                 known = true;
             }
+            propagate();
         }
-        while (__ballot(!known)) { // (rare; at most cnt rounds)
-            const uint32_t pp = __shfl_up(myp, 1, 64);
-            const bool pk = __shfl_up(known ? 1u : 0u, 1, 64) != 0u;
-            if (!known && pk) {
-                myp = pp == DEAD ? DEAD : s_cx[lane * PHASES6 + pp];
-                known = true;
-            }
-        }
-        const uint32_t lastp = __shfl(myp, static_cast<int>(cnt) - 1, 64);
+        const uint32_t lastp = full ? __shfl(myp, static_cast<int>(DEC_CH), 64) : DEAD; // the segment's exit phase: what the next one is entered at
         K6_STAMP(10, 256);
 
         // ---- the true chain, a quarter chunk per lane (chunk j = lane / 4, quarter r = lane % 4): where it crosses into
