@@ -251,11 +251,15 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                 dst = s_tab + k * TABQ + (j >> 4) * QTAB + (j & 15u) * 8u;
             }
         }
-        // (pieces i and i + 1 sit in neighbouring lanes; an even piece and its successor share a quarter)
-        const bool next_ones = __shfl_down(ones ? 1u : 0u, 1, 64) != 0u;
-        if (ones && next_ones && (i & 1u) == 0u && (tid & 63u) != 63u) {
-            lo = 0x01010100u | RUN6;
-            s_runs = 1u;
+        // (pieces i and i + 1 sit in neighbouring lanes; an even piece and its successor share a quarter; most waves
+        // hold no such piece at all and skip this)
+        const unsigned long long om = __ballot(ones);
+        if (om & (om >> 1)) {
+            const bool next_ones = ((om >> (lane & 63u)) >> 1) & 1ull;
+            if (ones && next_ones && (i & 1u) == 0u) {
+                lo = 0x01010100u | RUN6;
+                s_runs = 1u;
+            }
         }
         if (dst)
             *reinterpret_cast<uint2 *>(dst) = make_uint2(lo, hi);

@@ -14,7 +14,8 @@ import motioncam_decoder_amd as M
 
 w, h, n = 4000, 3000, int(os.environ.get("N", "32"))
 dev = torch.device("cuda:0")
-imgs = [L.synth_image(w, h, 12, 1, 12.0, 6000 + i) for i in range(4)]
+NB, DIST = int(os.environ.get("NB", "12")), int(os.environ.get("DIST", "1"))  # bits per sample; 1 = natural, 0 = uniform noise
+imgs = [L.synth_image(w, h, NB, DIST, 12.0, 6000 + i) for i in range(4)]
 bufs = [L.encode6(im) for im in imgs]
 tin = [torch.from_numpy(bufs[i % 4]).to(dev) for i in range(n)]
 tout = torch.zeros(n * w * h * 2, dtype=torch.uint8, device=dev)
