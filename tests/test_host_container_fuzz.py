@@ -57,7 +57,7 @@ def test_container_reader_survives_mutated_files(tmp_path):
             b[pos:pos + 4] = np.frombuffer(np.uint32(rng.integers(0, 2 ** 32)).tobytes(), np.uint8)
         p = str(tmp_path / "m.mcraw")
         b.tofile(p)
-        r = subprocess.run([exe, p, "x"], capture_output=True, env=env, timeout=30)  # a hang fails the test here
+        r = subprocess.run([exe, p, "x"], capture_output=True, env=env, timeout=120)  # a hang fails the test here
         err = r.stderr.decode("utf-8", "replace")
         assert "AddressSanitizer" not in err and "runtime error" not in err, (trial, mode, err[-800:])
         if r.returncode not in (0, 1):
