@@ -137,6 +137,16 @@ int mcraw_pool_decode_batch(mcraw_pool *pool, const mcraw_frame *frames, int nfr
 int mcraw_pool_decode_batch_async(mcraw_pool *pool, const mcraw_frame *frames, int nframes, mcraw_pool_ticket **ticket);
 int mcraw_pool_ticket_wait(mcraw_pool_ticket *ticket, size_t *written, int32_t *status);
 
+/* The order in which the legacy kernel's workgroups take the segments (16 KiB of stream each) of a batch's legacy frames,
+ * as the library builds it for every batch; exported so that the rule can be checked without a GPU.  `nseg[n]`: segments per
+ * frame.  The launch goes round by round -- round r = segment r of every frame that has one --, the frames by falling
+ * number of segments; stage t = the rounds in which all but the t smallest frames are in play.  `tab` receives 3 n + 1
+ * words: [0, n]: first workgroup of every stage (tab[n] = workgroups in all = segments of all frames); [n + 1, 2n]: first
+ * round of every stage; [2n + 1, 3n]: the frames in that order.  Workgroup b of stage t works on frame
+ * tab[2n + 1 + (b - tab[t]) % (n - t)] and is given -- if workgroups start in order -- segment
+ * tab[n + 1 + t] + (b - tab[t]) / (n - t). */
+void mcraw_legacy_launch_order(const uint32_t *nseg, int n, uint32_t *tab);
+
 /* ---- measurement -------------------------------------------------------- */
 
 /* Kernel ids for mcraw_ctx_kernel_ms. */

@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "mcraw_ctx_create", "mcraw_ctx_destroy", "mcraw_last_error", "mcraw_decode7", "mcraw_decode6",
     "mcraw_decode_batch", "mcraw_ctx_synchronize", "mcraw_ctx_profile", "mcraw_ctx_kernel_ms",
     "mcraw_host_alloc", "mcraw_host_free", "mcraw_ctx_set_post", "mcraw_decode_batch_async", "mcraw_ticket_wait",
-    "mcraw_ctx_profile_every", "mcraw_shard_of", "mcraw_shard_count", "mcraw_pool_create", "mcraw_pool_destroy", "mcraw_pool_last_error",
+    "mcraw_ctx_profile_every", "mcraw_legacy_launch_order", "mcraw_shard_of", "mcraw_shard_count", "mcraw_pool_create", "mcraw_pool_destroy", "mcraw_pool_last_error",
     "mcraw_pool_size", "mcraw_pool_device", "mcraw_pool_numa_cpus", "mcraw_pool_ctx", "mcraw_pool_set_post",
     "mcraw_pool_host_alloc", "mcraw_pool_decode_batch", "mcraw_pool_decode_batch_async", "mcraw_pool_ticket_wait",
 ]

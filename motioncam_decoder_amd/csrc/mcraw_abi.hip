@@ -356,23 +356,12 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     uint32_t smax = 0; // segments of the longest legacy stream
     std::vector<uint32_t> wg_tab(3 * n6 + 1, 0);
     {
-        std::vector<uint32_t> nseg(n6), order(n6);
+        std::vector<uint32_t> nseg(n6);
         for (int k = 0; k < n6; k++) {
             nseg[k] = (B.p6[k].nchunks + 4 * ROWS_CH - 1) / (4 * ROWS_CH);
-            order[k] = static_cast<uint32_t>(k);
             smax = std::max(smax, nseg[k]);
         }
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return nseg[a] > nseg[b]; });
-        uint32_t lo = 0, base = 0;
-        for (int t = 0; t < n6; t++) {
-            const uint32_t hi = nseg[order[n6 - 1 - t]]; // the smallest frame still in play leaves after this round
-            wg_tab[t] = base;
-            wg_tab[n6 + 1 + t] = lo;
-            wg_tab[2 * n6 + 1 + t] = order[t];
-            base += static_cast<uint32_t>(n6 - t) * (hi - lo);
-            lo = hi;
-        }
-        wg_tab[n6] = base; // = segments of all frames
+        mcraw_legacy_launch_order(nseg.data(), n6, wg_tab.data());
     }
     L.total = off;
     if (n6) {
@@ -1150,6 +1139,26 @@ int mcraw_ctx_set_post(mcraw_ctx *c, const mcraw_post *post)
         p.mode |= POST_PACK14;
     c->post = p;
     return 0;
+}
+
+void mcraw_legacy_launch_order(const uint32_t *nseg, int n, uint32_t *tab)
+{
+    if (!nseg || !tab || n <= 0)
+        return;
+    std::vector<uint32_t> order(n);
+    for (int k = 0; k < n; k++)
+        order[k] = static_cast<uint32_t>(k);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return nseg[a] > nseg[b]; });
+    uint32_t lo = 0, base = 0;
+    for (int t = 0; t < n; t++) {
+        const uint32_t hi = nseg[order[n - 1 - t]]; // the smallest frame still in play leaves after this round
+        tab[t] = base;
+        tab[n + 1 + t] = lo;
+        tab[2 * n + 1 + t] = order[t];
+        base += static_cast<uint32_t>(n - t) * (hi - lo);
+        lo = hi;
+    }
+    tab[n] = base; // = segments of all frames
 }
 
 int mcraw_ctx_profile(mcraw_ctx *c, int enable)
