@@ -208,39 +208,46 @@ __device__ __forceinline__ uint2 side_strides(const uint4 v, uint32_t odd)
     return make_uint2(st[0], st[1]);
 }
 
-#ifdef MCRAW_DIAG // phase stamps of one workgroup (timing experiments only; not in the product library)
+#ifdef MCRAW_DIAG // event timeline of one workgroup (timing experiments only; not in the product library)
 #ifndef SIDE_PROF_BLOCK
 #define SIDE_PROF_BLOCK 1u
 #endif
-__device__ unsigned long long g_side_prof[32];
+// [0][..]: wave 0 (the walker), [1][..]: wave 1 (a decoder): event id << 48 | shader cycles since the kernel's first stamp;
+// entry 0 of each row: number of events
+__device__ unsigned long long g_side_prof[2][256];
 #define SIDE_STAMP(slot)                                                                                               \
     do {                                                                                                               \
-        if (blockIdx.x == SIDE_PROF_BLOCK && (tid == 0u || tid == 64u)) {                                              \
+        if (blockIdx.x == SIDE_PROF_BLOCK && (tid == 0u || tid == 64u) && tl_n_ < 255u) {                              \
             const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                              \
-            g_side_prof[(slot) + (tid ? 16 : 0)] += now_ - stamp_;                                                      \
-            stamp_ = now_;                                                                                             \
+            g_side_prof[tid ? 1 : 0][++tl_n_] = (static_cast<unsigned long long>(slot) << 48) | (now_ - stamp_);       \
+            g_side_prof[tid ? 1 : 0][0] = tl_n_;                                                                        \
         }                                                                                                              \
     } while (0)
 #else
 #define SIDE_STAMP(slot)
 #endif
 
-__global__ __launch_bounds__(SIDE_T) void k7_side(const Work7 W)
+__global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) void k7_side(const Work7 W)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_b[SIDE_BYTES];       // bytes of the piece the decoders work on
-    __shared__ __attribute__((aligned(16))) uint8_t s_T[SIDE_HALF + 16];   // strides of the piece the walker is in; [SIDE_HALF] = SIDE_OUT
+    __shared__ __attribute__((aligned(16))) uint8_t s_T[SIDE_HALF + 80];   // strides of the piece the walker is in; [SIDE_HALF ..] = SIDE_OUT (the reach of a record)
     __shared__ __attribute__((aligned(16))) uint16_t s_L[2][SIDE_LCAP];
     __shared__ __attribute__((aligned(16))) uint16_t s_len[2][2 * SIDE_LCAP]; // item lengths of a unit (bits stream)
     __shared__ uint4 s_tab[72];
     __shared__ __attribute__((aligned(16))) uint32_t s_st[2][4]; // what the walker reports with list 0 / 1
+    __shared__ uint2 s_seg[64]; // segment walkers: {first record of the segment | records in it << 16, records of the piece in front of it}
     __shared__ int32_t s_err;
 
     const uint32_t fs = blockIdx.x, f = fs >> 1, s = fs & 1u;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef MCRAW_DIAG
+    const unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+    uint32_t tl_n_ = 0, nsteps_ = 0;
+#endif
     if (tid < 72u)
         s_tab[tid] = reinterpret_cast<const uint4 *>(c_tab7)[tid];
-    if (tid < 16u)
+    if (tid < 80u)
         s_T[SIDE_HALF + tid] = static_cast<uint8_t>(SIDE_OUT);
     if (tid == 0u)
         s_err = 0;
@@ -250,6 +257,7 @@ __global__ __launch_bounds__(SIDE_T) void k7_side(const Work7 W)
     int32_t *status = W.status + fs; // this stream's word
     const uint32_t len = P->len;
     const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
+    SIDE_STAMP(10); // plan here
 
     // ---- frame header (RawData.cpp:500-524) and its checks (:547-554)
     const uint4 hv = ld_b128(rs, 0); // zeros when len < 16
@@ -302,6 +310,7 @@ __global__ __launch_bounds__(SIDE_T) void k7_side(const Work7 W)
                 err = MCRAW_E_SIDESTREAM;
         }
     }
+    SIDE_STAMP(11); // header + count here
     if (s == 0u && tid == 0u) {
         Frame7 F;
         F.in = P->in;
@@ -335,9 +344,6 @@ __global__ __launch_bounds__(SIDE_T) void k7_side(const Work7 W)
     int32_t lane_err = 0;                  // per lane (a bits entry above 16)
     bool dead = false;                     // uniform: the chain ended before R records
 
-#ifdef MCRAW_DIAG
-    unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
-#endif
     // registers -> bytes of a piece (what the decoders read)
     auto store_bytes = [&](const Lines &r) {
 #pragma unroll
@@ -371,14 +377,112 @@ __global__ __launch_bounds__(SIDE_T) void k7_side(const Work7 W)
     // W (wave 0): list up to `room` (>= 1) records of the piece in s_T from candidate pu on; result in s_st:
     // where the chain stands, records listed, why it stopped (1 list full / stream complete, 2 behind the
     // piece, 3 chain dead) and the stride of the record it stands on when that is known (else 0).
-    // SU == 0 on entry makes the first pass a probe: every lane looks at pu itself, nothing matches stride 0,
-    // and "the record behind the run" is the record at pu.
-    auto walk = [&](uint32_t lst, uint32_t pu, uint32_t SU, uint32_t room) {
+    //
+    // Two ways to follow the chain.  RUN SPECULATION (above): one pass per run of equally long records -- what coded
+    // frames consist of.  A stream whose records keep changing size (the refs of a noise frame: 66- and 82-byte records
+    // taking turns, 2.2 records per pass) is followed by SEGMENT WALKERS instead (`segw`, from then on for the rest of
+    // the stream): lane j owns segment j of the piece (SEG_C candidates from where the chain stands) and walks one record
+    // per step like the reference does, all lanes side by side.  Lanes of the first WARM_C candidates start on the
+    // chain itself; the others start WARM_C candidates in front of their segment at a candidate that is most likely no
+    // record at all: a wrong chain reads payload bytes as headers and falls onto the true one with probability
+    // ~ 1/37 per step, so that after WARM_C candidates it has done so in 97 % of the cases.  Nothing is taken on trust:
+    // lane j's first record in its segment must be where lane j - 1 left its own (the lanes on the chain itself are the
+    // induction's start); the first lane for which that fails walks its segment again from there, and so on (each lane
+    // at most once).  A piece then costs ~ (WARM_C + SEG_C) / 30 dependent LDS reads instead of one pass per run.
+    #ifndef MCRAW_WARM_SEGS
+#define MCRAW_WARM_SEGS 4
+#endif
+    constexpr uint32_t SEG_C = SIDE_HALF / 64u, WARM_C = MCRAW_WARM_SEGS * SEG_C, SEG_NONE = 0x7FFFu, SEG_DEADX = 0xFFFFu;
+#ifdef MCRAW_FORCE_SEGW // test builds: every stream on the segment walkers from its first record on (tools/test_segw.sh)
+    bool segw = true, seg_valid = false;
+#else
+    bool segw = false, seg_valid = false;          // (uniform, wave 0)
+#endif
+    uint32_t seg_total = 0, seg_done = 0, seg_exit = 0;
+    // one lane = one chain: from `pos` to the end of the lane's segment [segs, sege); -> first record in the segment,
+    // records started in it, and where the chain leaves it (SEG_DEADX: it ended, a record would cross `len`)
+    auto seg_chain = [&](bool on, uint32_t pos, uint32_t segs, uint32_t sege, uint32_t &ent, uint32_t &cnt, uint32_t &ex) {
+        // branch-free: a lane that has left its segment, or stands in front of a record that would cross `len`, stays
+        // where it is (stride 0); the dependent chain of a step is one LDS read, a compare, a select and an addition
+        pos = on ? pos : SIDE_HALF;
+        sege = on ? sege : 0u;
+        bool stop;
+        do {
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t code = s_T[pos]; // (pos < sege + 65 <= SIDE_HALF + 65)
+                stop = pos >= sege || code >= SIDE_DEAD;
+                const bool inseg = !stop && pos >= segs;
+                ent = min(ent, inseg ? pos : SEG_NONE);
+                cnt += inseg ? 1u : 0u;
+                pos += stop ? 0u : code;
+            }
+#ifdef MCRAW_DIAG
+            nsteps_ += 2;
+#endif
+        } while (__any(!stop));
+        if (on)
+            ex = pos >= sege ? pos : SEG_DEADX;
+    };
+    auto seg_walk = [&](uint32_t org) {
+        const uint32_t segs = org + lane * SEG_C;
+        const bool act = segs < SIDE_HALF;
+        const uint32_t sege = min(segs + SEG_C, SIDE_HALF);
+        const bool on_chain = lane < WARM_C / SEG_C;
+        uint32_t ent = SEG_NONE, cnt = 0, ex = SEG_DEADX;
+        seg_chain(act, on_chain ? org : segs - WARM_C, segs, sege, ent, cnt, ex);
+        // Lane j's chain is the true one in its segment iff it enters it where lane j - 1's leaves its own.  Every lane
+        // for which that fails walks its segment again from where its predecessor says, all of them side by side; the
+        // lowest such lane is right afterwards for good (the lanes below it are), so the rounds end -- after one or
+        // two: wrong lanes are few and seldom neighbours, and a corrected lane mostly leaves its segment where it did before.
+        uint32_t src = SEG_NONE; // where a lane that walked again started from (its chain may end right there)
+        for (uint32_t round = 0; round < 64u; round++) { // (the lowest wrong lane is right after every round)
+            const uint32_t want = static_cast<uint32_t>(__shfl_up(static_cast<int>(ex), 1, 64));
+            const uint32_t claim = src != SEG_NONE ? src : ent != SEG_NONE ? ent : ex;
+            const bool bad = act && !on_chain && claim != want;
+            if (__ballot(bad) == 0ull)
+                break;
+            if (bad) {
+                ent = SEG_NONE;
+                cnt = 0;
+                ex = SEG_DEADX;
+                src = want;
+            }
+            seg_chain(bad && want != SEG_DEADX, want, segs, sege, ent, cnt, ex);
+        }
+        uint32_t total;
+        const uint32_t off = wave_excl_scan(act ? cnt : 0u, lane, &total);
+        s_seg[lane] = make_uint2((ent & 0xFFFFu) | (cnt << 16), off);
+        const uint32_t nact = (SIDE_HALF - org + SEG_C - 1u) / SEG_C; // (org < SIDE_HALF)
+        seg_exit = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ex), static_cast<int>(min(nact, 64u) - 1u)));
+        seg_total = total;
+        seg_done = 0;
+        seg_valid = true;
+    };
+    // records [seg_done, seg_done + take) of the piece, in chain order, into the list: every lane walks its segment
+    // once more, from its (now known) first record
+    auto seg_list = [&](uint16_t *L, uint32_t take) {
+        const uint2 sv = s_seg[lane];
+        const uint32_t cnt = sv.x >> 16, off = sv.y, lo = seg_done, hi = seg_done + take;
+        uint32_t pos = sv.x & 0xFFFFu, kk = off;
+        const uint32_t kend = min(off + cnt, hi);
+        bool part = cnt != 0u && off < hi && off + cnt > lo;
+        pos = part ? pos : SIDE_HALF;
+        while (__any(part)) {
+            const uint32_t code = s_T[pos];
+            if (part && kk >= lo)
+                L[kk - lo] = static_cast<uint16_t>(pos);
+            kk++;
+            part = part && kk < kend;
+            pos = part ? pos + code : SIDE_HALF;
+        }
+    };
+    auto walk = [&](uint32_t lst, uint32_t pu, uint32_t SU, uint32_t room, bool fresh) {
         uint16_t *L = s_L[lst];
         uint32_t cnt = 0, why = 2u;
-        if (pu < SIDE_HALF) {
+        if (!segw && pu < SIDE_HALF) {
             // one pass per run, one exit test per pass
-            uint32_t nb, take, nxt;
+            uint32_t nb, take, nxt, passes = 0;
             bool go;
             do {
                 const uint32_t u = pu + lane * SU;
@@ -394,12 +498,16 @@ __global__ __launch_bounds__(SIDE_T) void k7_side(const Work7 W)
                 pu += take * SU;
                 go = take == nb && cnt < room && (nb == 64u || nxt < SIDE_DEAD);
                 SU = (go && nb != 64u) ? nxt : SU;
+                passes++;
+                // fewer than three records per pass: the records keep changing size, runs do not pay here; the segment
+                // walkers take over where the chain stands (a record that is not listed yet), for the rest of the stream
+                segw = go && passes >= 12u && passes * 3u > cnt;
 #ifdef MCRAW_DIAG
-                if (blockIdx.x == SIDE_PROF_BLOCK && lane == 0u)
-                    g_side_prof[6]++;
+                nsteps_++;
 #endif
-            } while (go);
-            if (take < nb) {
+            } while (go && !segw);
+            if (segw) {
+            } else if (take < nb) {
                 why = 1u; // list full / stream complete inside the run: pu is a record of stride SU
             } else if (cnt >= room) {
                 why = 1u; // ... at the end of the run
@@ -408,26 +516,47 @@ __global__ __launch_bounds__(SIDE_T) void k7_side(const Work7 W)
                 why = nxt == SIDE_OUT ? 2u : 3u;
                 SU = 0u;
             }
-        } else {
+            if (segw)
+                seg_valid = false;
+        } else if (!segw) {
+            SU = 0u;
+        }
+        if (segw && pu < SIDE_HALF) {
+            if (fresh || !seg_valid)
+                seg_walk(pu);
+            const uint32_t take = min(room - cnt, seg_total - seg_done);
+            if (take)
+                seg_list(L + cnt, take);
+            seg_done += take;
+            cnt += take;
+            SU = 0u;
+            if (seg_done == seg_total) { // the piece is through
+                why = seg_exit == SEG_DEADX ? 3u : 2u;
+                pu = seg_exit == SEG_DEADX ? 0u : seg_exit;
+                seg_valid = false;
+            } else {
+                why = 1u;
+                pu = 0u; // (where the chain stands is in s_seg)
+            }
+        } else if (segw) {
             SU = 0u;
         }
         if (lane == 0u)
             *reinterpret_cast<uint4 *>(s_st[lst]) = make_uint4(pu, cnt, why, SU);
-#ifdef MCRAW_DIAG
-        if (blockIdx.x == SIDE_PROF_BLOCK && lane == 0u)
-            g_side_prof[7]++;
-#endif
     };
 
     const uint32_t k = lane & 7u, sub = lane >> 3;
     // prologue: piece 0 in LDS, pieces 1 and 2 on their way, first unit walked
     store_bytes(nx);
+    SIDE_STAMP(12); // piece 0 arrived
     build_strides(nx, 0u);
     load_piece(nx, 1u);
     load_piece(ny, 2u);
     lds_barrier();
+    SIDE_STAMP(13);
     if (wave == 0u)
-        walk(0u, static_cast<uint32_t>((so + 4u) & 15u) >> 1, 0u, min(R, SIDE_LCAP / 4u)); // a short first unit: the decoders start early
+        walk(0u, static_cast<uint32_t>((so + 4u) & 15u) >> 1, 0u, min(R, SIDE_LCAP / 4u), true); // a short first unit: the decoders start early
+    SIDE_STAMP(14);
     // S (wave 0, bits stream): item lengths of one unit -> payload offsets: exclusive scan, eight items per lane and pass
     static_assert((2u * SIDE_LCAP) % 512u == 0u, "whole passes of 512 items");
     auto scan_unit = [&](uint32_t par, uint32_t n0, uint32_t cnt) {
@@ -488,7 +617,7 @@ __global__ __launch_bounds__(SIDE_T) void k7_side(const Work7 W)
         SIDE_STAMP(1);
         if (wave == 0u) {
             if (!last)
-                walk(cur ^ 1u, npc > upc ? pu - SIDE_HALF : pu, SU, min(R - (n + total), SIDE_LCAP));
+                walk(cur ^ 1u, npc > upc ? pu - SIDE_HALF : pu, SU, min(R - (n + total), SIDE_LCAP), npc > upc);
             SIDE_STAMP(2);
             if (s == 0u && prev_total) // the unit the decoders finished before the last barrier
                 scan_unit(cur ^ 1u, prev_n, prev_total);
@@ -594,6 +723,11 @@ __global__ __launch_bounds__(SIDE_T) void k7_side(const Work7 W)
     lds_barrier();
     if (tid == 0u)
         *status = s_err;
+    SIDE_STAMP(15);
+#ifdef MCRAW_DIAG
+    if (blockIdx.x == SIDE_PROF_BLOCK && tid == 0u)
+        g_side_prof[0][255] = nsteps_;
+#endif
 }
 
 // ------------------------------------------------------------------ k7_tiles
