@@ -121,6 +121,9 @@ class Workload:
             self.t_outs.append(t_out)
             self.desc_sets.append(M.Context.make_frames(descs))
         self.t_out, self.descs = self.t_outs[0], self.desc_sets[0]
+        if os.environ.get("MCRAW_BENCH_DEBUG"):
+            print("buffers: in %#x (%d B) out %#x (%d B)" % (self.t_in.data_ptr(), self.t_in.numel(), self.t_out.data_ptr(), self.t_out.numel()),
+                  file=sys.stderr, flush=True)
         orc = L.oracle()
         used = [orc.mcraw_oracle_len_used7(L._ptr(p[1]), p[1].size) for p in self.pairs]
         assert all(u > 0 for u in used)
@@ -184,6 +187,31 @@ def run_timed(torch, comm, ctx, M, wl, args):
     tiles = ctx.kernel_ms("k7_tiles", reset=True) # (ms summed over warm-up + timed rounds, launches)
     ctx.profile(True)
     return times, kms, tiles, ok
+
+
+def box_calibration(torch, dev, nbytes=1 << 30, reps=8):
+    """This box's own yardstick, measured in this process: what a plain write-only stream (torch fill, 1 GiB, beyond
+    the Infinity Cache) and a plain copy reach right now.  Boxes of the pool -- and runs on one box -- differ by several
+    per cent on the HBM-bound kernel; roofline.frac can be normalised with these."""
+    buf = torch.empty(nbytes // 4, dtype=torch.int32, device=dev)
+    src = torch.empty(nbytes // 4, dtype=torch.int32, device=dev)
+
+    def rate(fn, moved):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return reps * moved / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+    res = {"fill_write_only_GBs": round(rate(lambda: buf.fill_(7), nbytes), 1),
+           "copy_read_plus_write_GBs": round(rate(lambda: buf.copy_(src), 2 * nbytes), 1)}
+    del buf, src
+    return res
 
 
 def link_probe(torch, dev, nbytes=256 << 20, reps=3):
@@ -524,6 +552,7 @@ def main():
 
     dists = [args.dist] + ([] if (args.no_also or world > 1) else [("u" if args.dist == "nat" else "nat")])
     results = {}
+    calib = box_calibration(torch, dev) if rank == 0 else None
     for d in dists:
         # weak scaling: the job is world * frames frames, frame i decoded by rank i % world
         wl = Workload(torch, M, L, dev, args, d, shard.shard_frames(world * args.frames, rank, world))
@@ -606,6 +635,9 @@ def main():
                          "timed_with": "HIP events on the launch stream around every 4th k7_tiles launch of the timed rounds"},
             "kernels_ms_per_step": {k: round(v, 4) for k, v in s["kernels_ms_per_step"].items()},
         }
+        calib_after = box_calibration(torch, dev)
+        out["box_calibration"] = {"before": calib, "after": calib_after,
+                                  "note": "torch fill / copy of 1 GiB in this process, before and after the timed rounds: this box's own HBM yardstick"}
         for d in dists[1:]:
             s2 = summarize(results[d])
             out["also_" + d] = {"mpix_s": round(s2["mpix_s"], 1), "ms_per_step": round(s2["st"]["median"], 4),

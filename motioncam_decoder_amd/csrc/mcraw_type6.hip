@@ -478,8 +478,15 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         if (uj >= cnt)
             qp = DEAD;
         uint32_t qn = 0;
+        // ... and notes where: a lane finds one record per step until its walk is over, so its n-th record is the one of
+        // step n -- its half position goes to byte n of eight registers (steps are unrolled: static indices).  The record
+        // lists below are made from these notes, without a second walk along the chain.
+        constexpr uint32_t NOTES6 = 32;
+        uint32_t nb[NOTES6 / 4u] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        bool notes_ok = s_runs == 0u;
         {
-            uint32_t A = (uj + 1u) * TABQ + ur * QTAB + (qp == DEAD ? HALF6 / 4u : qp); // (DEAD: starts on the zeros)
+            const uint32_t qb = (uj + 1u) * TABQ + ur * QTAB;
+            uint32_t A = qb + (qp == DEAD ? HALF6 / 4u : qp); // (DEAD: starts on the zeros)
             uint32_t t;
             if (s_runs) { // (some walk of this segment may meet a jump over sixteen records)
                 do {
@@ -491,14 +498,32 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                     }
                 } while (__any(t != 0u));
             } else {
-                do {
+                bool more = true;
 #pragma unroll
-                    for (int u = 0; u < 2; u++) {
+                for (uint32_t st = 0; st < NOTES6; st += 2u) {
+#pragma unroll
+                    for (uint32_t u = 0; u < 2u; u++) {
                         t = s_tab[A];
+                        nb[(st + u) >> 2] |= (A - qb) << (8u * ((st + u) & 3u)); // (< 256; bytes behind a lane's last record are never used)
                         qn += t ? 1u : 0u;
                         A += t;
                     }
-                } while (__any(t != 0u));
+                    if (!__any(t != 0u)) {
+                        more = false;
+                        break;
+                    }
+                }
+                if (more) { // records of less than 8 bytes on average: counted on, listed by a walk of their own below
+                    notes_ok = false;
+                    do {
+#pragma unroll
+                        for (int u = 0; u < 2; u++) {
+                            t = s_tab[A];
+                            qn += t ? 1u : 0u;
+                            A += t;
+                        }
+                    } while (__any(t != 0u));
+                }
             }
         }
         K6_STAMP(11, 256);
@@ -576,7 +601,33 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         const bool coop = __ballot(!rg.lean) == 0ull;
         if (lane == 0)
             s_coop = coop ? 1u : 0u;
-        if (K6_ABL != 3 && coop) {
+        // The common case (no jumps over runs of 2-byte records in this segment, at most NOTES6 records per quarter, every
+        // record listed): the lists are the notes of the count walk put in their places -- stores that do not depend on one
+        // another, instead of a second walk along the chain (which took 5 700 of a workgroup's 34 000 cycles).  Every lane
+        // stores whole groups of eight notes, from the last one down: what a lane stores beyond its own records lands on
+        // entries of the lanes behind it, whose own stores come later and put it right (hence the room of NOTES6 entries
+        // behind the last record that a list must have).
+        const bool noted = coop && notes_ok && __ballot(rg.pairmode || rg.N + NOTES6 > ROWS_CAP / 2u) == 0ull;
+        if (K6_ABL != 3 && noted) {
+            const int32_t slot0 = static_cast<int32_t>(qi - rg.R0); // -1: an odd first record belongs to the previous wave's
+            uint16_t *lp = s_pos[uw] + slot0;                        // last pair, never listed
+            const uint32_t boff = j * CHUNK6 + r * (CHUNK6 / 4u);
+#pragma unroll
+            for (int32_t g = NOTES6 / 8 - 1; g >= 0; g--) {
+                if (g && __ballot(qn > 8u * static_cast<uint32_t>(g)) == 0ull)
+                    continue;
+#pragma unroll
+                for (int32_t i = 8 * g + 7; i >= 8 * g; i--) {
+                    const uint32_t v = boff + 2u * ((nb[i >> 2] >> (8 * (i & 3))) & 255u);
+                    if (i > 0 || slot0 >= 0)
+                        lp[i] = static_cast<uint16_t>(v);
+                }
+            }
+            // my range ends on an even record: its partner is the next wave's first record, where the chain enters the chunk
+            // behind my last one
+            if (j == ROWS_CH - 1u && r == 3u && ((slot0 + static_cast<int32_t>(qn)) & 1))
+                lp[qn] = static_cast<uint16_t>(ROWS_CH * CHUNK6 + 2u * (ent_of(uw * ROWS_CH + ROWS_CH) & 255u));
+        } else if (K6_ABL != 3 && coop) {
             const uint32_t ej = s_ent4[lane], first = rg.R0;
             const uint8_t *base = s_own + uw * (ROWS_CH * CHUNK6);
             const uint8_t *p = base + j * CHUNK6 + r * (CHUNK6 / 4u) + 2u * (ej & 255u);
