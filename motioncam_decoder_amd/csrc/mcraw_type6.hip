@@ -603,29 +603,51 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
             s_coop = coop ? 1u : 0u;
         // The common case (no jumps over runs of 2-byte records in this segment, at most NOTES6 records per quarter, every
         // record listed): the lists are the notes of the count walk put in their places -- stores that do not depend on one
-        // another, instead of a second walk along the chain (which took 5 700 of a workgroup's 34 000 cycles).  Every lane
-        // stores whole groups of eight notes, from the last one down: what a lane stores beyond its own records lands on
-        // entries of the lanes behind it, whose own stores come later and put it right (hence the room of NOTES6 entries
-        // behind the last record that a list must have).
+        // another, instead of a second walk along the chain (which took 5 700 of a workgroup's 34 000 cycles).  A lane stores
+        // whole groups of eight entries.  The group its records end in is filled up with the first records of the NEXT quarter
+        // (every quarter starts at least seven: a record has at most 34 bytes), taken from the lane behind it: what a lane
+        // stores beyond its own records is then exactly what that lane stores there itself, and it does not matter which
+        // of the two stores comes last.
         const bool noted = coop && notes_ok && __ballot(rg.pairmode || rg.N + NOTES6 > ROWS_CAP / 2u) == 0ull;
         if (K6_ABL != 3 && noted) {
             const int32_t slot0 = static_cast<int32_t>(qi - rg.R0); // -1: an odd first record belongs to the previous wave's
             uint16_t *lp = s_pos[uw] + slot0;                        // last pair, never listed
             const uint32_t boff = j * CHUNK6 + r * (CHUNK6 / 4u);
+            {
+                const uint32_t kb = qn & 7u, gp = qn >> 3;
+                // the next quarter's first eight notes, 128 half positions further on (lane 63: the chunk behind the segment
+                // is entered at phase `aph`)
+                uint32_t x0 = __shfl_down(nb[0], 1, 64), x1 = __shfl_down(nb[1], 1, 64);
+                x0 = (lane == 63u ? aph & 31u : x0) | 0x80808080u;
+                x1 |= 0x80808080u;
+                const uint64_t nx = (static_cast<uint64_t>(x1) << 32) | x0;
+                const uint32_t o0 = gp == 0u ? nb[0] : gp == 1u ? nb[2] : gp == 2u ? nb[4] : nb[6];
+                const uint32_t o1 = gp == 0u ? nb[1] : gp == 1u ? nb[3] : gp == 2u ? nb[5] : nb[7];
+                const uint64_t own = (static_cast<uint64_t>(o1) << 32) | o0;
+                const uint64_t keep = (1ull << (8u * kb)) - 1ull; // (kb <= 7)
+                const uint64_t m = (own & keep) | (nx << (8u * kb));
 #pragma unroll
-            for (int32_t g = NOTES6 / 8 - 1; g >= 0; g--) {
-                if (g && __ballot(qn > 8u * static_cast<uint32_t>(g)) == 0ull)
-                    continue;
-#pragma unroll
-                for (int32_t i = 8 * g + 7; i >= 8 * g; i--) {
-                    const uint32_t v = boff + 2u * ((nb[i >> 2] >> (8 * (i & 3))) & 255u);
-                    if (i > 0 || slot0 >= 0)
-                        lp[i] = static_cast<uint16_t>(v);
+                for (uint32_t g = 0; g < NOTES6 / 8u; g++) {
+                    nb[2u * g] = gp == g ? static_cast<uint32_t>(m) : nb[2u * g];
+                    nb[2u * g + 1u] = gp == g ? static_cast<uint32_t>(m >> 32) : nb[2u * g + 1u];
                 }
             }
-            // my range ends on an even record: its partner is the next wave's first record, where the chain enters the chunk
-            // behind my last one
-            if (j == ROWS_CH - 1u && r == 3u && ((slot0 + static_cast<int32_t>(qn)) & 1))
+#pragma unroll
+            for (uint32_t g = 0; g < NOTES6 / 8u; g++) {
+                if (g && __ballot(qn > 8u * g) == 0ull)
+                    break;
+                if (qn > 8u * g) { // (at most seven entries behind a lane's last record: the next quarter's first seven)
+#pragma unroll
+                    for (uint32_t i = 8u * g; i < 8u * g + 8u; i++) {
+                        const uint32_t v = boff + 2u * ((nb[i >> 2] >> (8u * (i & 3u))) & 255u);
+                        if (i > 0u || slot0 >= 0)
+                            lp[i] = static_cast<uint16_t>(v);
+                    }
+                }
+            }
+            // behind a wave's last record: the next wave's first one (the partner of the wave's last record when its range
+            // ends on an even one; a lane whose records end on a group boundary has stored nothing behind them)
+            if (j == ROWS_CH - 1u && r == 3u)
                 lp[qn] = static_cast<uint16_t>(ROWS_CH * CHUNK6 + 2u * (ent_of(uw * ROWS_CH + ROWS_CH) & 255u));
         } else if (K6_ABL != 3 && coop) {
             const uint32_t ej = s_ent4[lane], first = rg.R0;
