@@ -73,6 +73,7 @@ struct Slot {
     std::vector<int32_t> host_status;
     int n7 = 0; // type-7 frames of the batch in this slot (their coded heights follow the statuses)
     hipEvent_t done = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr; // a batch that holds both encodings: its legacy kernel runs on the context's second stream
     ::mcraw_ticket *owner = nullptr; // host-memory batch whose statuses still sit in this slot's arena
     int owner_part = -1;
     hipEvent_t uploaded = nullptr; // host-memory pipeline: inputs of the sub-batch are in HBM
@@ -123,6 +124,7 @@ struct mcraw_ctx {
     int next_dslot = 0;
     Slot rslot;          // frames planned a second time (always drained before the call returns)
     hipStream_t aux = nullptr; // deferred second plans of batches whose caller stream is not known any more
+    hipStream_t legacy = nullptr; // the legacy kernel of a batch that holds both encodings (beside the type-7 kernels)
     uint32_t profile = 0; // bit id: bracket launches of kernel id with events
     uint32_t profile_every = 1, profile_tick[MCRAW_K_COUNT] = {0}; // ... every n-th launch of it only
     Post post{0, 0, 0};   // fused post-decode stage of the batches to come (mcraw_ctx_set_post)
@@ -407,6 +409,17 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         HIP_TRY(hipMemcpyAsync(dev, img, L.upload_bytes, hipMemcpyHostToDevice, st));
 
     // ---- launches -----------------------------------------------------------
+    // A batch that holds both encodings (BASELINE config 4): the two codecs share nothing, and k7_side is a handful of
+    // latency-bound workgroups -- the legacy kernel runs beside the type-7 kernels on the context's second stream, forked
+    // behind the table upload and joined in front of whatever the caller queues next.
+    static const bool no_fork = std::getenv("MCRAW_NO_FORK") != nullptr; // timing experiment: one stream
+    const bool both = n7 > 0 && n6 > 0 && s.fork && s.join && c->legacy && !no_fork;
+    hipStream_t st6 = st;
+    if (both) {
+        st6 = c->legacy;
+        HIP_TRY(hipEventRecord(s.fork, st));
+        HIP_TRY(hipStreamWaitEvent(st6, s.fork, 0));
+    }
     if (n7) {
         Work7 W{};
         W.plans = reinterpret_cast<const Plan7 *>((upload_plans ? dev : img) + L.plans7); // pinned host memory, device-visible at the same address
@@ -435,9 +448,13 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         lk.res = static_cast<uint64_t *>(s.look.p);
         lk.ex = lk.res + static_cast<size_t>(smax) * n6;
         lk.hm = lk.ex + static_cast<size_t>(smax) * n6;
-        KTimer t(c, MCRAW_K6_DECODE, st);
+        KTimer t(c, MCRAW_K6_DECODE, st6);
         launch_k6_decode(dp, reinterpret_cast<const uint32_t *>(dev + L.wg_tab), n6 > 1 ? wg_tab[1] : wg_tab[n6], wg_tab[n6], lk,
-                         reinterpret_cast<uint32_t *>(dev + L.tickets), s.look_epoch, n6, smax, c->post, st);
+                         reinterpret_cast<uint32_t *>(dev + L.tickets), s.look_epoch, n6, smax, c->post, st6);
+    }
+    if (both) {
+        HIP_TRY(hipEventRecord(s.join, st6));
+        HIP_TRY(hipStreamWaitEvent(st, s.join, 0));
     }
     HIP_TRY(hipGetLastError());
     *status_off = L.status;
@@ -952,14 +969,24 @@ int mcraw_ctx_create(int device, mcraw_ctx **out)
     HIP_TRY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->h2d, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->d2h, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->legacy, hipStreamNonBlocking));
+    for (Slot *sp : {&c->rslot}) {
+        HIP_TRY(hipEventCreateWithFlags(&sp->fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sp->join, hipEventDisableTiming));
+    }
     for (Slot &s : c->slots) {
+        HIP_TRY(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s.decoded, hipEventDisableTiming));
         HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     }
-    for (Slot &s : c->dslots)
+    for (Slot &s : c->dslots) {
         HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
+    }
     guard.c = nullptr;
     *out = c;
     return 0;
@@ -979,6 +1006,8 @@ void mcraw_ctx_destroy(mcraw_ctx *c)
         if (s.dev_in.p) (void)hipFree(s.dev_in.p);
         if (s.dev_out.p) (void)hipFree(s.dev_out.p);
         if (s.done) (void)hipEventDestroy(s.done);
+        if (s.fork) (void)hipEventDestroy(s.fork);
+        if (s.join) (void)hipEventDestroy(s.join);
         if (s.uploaded) (void)hipEventDestroy(s.uploaded);
         if (s.decoded) (void)hipEventDestroy(s.decoded);
         if (s.stream) (void)hipStreamDestroy(s.stream);
@@ -999,6 +1028,8 @@ void mcraw_ctx_destroy(mcraw_ctx *c)
         (void)hipStreamDestroy(c->stream);
     if (c->aux)
         (void)hipStreamDestroy(c->aux);
+    if (c->legacy)
+        (void)hipStreamDestroy(c->legacy);
     if (c->h2d)
         (void)hipStreamDestroy(c->h2d);
     if (c->d2h)

@@ -389,7 +389,10 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     // lane j's first record in its segment must be where lane j - 1 left its own (the lanes on the chain itself are the
     // induction's start); the first lane for which that fails walks its segment again from there, and so on (each lane
     // at most once).  A piece then costs ~ (WARM_C + SEG_C) / 30 dependent LDS reads instead of one pass per run.
-    #ifndef MCRAW_WARM_SEGS
+    #ifndef MCRAW_SEGW_RATIO
+#define MCRAW_SEGW_RATIO 3u
+#endif
+#ifndef MCRAW_WARM_SEGS
 #define MCRAW_WARM_SEGS 4
 #endif
     constexpr uint32_t SEG_C = SIDE_HALF / 64u, WARM_C = MCRAW_WARM_SEGS * SEG_C, SEG_NONE = 0x7FFFu, SEG_DEADX = 0xFFFFu;
@@ -499,9 +502,12 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                 go = take == nb && cnt < room && (nb == 64u || nxt < SIDE_DEAD);
                 SU = (go && nb != 64u) ? nxt : SU;
                 passes++;
-                // fewer than three records per pass: the records keep changing size, runs do not pay here; the segment
-                // walkers take over where the chain stands (a record that is not listed yet), for the rest of the stream
-                segw = go && passes >= 12u && passes * 3u > cnt;
+                // Fewer than three records per pass: the records keep changing size, runs do not pay here (a pass costs ~350
+                // cycles whatever it lists); the segment walkers take over where the chain stands (a record that is not listed
+                // yet), for the rest of the stream.  The bar is low on purpose: a chain that starts on payload bytes advances by
+                // what those bytes say, and the small residuals of coded frames make that a crawl (two bytes a step) -- a
+                // stream that lists 15 records per pass is followed three times FASTER by runs than by the walkers, measured.
+                segw = go && passes >= 8u && passes * MCRAW_SEGW_RATIO > cnt;
 #ifdef MCRAW_DIAG
                 nsteps_++;
 #endif

@@ -17,7 +17,8 @@ import motioncam_decoder_amd as M
 w, h, n = int(os.environ.get("W", "3840")), int(os.environ.get("H", "2160")), int(os.environ.get("N", "240"))
 dist = 1 if os.environ.get("DIST", "nat") == "nat" else 0
 dev = torch.device("cuda:0")
-imgs = [L.synth_image(w, h, 12, dist, 12.0, 3000 + i) for i in range(4)]
+nbits = int(os.environ.get("NB", "12"))
+imgs = [L.synth_image(w, h, nbits, dist, float(os.environ.get("SIGMA", "12")), 3000 + i) for i in range(4)]
 bufs = [L.encode7(im) for im in imgs]
 tin = [torch.from_numpy(bufs[i % 4]).to(dev) for i in range(n)]
 tout = torch.zeros(n * w * h * 2, dtype=torch.uint8, device=dev)

@@ -10,14 +10,15 @@ import torch
 import _libs as L
 import motioncam_decoder_amd as M
 
-w, h = 3840, 2160
+w, h = int(os.environ.get("W", "3840")), int(os.environ.get("H", "2160"))
+nbits = int(os.environ.get("NB", "12"))
 dist = 1 if os.environ.get("DIST", "nat") == "nat" else 0
 dev = torch.device("cuda:0")
-imgs = [L.synth_image(w, h, 12, dist, 12.0, 3000 + i) for i in range(4)]
+imgs = [L.synth_image(w, h, nbits, dist, float(os.environ.get("SIGMA", "12")), 3000 + i) for i in range(4)]
 bufs = [L.encode7(im) for im in imgs]
 ctx = M.Context(0)
 ctx.profile(True)
-nmax = 480
+nmax = int(os.environ.get("NMAX", "480"))
 tin = [torch.from_numpy(bufs[i % 4]).to(dev) for i in range(nmax)]
 tout = torch.zeros(nmax * w * h * 2, dtype=torch.uint8, device=dev)
 for n in [int(x) for x in os.environ.get("NS", "1,2,16,64,120,128,180,240,360,480").split(",")]:
