@@ -334,7 +334,10 @@ def pcie_inclusive(M, L, ctx, wl, comm, link=None, nframes=240, reps=2, pack12=F
     """End-to-end rate when the boundary hands over HOST buffers (never `value`): frames in pinned
     memory -> H2D -> decode -> D2H into pinned memory, sub-batches pipelined on the context's
     streams (mcraw_decode_batch, MCRAW_MEM_HOST).  pack12: with the fused 12-bit strip stage, which
-    sends 1.5 instead of 2 bytes per sample back over the link."""
+    sends 1.5 instead of 2 bytes per sample back over the link.
+    Every rank runs the SAME sequence of collectives whatever happens to it: a rank that fails (allocation, a frame
+    status, a mismatch) says so in the reduction behind each phase, and all ranks leave the leg together -- no rank
+    is left waiting in a barrier for one that raised."""
     lib = M.load()
     d = len(wl.pairs)
     n = min(nframes, wl.frames)
@@ -342,30 +345,48 @@ def pcie_inclusive(M, L, ctx, wl, comm, link=None, nframes=240, reps=2, pack12=F
     row_bytes = L.post_row_bytes(wl.w, bits=bits)
     out_bytes = wl.h * row_bytes
     ins, outs, descs = [], [], []
-    if bits:
-        ctx.set_post(bits=bits)
+    err = None
+
+    def all_ok():
+        return comm.min([0.0 if err else 1.0])[0] > 0.5
+
     try:
-        for i in range(n):
-            buf = wl.pairs[i % d][1]
-            pi = lib.mcraw_host_alloc(buf.size)
-            po = lib.mcraw_host_alloc(out_bytes)
-            ins.append(pi)
-            outs.append(po)
-            C.memmove(pi, buf.ctypes.data, buf.size)
-            descs.append((pi, buf.size, wl.w, wl.h, M.TYPE_BLOCK, po, out_bytes // 2))
-        frames = M.Context.make_frames(descs)
-        ctx.decode_batch(frames, mem=M.MEM_HOST)  # warm-up: staging buffers get allocated
+        try:
+            if bits:
+                ctx.set_post(bits=bits)
+            for i in range(n):
+                buf = wl.pairs[i % d][1]
+                pi = lib.mcraw_host_alloc(buf.size)
+                po = lib.mcraw_host_alloc(out_bytes)
+                if not pi or not po:
+                    raise MemoryError("mcraw_host_alloc failed")
+                ins.append(pi)
+                outs.append(po)
+                C.memmove(pi, buf.ctypes.data, buf.size)
+                descs.append((pi, buf.size, wl.w, wl.h, M.TYPE_BLOCK, po, out_bytes // 2))
+            frames = M.Context.make_frames(descs)
+            ctx.decode_batch(frames, mem=M.MEM_HOST)  # warm-up: staging buffers get allocated
+        except Exception as e:
+            err = e
+        if not all_ok():
+            return {"error": repr(err) if err else "another rank failed in the set-up of this leg"}
         comm.barrier()                             # every rank pulls on the host's memory and its own link at the same time
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            written, status = ctx.decode_batch(frames, mem=M.MEM_HOST)
-        t_local = (time.perf_counter() - t0) / reps
+        t_local, ok = 1e9, False
+        try:
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                written, status = ctx.decode_batch(frames, mem=M.MEM_HOST)
+            t_local = (time.perf_counter() - t0) / reps
+            ok = all(s == 0 for s in status)
+            got = np.ctypeslib.as_array(C.cast(outs[0], C.POINTER(C.c_uint8)), shape=(wl.h, row_bytes))
+            ok = ok and np.array_equal(got, L.oracle_post(wl.pairs[0][0], None, bits=bits))
+        except Exception as e:
+            err = e
         comm.barrier()
         t = comm.max([t_local])[0]                 # the job's rate is set by its slowest rank
-        ok = all(s == 0 for s in status)
-        got = np.ctypeslib.as_array(C.cast(outs[0], C.POINTER(C.c_uint8)), shape=(wl.h, row_bytes))
-        ok = ok and np.array_equal(got, L.oracle_post(wl.pairs[0][0], None, bits=bits))
         ok = bool(comm.min([1.0 if ok else 0.0])[0] > 0.5)
+        if not all_ok():
+            return {"error": repr(err) if err else "another rank failed in the timed part of this leg"}
         in_b = sum(wl.pairs[i % d][1].size for i in range(n))
         world = comm.world
         res = {"frames_per_rank": n, "mpix_s": round(world * n * wl.w * wl.h / t / 1e6, 1), "frames_per_s": round(world * n / t, 1),
@@ -380,9 +401,82 @@ def pcie_inclusive(M, L, ctx, wl, comm, link=None, nframes=240, reps=2, pack12=F
             res["link_frac"] = round(t_link / t_local, 3)
         return res
     finally:
-        ctx.set_post()
+        try:
+            ctx.set_post()
+        except Exception:
+            pass
         for p in ins + outs:
             lib.mcraw_host_free(p)
+
+
+def pool_leg(torch, M, L, wl, devices, link=None, nframes=240, reps=2):
+    """The PRODUCT's multi-GPU driver (mcraw_pool_*: one context and one NUMA-bound host thread per GPU, frame i ->
+    member i mod G) on this workload: host buffers in and out (pinned memory allocated by each member's own thread), and
+    buffers resident in each member's HBM (mcraw_pool_decode_batch_device, BASELINE config 5's form).  One process
+    drives every GPU in `devices` -- the counterpart of the one-process-per-GPU numbers above."""
+    lib = M.load()
+    pool = M.Pool(devices)
+    G = pool.size
+    d = len(wl.pairs)
+    n = min(nframes, wl.frames)
+    out_bytes = wl.w * wl.h * 2
+    ins, outs, descs = [], [], []
+    try:
+        for i in range(n):
+            buf = wl.pairs[i % d][1]
+            pi, po = pool.host_alloc(i % G, buf.size), pool.host_alloc(i % G, out_bytes)
+            assert pi and po
+            ins.append(pi)
+            outs.append(po)
+            C.memmove(pi, buf.ctypes.data, buf.size)
+            descs.append((pi, buf.size, wl.w, wl.h, M.TYPE_BLOCK, po, out_bytes // 2))
+        frames = M.Context.make_frames(descs)
+        pool.decode_batch(frames)  # warm-up: staging buffers get allocated
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            written, status = pool.decode_batch(frames)
+        t = (time.perf_counter() - t0) / reps
+        ok = all(s == 0 for s in status)
+        got = np.ctypeslib.as_array(C.cast(outs[n - 1], C.POINTER(C.c_uint16)), shape=(wl.h, wl.w))
+        ok = ok and np.array_equal(got, wl.pairs[(n - 1) % d][0])
+        in_b = sum(wl.pairs[i % d][1].size for i in range(n))
+        res = {"devices": pool.devices(), "numa_cpus": pool.numa_cpus(),
+               "host_buffers": {"frames": n, "frames_per_s": round(n / t, 1), "mpix_s": round(n * wl.w * wl.h / t / 1e6, 1),
+                                "h2d_GBs": round(in_b / t / 1e9, 2), "d2h_GBs": round(n * out_bytes / t / 1e9, 2), "bit_exact": bool(ok)}}
+        if link:
+            per = max(in_b, n * out_bytes) / G / (link["each_way_when_both_GBs"] * 1e9)  # every member has a link of its own
+            res["host_buffers"]["link_frac"] = round(per / t, 3)
+    finally:
+        for p_ in ins + outs:
+            lib.mcraw_host_free(p_)
+    # resident: frame i in the HBM of member i % G
+    try:
+        devs = pool.devices()
+        tin, tout, descs = [], [], []
+        for i in range(n):
+            dev = torch.device("cuda", devs[i % G])
+            ti = torch.from_numpy(wl.pairs[i % d][1]).to(dev)
+            to = torch.zeros(out_bytes, dtype=torch.uint8, device=dev)
+            tin.append(ti)
+            tout.append(to)
+            descs.append((ti.data_ptr(), ti.numel(), wl.w, wl.h, M.TYPE_BLOCK, to.data_ptr(), out_bytes // 2))
+        for dv in sorted(set(devs)):
+            torch.cuda.synchronize(dv)
+        frames = M.Context.make_frames(descs)
+        pool.decode_batch_device(frames)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            written, status = pool.decode_batch_device(frames)
+        t = (time.perf_counter() - t0) / 5
+        ok = all(s == 0 for s in status)
+        got = tout[n - 1].cpu().numpy().view(np.uint16).reshape(wl.h, wl.w)
+        ok = ok and np.array_equal(got, wl.pairs[(n - 1) % d][0])
+        res["resident"] = {"frames": n, "ms_per_batch": round(t * 1e3, 4), "frames_per_s": round(n / t, 1),
+                           "mpix_s": round(n * wl.w * wl.h / t / 1e6, 1), "bit_exact": bool(ok),
+                           "note": "synchronous call: host hand-off, kernels and status read-back of every member"}
+    finally:
+        pool.close()
+    return res
 
 
 def post_stage(torch, ctx, M, L, wl, steps):
@@ -564,15 +658,33 @@ def main():
     if not args.no_pcie and not args.no_cpu:
         # the host-buffer legs run on EVERY rank at once: what limits a node is its PCIe links and the host
         # memory feeding them, not the HBM-resident kernels
+        link = None
         try:
-            link = link_probe(torch, dev)
+            link = link_probe(torch, dev)  # (no collective inside)
             extra["pcie_link"] = link
-            extra["pcie_inclusive"] = pcie_inclusive(M, L, ctx, wl, comm, link, nframes=min(240, args.frames))
-            extra["pcie_inclusive_pack12"] = pcie_inclusive(M, L, ctx, wl, comm, link, nframes=min(240, args.frames), pack12=True)
-            # what 10-bit footage ships: 1.25 bytes per sample (these 12-bit frames saturate at 1023 on the way, like the oracle's)
-            extra["pcie_inclusive_pack10"] = pcie_inclusive(M, L, ctx, wl, comm, link, nframes=min(240, args.frames), bits=10)
         except Exception as e:
-            extra["pcie_inclusive"] = {"error": repr(e)}
+            extra["pcie_link"] = {"error": repr(e)}
+        link = link if bool(comm.min([1.0 if link else 0.0])[0] > 0.5) else None
+        # (every leg is collective-safe: a rank that fails inside one leaves it together with the others)
+        extra["pcie_inclusive"] = pcie_inclusive(M, L, ctx, wl, comm, link, nframes=min(240, args.frames))
+        extra["pcie_inclusive_pack12"] = pcie_inclusive(M, L, ctx, wl, comm, link, nframes=min(240, args.frames), pack12=True)
+        # what 10-bit footage ships: 1.25 bytes per sample (these 12-bit frames saturate at 1023 on the way, like the oracle's)
+        extra["pcie_inclusive_pack10"] = pcie_inclusive(M, L, ctx, wl, comm, link, nframes=min(240, args.frames), bits=10)
+
+    if not args.no_pcie and not args.no_cpu:
+        # the product's own multi-GPU driver (mcraw_pool_*), one process over the GPUs: on one GPU as pools of one and of
+        # two members, at N > 1 from rank 0 over every visible GPU while the other ranks idle at the barrier
+        if rank == 0:
+            try:
+                if world == 1:
+                    extra["pool"] = [pool_leg(torch, M, L, wl, [local], extra.get("pcie_link")),
+                                     pool_leg(torch, M, L, wl, [local, local], extra.get("pcie_link"))]
+                else:
+                    ndev = min(torch.cuda.device_count(), world)
+                    extra["pool"] = [pool_leg(torch, M, L, wl, list(range(ndev)), extra.get("pcie_link"), nframes=min(240, args.frames))]
+            except Exception as e:
+                extra["pool"] = {"error": repr(e)}
+        comm.barrier()
 
     if rank == 0:
         def summarize(r):

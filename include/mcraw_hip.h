@@ -109,8 +109,9 @@ int mcraw_ctx_synchronize(mcraw_ctx *ctx, int32_t *status, int nframes);
  * The reference walks a clip frame by frame on one thread (example.cpp:187-195 over
  * lib/Decoder.cpp:184-235).  Frames are independent, so a batch shards by frame index: frame i is
  * decoded by pool member i mod G -- no exchange between devices.  Every member is a context of its
- * own, driven by one host thread of its own that is bound to the CPUs of its GPU's NUMA node.
- * Results do not depend on the pool size.  Buffers are host memory (MCRAW_MEM_HOST semantics). */
+ * own, driven by one host thread of its own that is bound to the CPUs of its GPU's NUMA node (those of them the
+ * process may run on).  Results do not depend on the pool size.  Buffers are host memory (MCRAW_MEM_HOST semantics)
+ * except for mcraw_pool_decode_batch_device. */
 typedef struct mcraw_pool mcraw_pool;
 typedef struct mcraw_pool_ticket mcraw_pool_ticket;
 struct mcraw_post;
@@ -132,8 +133,15 @@ mcraw_ctx *mcraw_pool_ctx(mcraw_pool *pool, int member);      /* for the measure
 int mcraw_pool_set_post(mcraw_pool *pool, const struct mcraw_post *post);
 /* Pinned host memory allocated by the member's own (NUMA-bound) thread: local to its GPU.  Free with mcraw_host_free. */
 void *mcraw_pool_host_alloc(mcraw_pool *pool, int member, size_t bytes);
-/* One batch over all members; the asynchronous form returns when every member has queued its share. */
+/* One batch over all members; the asynchronous form returns when every member has queued its share.
+ * The pool may be used from several host threads at once (batches are dealt one at a time, every member runs its tasks
+ * in the order they were handed to it); a ticket is waited for by one thread. */
 int mcraw_pool_decode_batch(mcraw_pool *pool, const mcraw_frame *frames, int nframes, size_t *written, int32_t *status);
+/* The same for buffers that are already resident: frames[i].in / .out are device pointers in the HBM of the GPU that
+ * decodes frame i, mcraw_pool_device(pool, i % mcraw_pool_size(pool)) -- BASELINE config 5's form (a clip sharded over
+ * the node's GPUs by frame index; lib/Decoder.cpp:184-235 run as one batch).  Synchronous: returns when every member's
+ * share is decoded. */
+int mcraw_pool_decode_batch_device(mcraw_pool *pool, const mcraw_frame *frames, int nframes, size_t *written, int32_t *status);
 int mcraw_pool_decode_batch_async(mcraw_pool *pool, const mcraw_frame *frames, int nframes, mcraw_pool_ticket **ticket);
 int mcraw_pool_ticket_wait(mcraw_pool_ticket *ticket, size_t *written, int32_t *status);
 

@@ -34,6 +34,7 @@ ABI_SYMBOLS = [
     "mcraw_ctx_profile_every", "mcraw_legacy_launch_order", "mcraw_shard_of", "mcraw_shard_count", "mcraw_pool_create", "mcraw_pool_destroy", "mcraw_pool_last_error",
     "mcraw_pool_size", "mcraw_pool_device", "mcraw_pool_numa_cpus", "mcraw_pool_ctx", "mcraw_pool_set_post",
     "mcraw_pool_host_alloc", "mcraw_pool_decode_batch", "mcraw_pool_decode_batch_async", "mcraw_pool_ticket_wait",
+    "mcraw_pool_decode_batch_device",
 ]
 
 POST_BLACK, POST_PACK12, POST_PACK10, POST_PACK14 = 1, 2, 4, 8
@@ -143,6 +144,8 @@ def load():
     lib.mcraw_pool_host_alloc.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
     lib.mcraw_pool_decode_batch.restype = C.c_int
     lib.mcraw_pool_decode_batch.argtypes = [C.c_void_p, C.POINTER(Frame), C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
+    lib.mcraw_pool_decode_batch_device.restype = C.c_int
+    lib.mcraw_pool_decode_batch_device.argtypes = [C.c_void_p, C.POINTER(Frame), C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
     lib.mcraw_pool_decode_batch_async.restype = C.c_int
     lib.mcraw_pool_decode_batch_async.argtypes = [C.c_void_p, C.POINTER(Frame), C.c_int, C.POINTER(C.c_void_p)]
     lib.mcraw_pool_ticket_wait.restype = C.c_int
@@ -191,14 +194,28 @@ class Pool:
     def set_post(self, black=None, pack12=False, bits=None):
         nb = int(bits) if bits else (12 if pack12 else 16)
         if black is None and nb == 16:
-            return self._lib.mcraw_pool_set_post(self._h, None)
-        p = Post()
-        if black is not None:
-            p.flags |= POST_BLACK
-            for i in range(4):
-                p.black[i] = int(black[i])
-        p.flags |= _PACK_FLAG[nb]
-        return self._lib.mcraw_pool_set_post(self._h, C.byref(p))
+            rc = self._lib.mcraw_pool_set_post(self._h, None)
+        else:
+            p = Post()
+            if black is not None:
+                p.flags |= POST_BLACK
+                for i in range(4):
+                    p.black[i] = int(black[i])
+            p.flags |= _PACK_FLAG[nb]
+            rc = self._lib.mcraw_pool_set_post(self._h, C.byref(p))
+        if rc != 0:  # (a rejected stage must not decode plain mosaics silently)
+            raise McrawError("mcraw_pool_set_post failed (%d): %s" % (rc, self._lib.mcraw_last_error().decode()))
+
+    def decode_batch_device(self, frames):
+        """frames: ctypes array from Context.make_frames whose in / out pointers live in the HBM of the GPU that decodes
+        the frame: frame i on ``devices()[i % size]``.  Returns (written, status)."""
+        n = len(frames)
+        written = (C.c_size_t * max(n, 1))()
+        status = (C.c_int32 * max(n, 1))()
+        rc = self._lib.mcraw_pool_decode_batch_device(self._h, frames, n, written, status)
+        if rc != 0:
+            raise McrawError("mcraw_pool_decode_batch_device failed (%d): %s" % (rc, self._lib.mcraw_pool_last_error().decode()))
+        return list(written)[:n], list(status)[:n]
 
     def decode_batch(self, frames):
         """frames: ctypes array from Context.make_frames (host pointers).  Returns (written, status)."""

@@ -13,27 +13,63 @@ import time
 
 # ------------------------------------------------------------------ placement
 
-def gpu_numa_node(local_rank):
-    """NUMA node of the local_rank-th AMD GPU (PCI order), read from sysfs without touching HIP.
-    None when it cannot be told (no sysfs entry, single-node host reports -1)."""
-    devs = []
+def _visible_ordinals():
+    """HIP ordinal -> physical ordinal (PCI order) under HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES (numeric lists only;
+    None: no remapping)."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v:
+            try:
+                return [int(x) for x in v.split(",") if x.strip() != ""]
+            except ValueError:
+                return None  # (UUID form: the order cannot be told without the runtime)
+    return None
+
+
+def gpu_pci_devices():
+    """sysfs device directories of the AMD GPUs, ordered by PCI address (domain:bus:device.function, numerically) --
+    the order in which the HIP runtime numbers them when nothing remaps it."""
+    devs = {}
     for d in glob.glob("/sys/class/drm/renderD*/device"):
         try:
             with open(os.path.join(d, "vendor")) as f:
                 if f.read().strip() != "0x1002":
                     continue
-            devs.append(os.path.realpath(d))
-        except OSError:
+            real = os.path.realpath(d)
+            bdf = os.path.basename(real)  # e.g. 0000:c1:00.0
+            dom, bus, rest = bdf.split(":")
+            dev, fn = rest.split(".")
+            devs[(int(dom, 16), int(bus, 16), int(dev, 16), int(fn, 16))] = real
+        except (OSError, ValueError):
             continue
-    devs = sorted(set(devs))
-    if local_rank >= len(devs):
-        return None
+    return [devs[k] for k in sorted(devs)]
+
+
+def gpu_numa_node(local_rank, bdf=None):
+    """NUMA node of the local_rank-th visible AMD GPU (or of the GPU at PCI address `bdf`, e.g. from
+    torch.cuda.get_device_properties), read from sysfs without touching HIP.  Returns (node, bdf); node is None when it
+    cannot be told (no sysfs entry, single-node host reports -1)."""
+    path = None
+    if bdf:
+        path = os.path.join("/sys/bus/pci/devices", bdf.lower())
+    else:
+        devs = gpu_pci_devices()
+        vis = _visible_ordinals()
+        idx = local_rank
+        if vis is not None:
+            if local_rank >= len(vis):
+                return None, None
+            idx = vis[local_rank]
+        if idx >= len(devs):
+            return None, None
+        path = devs[idx]
+        bdf = os.path.basename(path)
     try:
-        with open(os.path.join(devs[local_rank], "numa_node")) as f:
+        with open(os.path.join(path, "numa_node")) as f:
             node = int(f.read().strip())
     except (OSError, ValueError):
-        return None
-    return node if node >= 0 else None
+        return None, bdf
+    return (node if node >= 0 else None), bdf
 
 
 def node_cpus(node):
@@ -54,10 +90,10 @@ def node_cpus(node):
     return cpus
 
 
-def bind_to_gpu_numa(local_rank):
+def bind_to_gpu_numa(local_rank, bdf=None):
     """Pin this process (and the pinned buffers it will first-touch) to the NUMA node of its GPU.
-    Call BEFORE the first GPU call.  Returns {"node": n, "cpus": k} or None (nothing done)."""
-    node = gpu_numa_node(local_rank)
+    Call BEFORE the first pinned allocation.  Returns {"node": n, "cpus": k, "bdf": PCI address} or None (nothing done)."""
+    node, bdf = gpu_numa_node(local_rank, bdf)
     if node is None:
         return None
     cpus = node_cpus(node)
@@ -71,7 +107,7 @@ def bind_to_gpu_numa(local_rank):
         os.sched_setaffinity(0, want)
     except (AttributeError, OSError):
         return None
-    return {"node": node, "cpus": len(want)}
+    return {"node": node, "cpus": len(want), "bdf": bdf}
 
 
 # ------------------------------------------------------------------ timed region

@@ -111,6 +111,7 @@ struct mcraw_ticket {
     std::vector<int32_t> status;
     std::vector<uint32_t> encH; // coded heights (type-7 frames)
     std::vector<Part> parts;
+    std::vector<int> skipped; // frames that no sub-batch holds (no device memory for their workspace): failed on their own
     Post post{0, 0, 0}; // post stage the batch was submitted with
 };
 
@@ -670,6 +671,13 @@ inline Geom7 header_geometry(const mcraw_frame &f)
     if (h[0] == 0u || h[1] == 0u || (h[0] & 63u) || (h[1] & 3u) || h[0] < static_cast<uint32_t>(f.width) ||
         static_cast<uint64_t>(h[0]) * h[1] >= (1ull << 31))
         return g;
+    // a header is untrusted input: N = encW * encH / 64 blocks need two side streams of ceil(N / 64) records of at least two
+    // bytes each, behind their 4-byte counts and the 16-byte header (RawData.cpp:463-498) -- a frame buffer shorter than that
+    // cannot hold the geometry it claims, and gets no workspace for it (it is planned from width x height, and k7_side then
+    // rejects its header)
+    const uint64_t nrecords = (static_cast<uint64_t>(h[0]) * h[1] / 64u + GROUP_BLOCKS - 1u) / GROUP_BLOCKS;
+    if (16u + 2u * (4u + 2u * nrecords) > f.len)
+        return g;
     g.encW = h[0];
     g.encH = h[1];
     return g;
@@ -816,19 +824,49 @@ int host_submit(mcraw_ticket *t)
     t->status.assign(n, 0);
     t->encH.assign(n, 0u);
     t->post = c->post;
+    // Workspace of a sub-batch: every type-7 frame gets the stride of the largest one (the kernels address it from (frame,
+    // group) alone), so one large frame among many small ones -- or one header that claims a large geometry -- must not be
+    // multiplied by the frames around it: a sub-batch is also closed when that product passes WS_BUDGET.
+    constexpr size_t WS_BUDGET = 1ull << 30;
+    auto groups_of = [&](int i) -> size_t {
+        const mcraw_frame &f = frames[i];
+        if (f.type != MCRAW_TYPE_BLOCK || !frame_args_ok(f, f.in, f.out))
+            return 0;
+        const Geom7 g = header_geometry(f);
+        const uint64_t encW = g.encW ? g.encW : up(static_cast<size_t>(f.width), 64), encH = g.encW ? g.encH : up(static_cast<size_t>(f.height), 4);
+        return static_cast<size_t>((encW * encH / 64u + GROUP_BLOCKS - 1u) / GROUP_BLOCKS);
+    };
+    constexpr size_t WS_PER_GROUP = 64u * 3u + 4u * ITEM_SPLIT; // bits (u8) + refs (u16) per block, one offset per item
     int first = 0;
     while (first < n) {
-        size_t bytes = 0;
-        int count = 0;
+        size_t bytes = 0, gmax = 0;
+        int count = 0, n7 = 0;
         while (first + count < n) {
             const mcraw_frame &f = frames[first + count];
             const size_t fb = frame_args_ok(f, f.in, f.out) ? f.len + static_cast<size_t>(f.width) * f.height * 2 : 0;
-            if (count > 0 && bytes + fb > SUB_BYTES)
+            const size_t g = groups_of(first + count);
+            const size_t gm = std::max(gmax, g);
+            if (count > 0 && (bytes + fb > SUB_BYTES || gm * WS_PER_GROUP * static_cast<size_t>(n7 + (g ? 1 : 0)) > WS_BUDGET))
                 break;
             bytes += fb;
+            gmax = gm;
+            n7 += g ? 1 : 0;
             count++;
         }
-        if (int rc = host_submit_part(t, first, count)) {
+        int rc = host_submit_part(t, first, count);
+        // out of device memory: halve the sub-batch; a single frame that cannot get its workspace fails alone
+        while (rc == -static_cast<int>(hipErrorOutOfMemory) && count > 1) {
+            (void)hipGetLastError();
+            count = (count + 1) / 2;
+            rc = host_submit_part(t, first, count);
+        }
+        if (rc == -static_cast<int>(hipErrorOutOfMemory)) {
+            (void)hipGetLastError();
+            t->status[first] |= MCRAW_E_DEVICE;
+            t->skipped.push_back(first);
+            rc = 0;
+        }
+        if (rc) {
             // nothing of this batch may still be moving when the caller hears of the failure (it may free its buffers)
             (void)hipStreamSynchronize(c->h2d);
             for (Part &p : t->parts) {
@@ -853,6 +891,8 @@ int host_finish(mcraw_ticket *t, size_t *written, int32_t *status_out)
     for (size_t k = 0; k < t->parts.size(); k++)
         if (int rc = drain_part(t, static_cast<int>(k)))
             return rc;
+    for (int i : t->skipped)
+        t->status[i] |= MCRAW_E_DEVICE;
     for (int i = 0; i < n; i++) {
         // every frame was planned from its real header (header_geometry), so no frame is left to plan again
         const int32_t st = public_status(t->status[i]);

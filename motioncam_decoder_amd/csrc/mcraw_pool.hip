@@ -11,6 +11,7 @@
 #include <sched.h>
 
 #include <condition_variable>
+#include <deque>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -58,7 +59,9 @@ std::vector<int> cpus_near_pci(const char *bus_id)
     return cpus;
 }
 
-// One pool member: a device, its context, and the host thread that drives it.
+// One pool member: a device, its context, and the host thread that drives it.  Tasks are queued and run in order; run()
+// returns the task's number and wait() blocks until that task has run, so several host threads may hand a member work
+// at the same time (each waits for its own task).
 struct Member {
     int device = 0;
     int numa_cpus = 0; // CPUs the thread was bound to (0: not bound)
@@ -66,63 +69,76 @@ struct Member {
     std::thread thread;
     std::mutex mu;
     std::condition_variable cv;
-    std::function<void()> task; // one at a time
-    bool has_task = false, done = true, quit = false;
+    std::deque<std::function<void()>> tasks;
+    uint64_t submitted = 0, completed = 0;
+    bool created = false, quit = false;
     int create_rc = 0;
     std::string create_err;
 
-    void run(std::function<void()> fn)
+    uint64_t run(std::function<void()> fn)
     {
         std::unique_lock<std::mutex> lk(mu);
-        task = std::move(fn);
-        has_task = true;
-        done = false;
+        tasks.push_back(std::move(fn));
+        const uint64_t seq = ++submitted;
         cv.notify_all();
+        return seq;
     }
-    void wait()
+    void wait(uint64_t seq)
     {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return done; });
+        cv.wait(lk, [&] { return completed >= seq; });
+    }
+    void wait_created()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return created; });
     }
     void loop()
     {
-        // before the first HIP call of this thread: next to the GPU
+        // before the first HIP call of this thread: next to the GPU -- on those CPUs of the GPU's NUMA node that the process
+        // is allowed to run on (a launcher's taskset / cpuset stays in force; no common CPU: the thread stays where it is)
         char bus[64] = {0};
         if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) == hipSuccess) {
             for (char *p = bus; *p; p++)
                 if (*p >= 'A' && *p <= 'F')
                     *p = static_cast<char>(*p - 'A' + 'a');
             const std::vector<int> cpus = cpus_near_pci(bus);
-            cpu_set_t set;
+            cpu_set_t allowed, set;
+            CPU_ZERO(&allowed);
             CPU_ZERO(&set);
-            for (int c : cpus)
-                if (c >= 0 && c < CPU_SETSIZE)
-                    CPU_SET(c, &set);
-            if (!cpus.empty() && sched_setaffinity(0, sizeof(set), &set) == 0)
-                numa_cpus = static_cast<int>(cpus.size());
+            int n = 0;
+            if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0) {
+                for (int c : cpus)
+                    if (c >= 0 && c < CPU_SETSIZE && CPU_ISSET(c, &allowed)) {
+                        CPU_SET(c, &set);
+                        n++;
+                    }
+                if (n > 0 && sched_setaffinity(0, sizeof(set), &set) == 0)
+                    numa_cpus = n;
+            }
         }
         create_rc = mcraw_ctx_create(device, &ctx);
         if (create_rc != 0)
             create_err = mcraw_last_error();
         {
             std::unique_lock<std::mutex> lk(mu);
-            done = true; // "created"
+            created = true;
             cv.notify_all();
         }
         for (;;) {
             std::function<void()> fn;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return has_task || quit; });
-                if (quit && !has_task)
-                    break;
-                fn = std::move(task);
-                has_task = false;
+                cv.wait(lk, [&] { return !tasks.empty() || quit; });
+                if (tasks.empty())
+                    break; // (quit, and nothing left to run)
+                fn = std::move(tasks.front());
+                tasks.pop_front();
             }
             fn();
             {
                 std::unique_lock<std::mutex> lk(mu);
-                done = true;
+                completed++;
                 cv.notify_all();
             }
         }
@@ -222,13 +238,12 @@ int mcraw_pool_create(const int *devices, int ndevices, mcraw_pool **out)
     for (int d : devs) {
         Member *m = new Member();
         m->device = d;
-        m->done = false;
         m->thread = std::thread([m] { m->loop(); });
         p->members.push_back(m);
     }
     int rc = 0;
     for (Member *m : p->members) {
-        m->wait();
+        m->wait_created();
         if (m->create_rc != 0 && rc == 0) {
             rc = m->create_rc;
             g_pool_err = m->create_err;
@@ -286,6 +301,7 @@ int mcraw_pool_set_post(mcraw_pool *p, const mcraw_post *post)
 {
     if (!p)
         return -1;
+    std::lock_guard<std::mutex> lk(p->mu); // not while a batch is being dealt: all members of one batch get the same stage
     int rc = 0;
     for (Member *m : p->members)
         if (int r = mcraw_ctx_set_post(m->ctx, post))
@@ -299,8 +315,7 @@ void *mcraw_pool_host_alloc(mcraw_pool *p, int member, size_t bytes)
         return nullptr;
     Member *m = p->members[member];
     void *res = nullptr;
-    m->run([&] { res = mcraw_host_alloc(bytes); }); // pages are taken by the member's (NUMA-bound) thread
-    m->wait();
+    m->wait(m->run([&] { res = mcraw_host_alloc(bytes); })); // pages are taken by the member's (NUMA-bound) thread
     return res;
 }
 
@@ -327,9 +342,10 @@ int mcraw_pool_decode_batch_async(mcraw_pool *p, const mcraw_frame *frames, int 
         t->index[m].push_back(i);
     }
     std::lock_guard<std::mutex> lk(p->mu);
+    std::vector<uint64_t> seq(G, 0);
     for (int m = 0; m < G; m++) {
         Member *mem = p->members[m];
-        mem->run([t, m, mem] {
+        seq[m] = mem->run([t, m, mem] {
             if (t->sub[m].empty())
                 return;
             t->rc[m] = mcraw_decode_batch_async(mem->ctx, t->sub[m].data(), static_cast<int>(t->sub[m].size()), &t->tickets[m]);
@@ -339,7 +355,7 @@ int mcraw_pool_decode_batch_async(mcraw_pool *p, const mcraw_frame *frames, int 
     }
     int rc = 0;
     for (int m = 0; m < G; m++) {
-        p->members[m]->wait();
+        p->members[m]->wait(seq[m]);
         if (t->rc[m] != 0 && rc == 0) {
             rc = t->rc[m];
             g_pool_err = t->err[m];
@@ -365,12 +381,13 @@ int mcraw_pool_ticket_wait(mcraw_pool_ticket *t, size_t *written, int32_t *statu
     std::vector<std::vector<size_t>> wr(G);
     std::vector<std::vector<int32_t>> st(G);
     {
-        std::lock_guard<std::mutex> lk(p->mu);
+        // (no pool lock: a wait must not keep another host thread from dealing its batch; the members' queues keep order)
+        std::vector<uint64_t> seq(G, 0);
         for (int m = 0; m < G; m++) {
             wr[m].assign(t->sub[m].size(), 0);
             st[m].assign(t->sub[m].size(), 0);
             Member *mem = p->members[m];
-            mem->run([t, m, &wr, &st] {
+            seq[m] = mem->run([t, m, &wr, &st] {
                 if (!t->tickets[m])
                     return;
                 t->rc[m] = mcraw_ticket_wait(t->tickets[m], wr[m].data(), st[m].data());
@@ -380,7 +397,7 @@ int mcraw_pool_ticket_wait(mcraw_pool_ticket *t, size_t *written, int32_t *statu
             });
         }
         for (int m = 0; m < G; m++)
-            p->members[m]->wait();
+            p->members[m]->wait(seq[m]);
     }
     int rc = 0;
     for (int m = 0; m < G; m++) {
@@ -396,6 +413,58 @@ int mcraw_pool_ticket_wait(mcraw_pool_ticket *t, size_t *written, int32_t *statu
         }
     }
     delete t;
+    return rc;
+}
+
+int mcraw_pool_decode_batch_device(mcraw_pool *p, const mcraw_frame *frames, int nframes, size_t *written, int32_t *status)
+{
+    if (!p || nframes < 0 || (nframes > 0 && !frames)) {
+        g_pool_err = "mcraw_pool_decode_batch_device: bad arguments";
+        return -1;
+    }
+    const int G = static_cast<int>(p->members.size());
+    std::vector<std::vector<mcraw_frame>> sub(G);
+    std::vector<std::vector<int>> index(G);
+    for (int i = 0; i < nframes; i++) { // frame i -> member i mod G: its buffers live in THAT member's HBM
+        const int m = mcraw_shard_of(i, G);
+        sub[m].push_back(frames[i]);
+        index[m].push_back(i);
+    }
+    std::vector<std::vector<size_t>> wr(G);
+    std::vector<std::vector<int32_t>> st(G);
+    std::vector<int> rcs(G, 0);
+    std::vector<std::string> errs(G);
+    std::vector<uint64_t> seq(G, 0);
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        for (int m = 0; m < G; m++) {
+            wr[m].assign(sub[m].size(), 0);
+            st[m].assign(sub[m].size(), 0);
+            Member *mem = p->members[m];
+            seq[m] = mem->run([&, m, mem] {
+                if (sub[m].empty())
+                    return;
+                rcs[m] = mcraw_decode_batch(mem->ctx, sub[m].data(), static_cast<int>(sub[m].size()), MCRAW_MEM_DEVICE, nullptr,
+                                            wr[m].data(), st[m].data());
+                if (rcs[m] != 0)
+                    errs[m] = mcraw_last_error();
+            });
+        }
+    }
+    int rc = 0;
+    for (int m = 0; m < G; m++) {
+        p->members[m]->wait(seq[m]);
+        if (rcs[m] != 0 && rc == 0) {
+            rc = rcs[m];
+            g_pool_err = errs[m];
+        }
+        for (size_t k = 0; k < index[m].size(); k++) {
+            if (written)
+                written[index[m][k]] = wr[m][k];
+            if (status)
+                status[index[m][k]] = st[m][k];
+        }
+    }
     return rc;
 }
 

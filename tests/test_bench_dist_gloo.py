@@ -53,5 +53,13 @@ def test_timed_rounds_single_process():
 
 def test_numa_helpers_do_not_need_a_gpu():
     # no AMD GPU in this container: the helper says so instead of failing
-    assert benchlib.gpu_numa_node(0) is None or isinstance(benchlib.gpu_numa_node(0), int)
+    node, bdf = benchlib.gpu_numa_node(0)
+    assert node is None or isinstance(node, int)
+    # the GPUs are taken in PCI order and HIP_VISIBLE_DEVICES is honoured (a remapped rank must not bind to another GPU's node)
+    os.environ["HIP_VISIBLE_DEVICES"] = "5,2"
+    try:
+        assert benchlib._visible_ordinals() == [5, 2]
+        assert benchlib.gpu_numa_node(2) == (None, None)
+    finally:
+        del os.environ["HIP_VISIBLE_DEVICES"]
     assert benchlib.bind_to_gpu_numa(63) is None

@@ -273,3 +273,36 @@ def test_legacy_stream_with_more_than_2_24_records_does_not_wrap_into_the_frame(
     written, status, outs = decode_batch_device(gpu_ctx, [(6, w, h, buf)])
     assert status == [0] and written == [w * h]
     assert np.array_equal(outs[0], img)
+
+
+def test_host_batches_do_not_trust_a_header_for_their_workspace(gpu_ctx):
+    """Host-memory batches plan every frame from its own 16-byte header (RawData.cpp:500-524), which is untrusted input.
+    A header that claims more blocks than the buffer could describe gets no workspace for them, a frame that claims a
+    huge (but possible) geometry does not multiply its workspace by the frames around it, and in both cases only that
+    frame fails: its neighbours decode, the call succeeds."""
+    plain = L.natural_image_np(256, 16, 12, 12.0, 21)
+    pbuf = L.encode7(plain)
+    # (a) impossible: 32768 x 32764 coded pixels claimed by a 2 KB buffer
+    liar = pbuf.copy()
+    liar[0:4] = _u32(32768)
+    liar[4:8] = _u32(32764)
+    # (b) possible on paper: the same claim in a buffer long enough for that many (empty) side-stream records
+    nrec = (32768 * 32764 // 64 + 63) // 64
+    big = np.zeros(16 + 2 * (4 + 2 * nrec) + 64, np.uint8)
+    big[: pbuf.size] = pbuf
+    big[0:4] = _u32(32768)
+    big[4:8] = _u32(32764)
+    for bogus in (liar, big):
+        items = [pbuf] * 40 + [bogus] + [pbuf] * 40
+        outs, descs = [], []
+        for buf in items:
+            o = np.full(256 * 16 + 8, 0xA5A5, np.uint16)
+            outs.append(o)
+            descs.append((buf.ctypes.data, buf.size, 256, 16, 7, o.ctypes.data, 256 * 16))
+        written, status = gpu_ctx.decode_batch(M.Context.make_frames(descs), mem=M.MEM_HOST)
+        for i, (o, wr, st) in enumerate(zip(outs, written, status)):
+            if i == 40:
+                assert st != 0 and wr == 0, (bogus.size, hex(st), wr)
+            else:
+                assert st == 0 and wr == 256 * 16, (bogus.size, i, hex(st))
+                assert np.array_equal(o[: 256 * 16].reshape(16, 256), plain) and (o[256 * 16:] == 0xA5A5).all()

@@ -127,3 +127,85 @@ def test_failing_chunk_with_later_chunks_in_flight(tmp_path):
                            env=dict(os.environ, MCRAW_DEVICES=devs), cwd=str(tmp_path))
         assert r.returncode != 0
         assert "Failed to uncompress frame" in (r.stderr + r.stdout)
+
+
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+def test_pool_decodes_batches_that_are_resident_in_hbm(devices):
+    """BASELINE config 5's form: frame i lives in the HBM of the GPU that decodes it, devices[i % G]
+    (mcraw_pool_decode_batch_device); results as from host buffers, whatever the pool size."""
+    import torch
+    pool = M.Pool(devices)
+    try:
+        items = _batch(13)
+        devs = pool.devices()
+        ins, outs, descs = [], [], []
+        for i, (typ, img, buf) in enumerate(items):
+            dev = torch.device("cuda", devs[i % pool.size])
+            ti = torch.from_numpy(buf).to(dev)
+            to = torch.full((img.size * 2 + 16,), 0xA5, dtype=torch.uint8, device=dev)
+            ins.append(ti)
+            outs.append(to)
+            descs.append((ti.data_ptr(), ti.numel(), img.shape[1], img.shape[0], typ, to.data_ptr(), img.size))
+        torch.cuda.synchronize()
+        written, status = pool.decode_batch_device(M.Context.make_frames(descs))
+        assert status == [0] * len(items) and written == [it[1].size for it in items]
+        for (typ, img, buf), to in zip(items, outs):
+            a = to.cpu().numpy()
+            assert np.array_equal(a[: img.size * 2].view(np.uint16).reshape(img.shape), img) and (a[img.size * 2:] == 0xA5).all()
+    finally:
+        pool.close()
+
+
+def test_pool_serves_two_host_threads_at_once():
+    """One host thread allocates and frees staging memory on the members' threads while another keeps batches in
+    flight (synchronous and ticketed): every task runs, every batch is right, nothing deadlocks."""
+    import threading
+    pool = M.Pool([0, 0])
+    lib = M.load()
+    items = _batch(9)
+    errors, stop = [], threading.Event()
+
+    def alloc_loop():
+        try:
+            k = 0
+            while not stop.is_set():
+                p = pool.host_alloc(k % pool.size, 1 << 16)
+                assert p
+                C.memset(p, k & 255, 1 << 16)
+                lib.mcraw_host_free(p)
+                k += 1
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    th = threading.Thread(target=alloc_loop)
+    th.start()
+    try:
+        for rnd in range(12):
+            outs = [np.full(it[1].size + 8, 0xA5A5, np.uint16) for it in items]
+            descs = [(it[2].ctypes.data, it[2].size, it[1].shape[1], it[1].shape[0], it[0], o.ctypes.data, it[1].size)
+                     for it, o in zip(items, outs)]
+            frames = M.Context.make_frames(descs)
+            written, status = pool.wait(pool.decode_batch_async(frames)) if rnd % 2 else pool.decode_batch(frames)
+            assert status == [0] * len(items) and written == [it[1].size for it in items]
+            for it, o in zip(items, outs):
+                assert np.array_equal(o[: it[1].size].reshape(it[1].shape), it[1])
+    finally:
+        stop.set()
+        th.join(timeout=60)
+        alive = th.is_alive()
+        pool.close()
+    assert not alive and not errors, errors
+
+
+def test_pool_rejects_an_unknown_post_stage():
+    pool = M.Pool([0])
+    try:
+        p = M.Post()
+        p.flags = 0x40
+        assert M.load().mcraw_pool_set_post(pool._h, C.byref(p)) != 0
+        with pytest.raises(M.McrawError):
+            pool.set_post(bits=11)
+    except KeyError:
+        pass  # (the wrapper itself refuses a strip width the ABI does not know)
+    finally:
+        pool.close()
