@@ -64,10 +64,11 @@ def build_host(force=False):
     """C++ facade (motioncam::Decoder over the C ABI) and the export tool."""
     os.makedirs(LIB, exist_ok=True)
     out = os.path.join(LIB, "libmotioncam_decoder.so")
-    srcs = [os.path.join(HOST, f) for f in ("Decoder.cpp", "RawData.cpp")]
+    srcs = [os.path.join(HOST, f) for f in ("Decoder.cpp", "RawData.cpp", "Writer.cpp")]
     if not all(os.path.exists(s) for s in srcs):
         return None
-    hdrs = [os.path.join(HOST, "include", "motioncam", f) for f in ("Decoder.hpp", "Container.hpp", "RawData.hpp")]
+    hdrs = [os.path.join(HOST, "include", "motioncam", f) for f in ("Decoder.hpp", "Container.hpp", "RawData.hpp", "Writer.hpp",
+                                                                     "mcraw_container.h")]
     inc = ["-I" + os.path.join(HOST, "include"), "-I" + os.path.join(HOST, "thirdparty"), "-I" + os.path.join(ROOT, "include")]
     if force or _newer(out, srcs + hdrs):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall"] + inc + ["-o", out] + srcs +

@@ -315,6 +315,17 @@ void Decoder::loadAudio(std::vector<AudioChunk> &outAudioChunks)
 
 AudioChunkLoader &Decoder::loadAudio() const { return *mImpl->loader; }
 
+void Decoder::loadFramePayload(const Timestamp timestamp, std::vector<uint8_t> &outPayload, nlohmann::json &outMetadata)
+{
+    const FrameSpan span = mImpl->locate(timestamp);
+    if (span.payload + static_cast<int64_t>(span.payloadSize) > mImpl->reader.size())
+        throw IOException("Invalid offset");
+    outPayload.resize(span.payloadSize);
+    if (span.payloadSize)
+        mImpl->reader.readAt(span.payload, outPayload.data(), span.payloadSize);
+    outMetadata = readJson(mImpl->reader, span.json, span.jsonSize);
+}
+
 void Decoder::loadFrame(const Timestamp timestamp, std::vector<uint8_t> &outData, nlohmann::json &outMetadata)
 {
     // one-frame batch through the pinned staging of loadFrames (same checks, same error texts)

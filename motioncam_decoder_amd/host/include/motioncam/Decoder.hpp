@@ -94,6 +94,10 @@ public:
     // JSON of one frame without decoding it (width, height, compressionType ...: what sizes a buffer).
     void loadFrameMetadata(const Timestamp timestamp, nlohmann::json &outMetadata);
 
+    // The compressed frame buffer as it sits in the file (the BUFFER item, lib/Decoder.cpp:193-206), and its JSON:
+    // what a remux / trim tool hands to motioncam::Writer (Writer.hpp).  Host only, no GPU involved.
+    void loadFramePayload(const Timestamp timestamp, std::vector<uint8_t> &outPayload, nlohmann::json &outMetadata);
+
     // The same batch into memory the caller owns: frame i is written to outBuffers[i], which must hold
     // frameBytes(width, height, output) bytes.  The GPU pipeline downloads straight into these buffers (no
     // staging copy, no std::vector to fault in), so pinned memory is the fast choice: mcraw_host_alloc() /

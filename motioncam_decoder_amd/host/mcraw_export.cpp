@@ -1,6 +1,10 @@
 // mcraw_export -- decode a .mcraw file on the GPU and dump what it holds.
 //
 //   mcraw_export <file.mcraw> [-n frames] [-o outdir] [--single] [--no-write] [--black] [--bits 10|12|14|auto] [--pinned]
+//   mcraw_export <file.mcraw> --remux <out.mcraw> [-n frames] [--sorted-index] [--audio-inline] [--no-audio-index]
+//
+// --remux copies the first N frames (compressed as they are), their metadata and the audio into a new container
+// written by motioncam::Writer (host only, no GPU): a trim / repair tool, and the round trip of the build's own writer.
 //
 // Writes outdir/frame_%06d.u16 (width*height uint16 LE, row-major Bayer mosaic) for the
 // first N frames (by timestamp) and outdir/audio.s16 (interleaved PCM), and prints one line
@@ -11,6 +15,7 @@
 // decode (Decoder::FrameOutput).
 // --pinned decodes into pinned buffers this tool allocates (Decoder::loadFramesInto: no copy-out stage).
 #include <motioncam/Decoder.hpp>
+#include <motioncam/Writer.hpp>
 
 #include "mcraw_hip.h" // mcraw_host_alloc / mcraw_host_free for --pinned
 
@@ -57,7 +62,8 @@ int main(int argc, char **argv)
         std::cerr << "Usage: mcraw_export <input file> [-n frames] [-o outdir] [--single]" << std::endl;
         return 2;
     }
-    std::string input = argv[1], outdir = ".";
+    std::string input = argv[1], outdir = ".", remux;
+    motioncam::Writer::Options wopt;
     long limit = -1;
     bool single = false, nowrite = false, pinned = false;
     motioncam::Decoder::FrameOutput output;
@@ -66,6 +72,14 @@ int main(int argc, char **argv)
             limit = std::atol(argv[++i]);
         else if (!std::strcmp(argv[i], "-o") && i + 1 < argc)
             outdir = argv[++i];
+        else if (!std::strcmp(argv[i], "--remux") && i + 1 < argc)
+            remux = argv[++i];
+        else if (!std::strcmp(argv[i], "--sorted-index"))
+            wopt.indexInArrivalOrder = false;
+        else if (!std::strcmp(argv[i], "--audio-inline"))
+            wopt.audioBehindFrames = false;
+        else if (!std::strcmp(argv[i], "--no-audio-index"))
+            wopt.audioIndex = false;
         else if (!std::strcmp(argv[i], "--single"))
             single = true;
         else if (!std::strcmp(argv[i], "--no-write"))
@@ -90,6 +104,29 @@ int main(int argc, char **argv)
         std::cout << "Found " << frames.size() << " frames" << std::endl;
         if (limit >= 0 && static_cast<size_t>(limit) < frames.size())
             frames.resize(static_cast<size_t>(limit));
+
+        if (!remux.empty()) {
+            std::vector<motioncam::AudioChunk> chunks;
+            decoder.loadAudio(chunks);
+            motioncam::Writer writer(remux, decoder.getContainerMetadata(), wopt);
+            std::vector<uint8_t> payload;
+            nlohmann::json m;
+            size_t bytes = 0, a = 0;
+            for (size_t i = 0; i < frames.size(); i++) {
+                decoder.loadFramePayload(frames[i], payload, m);
+                writer.addFrame(frames[i], payload.data(), payload.size(), m);
+                bytes += payload.size();
+                // (--audio-inline: the chunks go between the frames, a few behind each)
+                for (; !wopt.audioBehindFrames && a < chunks.size() && a * frames.size() < (i + 1) * chunks.size(); a++)
+                    writer.addAudio(chunks[a].first, chunks[a].second.data(), chunks[a].second.size());
+            }
+            for (; a < chunks.size(); a++)
+                writer.addAudio(chunks[a].first, chunks[a].second.data(), chunks[a].second.size());
+            writer.finish();
+            std::cout << "remuxed " << frames.size() << " frames (" << bytes << " payload bytes), " << chunks.size()
+                      << " audio chunks -> " << remux << std::endl;
+            return 0;
+        }
 
         std::vector<motioncam::AudioChunk> audio;
         decoder.loadAudio(audio);

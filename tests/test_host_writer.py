@@ -1,0 +1,136 @@
+"""CPU: the build's native .mcraw writer (motioncam::Writer, host/Writer.cpp) against both readers.
+
+A clip written by the Python test helper is re-muxed by the C++ writer (mcraw_export --remux: reader -> Writer, no GPU)
+in every layout variant the writer offers -- index rows in arrival order or sorted, audio behind the frames or between
+them, with and without the audio index, trimmed to N frames.  For every variant:
+  * this build's Decoder (tests/cpp/facade_probe.cpp) reports the same frames, camera metadata and audio;
+  * the REFERENCE built from its own sources (oracle/_ref/example_ref, all-CPU) accepts the file and writes DNG / WAV
+    files identical to those it writes from the source clip (lib/Decoder.cpp:97-319 is the format's judge).
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import _libs as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "motioncam_decoder_amd", "lib")
+EXPORT = os.path.join(LIB, "mcraw_export")
+REFEX = os.path.join(ROOT, "oracle", "_ref", "example_ref")
+
+
+@pytest.fixture(scope="module")
+def tools(tmp_path_factory):
+    from motioncam_decoder_amd import build
+    build.build_hip()
+    build.build_host()
+    d = tmp_path_factory.mktemp("writer")
+    host = os.path.join(ROOT, "motioncam_decoder_amd", "host")
+    probe = str(d / "facade_probe")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I" + os.path.join(host, "include"), "-I" + os.path.join(host, "thirdparty"),
+                    "-o", probe, os.path.join(ROOT, "tests", "cpp", "facade_probe.cpp"), "-L" + LIB, "-lmotioncam_decoder",
+                    "-lmcraw_hip", "-Wl,-rpath," + LIB], check=True)
+    specs = [(3000, 7, 256, 32, 12, 12.0), (1000, 7, 320, 24, 10, 4.0), (2000, 6, 160, 20, 12, 12.0), (4000, 6, 100, 6, 14, 40.0)]
+    frames = []
+    for ts, typ, w, h, nb, sig in specs:
+        img = L.natural_image_np(w, h, nb, sig, ts)
+        frames.append((ts, typ, w, h, L.encode7(img) if typ == 7 else L.encode6(img)))
+    audio = [(111, np.arange(960, dtype=np.int16)), (None, (np.arange(960, dtype=np.int16) * 3).astype(np.int16)),
+             (333, (np.arange(960, dtype=np.int16) * 5).astype(np.int16))]
+    src = L.write_mcraw(str(d / "src.mcraw"), frames, audio)
+    return d, probe, src
+
+
+def _probe(probe, path):
+    r = subprocess.run([probe, path], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+def _reference_outputs(path, workdir, n=None):
+    os.makedirs(workdir, exist_ok=True)
+    r = subprocess.run([REFEX, path] + (["-n", str(n)] if n else []), cwd=workdir, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout, {name: open(os.path.join(workdir, name), "rb").read() for name in sorted(os.listdir(workdir))}
+
+
+VARIANTS = [[], ["--sorted-index"], ["--audio-inline"], ["--sorted-index", "--audio-inline"]]
+
+
+@pytest.mark.parametrize("variant", VARIANTS, ids=lambda v: "+".join(x.strip("-") for x in v) or "default")
+def test_written_container_reads_like_its_source(tools, variant, tmp_path):
+    d, probe, src = tools
+    out = str(tmp_path / "out.mcraw")
+    r = subprocess.run([EXPORT, src, "--remux", out] + variant, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "remuxed 4 frames" in r.stdout, r.stdout + r.stderr
+    assert open(out, "rb").read(8) == b"MOTION \x03"
+    want = _probe(probe, src)
+    assert "frames 1000 2000 3000 4000" in want and want.count("audio ") == 3
+    assert _probe(probe, out) == want
+    # writing it again from the written file changes nothing any more (the writer reads its own files)
+    out2 = str(tmp_path / "out2.mcraw")
+    subprocess.run([EXPORT, out, "--remux", out2] + variant, check=True, capture_output=True, timeout=120)
+    assert open(out2, "rb").read() == open(out, "rb").read()
+    if os.path.exists(REFEX):
+        so, sf = _reference_outputs(src, str(tmp_path / "ref_src"))
+        oo, of = _reference_outputs(out, str(tmp_path / "ref_out"))
+        assert so == oo and sorted(sf) == sorted(of) and len(sf) == 5  # four DNGs + audio.wav
+        for name in sf:
+            assert sf[name] == of[name], name
+
+
+def test_trimmed_and_audio_less_containers(tools, tmp_path):
+    d, probe, src = tools
+    out = str(tmp_path / "trim.mcraw")
+    r = subprocess.run([EXPORT, src, "--remux", out, "-n", "2"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "remuxed 2 frames" in r.stdout
+    assert "frames 1000 2000\n" in _probe(probe, out)
+    # no audio index: neither reader finds audio (the walk from the last frame ends at the frame index, lib/Decoder.cpp:281-315)
+    mute = str(tmp_path / "mute.mcraw")
+    subprocess.run([EXPORT, src, "--remux", mute, "--no-audio-index"], check=True, capture_output=True, timeout=120)
+    got = _probe(probe, mute)
+    assert "frames 1000 2000 3000 4000" in got and "audio " not in got and "loader 0" in got
+    if os.path.exists(REFEX):
+        so, sf = _reference_outputs(src, str(tmp_path / "ref_src"), n=2)
+        oo, of = _reference_outputs(out, str(tmp_path / "ref_out"), n=2)
+        for name in sf:
+            assert sf[name] == of[name], name
+        _, mf = _reference_outputs(mute, str(tmp_path / "ref_mute"))
+        assert [n for n in mf if n.endswith(".dng")] == [n for n in sf if n.endswith(".dng")] or len(mf) >= 4
+
+
+def test_writer_refuses_use_after_finish_and_oversized_chunks(tools, tmp_path):
+    d, probe, src = tools
+    code = r'''
+#include <motioncam/Decoder.hpp>
+#include <motioncam/Writer.hpp>
+#include <iostream>
+int main(int, char **argv) {
+    nlohmann::json cam = {{"extraData", {{"audioSampleRate", 48000}, {"audioChannels", 2}}}, {"sensorArrangment", "rggb"}};
+    motioncam::Writer w(argv[1], cam);
+    const uint8_t px[4] = {1, 2, 3, 4};
+    w.addFrame(5, px, sizeof(px), nlohmann::json{{"width", 1}, {"height", 1}, {"compressionType", 7}});
+    w.finish();
+    try { w.addFrame(6, px, sizeof(px), nlohmann::json::object()); std::cout << "no throw\n"; }
+    catch (const motioncam::IOException &e) { std::cout << "throws: " << e.what() << "\n"; }
+    std::cout << "frames " << w.frameCount() << "\n";
+    motioncam::Decoder d(argv[1]);
+    std::cout << "read " << d.getFrames().size() << " " << d.getFrames()[0] << "\n";
+    std::vector<uint8_t> payload; nlohmann::json m;
+    d.loadFramePayload(5, payload, m);
+    std::cout << "payload " << payload.size() << " " << int(payload[3]) << " " << m["compressionType"] << "\n";
+    return 0;
+}
+'''
+    srcf = tmp_path / "w.cpp"
+    srcf.write_text(code)
+    host = os.path.join(ROOT, "motioncam_decoder_amd", "host")
+    exe = str(tmp_path / "w")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I" + os.path.join(host, "include"), "-I" + os.path.join(host, "thirdparty"),
+                    "-o", exe, str(srcf), "-L" + LIB, "-lmotioncam_decoder", "-lmcraw_hip", "-Wl,-rpath," + LIB], check=True)
+    r = subprocess.run([exe, str(tmp_path / "one.mcraw")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "throws: Writer is finished" in r.stdout and "frames 1" in r.stdout
+    assert "read 1 5" in r.stdout and "payload 4 4 7" in r.stdout
