@@ -433,6 +433,16 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         W.Rmax = static_cast<uint32_t>(Rmax);
         W.n7 = n7;
         W.post = c->post;
+        // How k7_tiles' workgroups are dealt to the eight XCDs: runs of 128 workgroups = 2 MiB of output each, so that the
+        // eight write streams of a moment sit 2 MiB apart.  With the grid cut into eight parts instead (one per XCD, half a
+        // gigabyte apart) the same launch took 0.96 or 1.04 ms from one process to the next on one box -- the streams then
+        // meet on memory channels or not, as the physical pages fall; runs of 8 MiB are the slow case every time, runs of
+        // 2 MiB the fast one (0.97 ms, +- 0.5 %).  MCRAW_XCD_CHUNK overrides (0: eight parts, 1: blockIdx order).
+        static const uint32_t xcd_chunk = []() {
+            const char *e = std::getenv("MCRAW_XCD_CHUNK");
+            return e ? static_cast<uint32_t>(std::atoi(e)) : 128u;
+        }();
+        W.xcd_chunk = xcd_chunk;
         W.nclasses = nclasses;
         for (uint32_t k = 0; k <= nclasses; k++)
             W.class_first[k] = class_first[k];

@@ -79,6 +79,16 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n)
     return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + i;
 }
 
+// The same in chunks: every run of 8 * c consecutive logical items is dealt to the 8 XCDs in pieces of c (c = n / 8 is
+// xcd_remap, c = 1 the identity); the tail that does not fill a run keeps its order.  Bijective for any grid size.
+__device__ __forceinline__ uint32_t xcd_chunked(uint32_t b, uint32_t n, uint32_t c)
+{
+    const uint32_t group = 8u * c, g = b / group, r = b - g * group;
+    if ((g + 1u) * group > n)
+        return b;
+    return g * group + (r & 7u) * c + (r >> 3);
+}
+
 // Exclusive prefix sum over the 64 lanes (all lanes must be active) and the wave total.
 // DPP form (no LDS traffic): Hillis-Steele inside each 16-lane row with row_shr:1,2,4,8, then
 // row_bcast:15 / row_bcast:31 carry the row totals across (gfx9 DPP controls).

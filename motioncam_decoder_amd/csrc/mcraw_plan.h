@@ -93,6 +93,7 @@ struct Work7 {
     uint32_t nstatus;    // status words in front of the coded heights (2 * n7 + legacy frames + 1)
     int32_t n7;
     Post post;           // fused post-decode stage (mode 0: none)
+    uint32_t xcd_chunk;  // k7_tiles: logical items per XCD run (0: one run per XCD = the whole grid in eight parts)
     // k7_tiles is launched once per SIZE CLASS of the batch (plans are sorted by ngroups, descending):
     // frames [class_first[k], class_first[k+1]) get class_groups[k] decode groups each, so a batch that
     // mixes small and large frames does not pay the largest frame's grid for every frame

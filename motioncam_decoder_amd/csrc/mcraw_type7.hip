@@ -916,7 +916,7 @@ __global__ __launch_bounds__(256) void k7_tiles(const Work7 W, uint32_t total, u
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint32_t item = xcd_remap(blockIdx.x, gridDim.x) * 4u + wave;
+    const uint32_t item = (W.xcd_chunk ? xcd_chunked(blockIdx.x, gridDim.x, W.xcd_chunk) : xcd_remap(blockIdx.x, gridDim.x)) * 4u + wave;
     if (tid < 72u)
         s_tab[tid] = reinterpret_cast<const uint4 *>(c_tab7)[tid];
 
