@@ -131,6 +131,23 @@ struct mcraw_ctx {
     Post post{0, 0, 0};   // fused post-decode stage of the batches to come (mcraw_ctx_set_post)
     KStat kstat[MCRAW_K_COUNT];
     std::vector<hipEvent_t> event_pool;
+    // How k7_tiles' workgroups are dealt to the XCDs (Work7::xcd_chunk), chosen by measurement for large resident batches:
+    // which of the candidates is faster depends on where the caller's buffers lie in physical memory (see submit()), so
+    // the first launches on a new set of buffers try each candidate twice between events and the faster one stays.
+    struct Tune {
+        static constexpr int NC = 2;
+        const void *key_out = nullptr; // what the choice was made for: first output pointer, frames, groups
+        int key_n = 0;
+        uint32_t key_R = 0;
+        int issued[NC] = {0, 0}, done[NC] = {0, 0};
+        float best[NC] = {0.f, 0.f};
+        int decided = -1;
+        struct Pending {
+            hipEvent_t a, b;
+            int cand;
+        };
+        std::vector<Pending> pending;
+    } tune;
     // last device-memory batch, for mcraw_ctx_synchronize
     int last_slot = -1;
     int last_n = 0;
@@ -221,6 +238,66 @@ struct Layout { // byte offsets inside the slot arena / upload image
     size_t upload_bytes = 0;                             // tables end here, workspace follows
     size_t total = 0;
 };
+
+constexpr uint32_t TUNE_CHUNKS[mcraw_ctx::Tune::NC] = {128u, 0u};
+
+// Which candidate the next k7_tiles launch of a large resident batch runs with: -1 = the choice is made
+// (c->tune.decided), else the candidate to time.  Never blocks: finished event pairs are collected as they come.
+int tune_pick(mcraw_ctx *c, const void *out0, int n7, uint32_t R)
+{
+    mcraw_ctx::Tune &t = c->tune;
+    constexpr int NC = mcraw_ctx::Tune::NC, SAMPLES = 2;
+    if (t.key_out != out0 || t.key_n != n7 || t.key_R != R) { // another set of buffers: measure again
+        for (auto &p : t.pending) { // (their results belong to the old buffers)
+            (void)hipEventSynchronize(p.b);
+            c->event_pool.push_back(p.a);
+            c->event_pool.push_back(p.b);
+        }
+        t.pending.clear();
+        t.key_out = out0;
+        t.key_n = n7;
+        t.key_R = R;
+        t.decided = -1;
+        for (int k = 0; k < NC; k++)
+            t.issued[k] = t.done[k] = 0, t.best[k] = 0.f;
+    }
+    for (size_t i = 0; i < t.pending.size();) {
+        if (hipEventQuery(t.pending[i].b) != hipSuccess) {
+            (void)hipGetLastError(); // (hipErrorNotReady is no error)
+            i++;
+            continue;
+        }
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.pending[i].a, t.pending[i].b) == hipSuccess && ms > 0.f) {
+            const int k = t.pending[i].cand;
+            t.best[k] = t.done[k] ? std::min(t.best[k], ms) : ms;
+            t.done[k]++;
+        }
+        c->event_pool.push_back(t.pending[i].a);
+        c->event_pool.push_back(t.pending[i].b);
+        t.pending.erase(t.pending.begin() + static_cast<long>(i));
+    }
+    if (t.decided >= 0)
+        return -1;
+    bool all = true;
+    for (int k = 0; k < NC; k++)
+        all = all && t.done[k] >= SAMPLES;
+    if (all) {
+        t.decided = 0;
+        for (int k = 1; k < NC; k++)
+            if (t.best[k] < t.best[t.decided])
+                t.decided = k;
+        return -1;
+    }
+    int pick = -1;
+    for (int k = 0; k < NC; k++)
+        if (t.issued[k] < SAMPLES + 1 && (pick < 0 || t.issued[k] < t.issued[pick]))
+            pick = k;
+    if (pick < 0) // every candidate is issued, results still on their way: the caller runs with the first meanwhile
+        return -1;
+    t.issued[pick]++;
+    return pick;
+}
 
 int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::vector<Geom7> *geom_override,
            const uint8_t *const *dev_in, uint16_t *const *dev_out, hipStream_t st, size_t *status_off)
@@ -433,15 +510,25 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         W.Rmax = static_cast<uint32_t>(Rmax);
         W.n7 = n7;
         W.post = c->post;
-        // How k7_tiles' workgroups are dealt to the eight XCDs: runs of 128 workgroups = 2 MiB of output each, so that the
-        // eight write streams of a moment sit 2 MiB apart.  With the grid cut into eight parts instead (one per XCD, half a
-        // gigabyte apart) the same launch took 0.96 or 1.04 ms from one process to the next on one box -- the streams then
-        // meet on memory channels or not, as the physical pages fall; runs of 8 MiB are the slow case every time, runs of
-        // 2 MiB the fast one (0.97 ms, +- 0.5 %).  MCRAW_XCD_CHUNK overrides (0: eight parts, 1: blockIdx order).
-        static const uint32_t xcd_chunk = []() {
+        // How k7_tiles' workgroups are dealt to the eight XCDs: in runs of 128 workgroups (2 MiB of output: the eight write
+        // streams of a moment sit 2 MiB apart) or the grid in eight parts (one per XCD, a few hundred megabytes apart).
+        // Neither is the faster one everywhere: the same launch takes 0.96 - 1.04 ms with the one and 0.97 - 1.01 ms with
+        // the other, from box to box and -- for the eight parts -- from one process to the next on one box: the streams
+        // meet on memory channels or not, as the physical pages of the caller's buffers fall (runs of 8 MiB are the slow
+        // case every time).  So large resident batches measure: the first launches on a new set of buffers take turns
+        // between events, then the faster candidate stays (tune_pick).  MCRAW_XCD_CHUNK pins the choice (0: eight parts,
+        // 1: blockIdx order, n: runs of n).
+        static const int xcd_env = []() {
             const char *e = std::getenv("MCRAW_XCD_CHUNK");
-            return e ? static_cast<uint32_t>(std::atoi(e)) : 128u;
+            return e ? std::atoi(e) : -1;
         }();
+        const bool tunable = xcd_env < 0 && !dev_in && !geom_override && n7 >= 32;
+        int tune_cand = -1;
+        uint32_t xcd_chunk = xcd_env >= 0 ? static_cast<uint32_t>(xcd_env) : 128u;
+        if (tunable) {
+            tune_cand = tune_pick(c, B.p7[0].out, n7, static_cast<uint32_t>(Rmax));
+            xcd_chunk = TUNE_CHUNKS[tune_cand >= 0 ? tune_cand : std::max(c->tune.decided, 0)];
+        }
         W.xcd_chunk = xcd_chunk;
         W.nclasses = nclasses;
         for (uint32_t k = 0; k <= nclasses; k++)
@@ -449,8 +536,21 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         for (uint32_t k = 0; k < nclasses; k++)
             W.class_groups[k] = class_groups[k];
         for (uint32_t stage : {MCRAW_K7_SIDE, MCRAW_K7_TILES}) {
-            KTimer t(c, static_cast<int>(stage), st);
-            launch_k7(W, stage, st);
+            hipEvent_t ta = nullptr, tb = nullptr;
+            if (stage == MCRAW_K7_TILES && tune_cand >= 0) {
+                ta = get_event(c);
+                tb = get_event(c);
+                if (ta && tb)
+                    (void)hipEventRecord(ta, st);
+            }
+            {
+                KTimer t(c, static_cast<int>(stage), st);
+                launch_k7(W, stage, st);
+            }
+            if (ta && tb) {
+                (void)hipEventRecord(tb, st);
+                c->tune.pending.push_back({ta, tb, tune_cand});
+            }
         }
     }
     if (n6) {
@@ -1072,6 +1172,10 @@ void mcraw_ctx_destroy(mcraw_ctx *c)
             (void)hipEventDestroy(p.first);
             (void)hipEventDestroy(p.second);
         }
+    for (auto &p : c->tune.pending) {
+        (void)hipEventDestroy(p.a);
+        (void)hipEventDestroy(p.b);
+    }
     for (hipEvent_t e : c->event_pool)
         (void)hipEventDestroy(e);
     if (c->stream)
