@@ -546,18 +546,20 @@ def legacy_leg(torch, ctx, M, L, dev, n=32, w=4000, h=3000, nbits=12, sigma=12.0
            "mpix_s": round(n * w * h / t / 1e6, 1), "in_plus_out_GBs": round(byts / t / 1e9, 1),
            "input_bpp": round(8.0 * bufs[0].size / (w * h), 2), "kernels_ms": kms, "bit_exact": bool(ok)}
     # the same roofline figures as for the bench line: the batch (wall) and its one kernel against the HBM peak, and the
-    # HBM traffic of that kernel from the committed counter passes (tools/pmc_legacy.sh; not measured in this run)
+    # HBM traffic of that kernel from the committed counter passes (tools/profile_r03.sh; not measured in this run)
     out["step_frac"] = round(byts / t / 1e9 / 8000.0, 4)
+    out["algorithmic_bytes_per_batch"] = byts
     if kms["k6_decode"] > 0:
         out["frac"] = round(byts / (kms["k6_decode"] * 1e-3) / 1e9 / 8000.0, 4)
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_legacy_traffic.json")) as f:
-            tj = json.load(f)
-        out["traffic"] = tj["total_bytes_per_batch"]
-        out["algorithmic_bytes_per_batch"] = byts
-        out["traffic_source"] = "profiles/r02_legacy_traffic.json (rocprofv3 --pmc passes of tools/bench_legacy.py, committed; not measured in this run)"
-    except Exception:
-        pass
+    for tag in ("r03", "r02"):
+        try:
+            with open(os.path.join(ROOT, "profiles", tag + "_legacy_traffic.json")) as f:
+                tj = json.load(f)
+            out["traffic"] = tj["total_bytes_per_batch"]
+            out["traffic_source"] = ("profiles/%s_legacy_traffic.json (rocprofv3 --pmc passes, committed; not measured in this run)" % tag)
+            break
+        except Exception:
+            continue
     return out
 
 
@@ -752,10 +754,15 @@ def main():
                                   "note": "torch fill / copy of 1 GiB in this process, before and after the timed rounds: this box's own HBM yardstick"}
         for d in dists[1:]:
             s2 = summarize(results[d])
+            key2 = "%dx%d_%dbit_%d_%s" % (args.width, args.height, args.nbits, args.frames, d)
             out["also_" + d] = {"mpix_s": round(s2["mpix_s"], 1), "ms_per_step": round(s2["st"]["median"], 4),
                                 "input_bpp": round(s2["bpp"], 2), "achieved_gbs": round(s2["achieved_gbs"], 1),
                                 "frac": round(s2["achieved_gbs"] / HBM_PEAK_GBS, 4),
-                                "step_frac": round(s2["step_gbs"] / HBM_PEAK_GBS, 4), "bit_exact": results[d]["ok"]}
+                                "step_frac": round(s2["step_gbs"] / HBM_PEAK_GBS, 4),
+                                "algorithmic_bytes_per_launch": round(s2["bytes_per_launch"]), "avg_launch_ms": round(s2["tiles_ms_per_launch"], 4),
+                                "traffic": traffic_from_profile(key2),
+                                "kernels_ms_per_step": {k: round(v, 4) for k, v in s2["kernels_ms_per_step"].items()},
+                                "bit_exact": results[d]["ok"]}
         out.update(extra)
         if world == 1 and not args.no_cpu:
             try:
