@@ -176,6 +176,12 @@ int mcraw_ctx_profile(mcraw_ctx *ctx, int enable);
  * several microseconds, a sample of the launches gives the same average duration. */
 int mcraw_ctx_profile_every(mcraw_ctx *ctx, int n);
 int mcraw_ctx_kernel_ms(mcraw_ctx *ctx, int id, double *ms, int *launches, int reset);
+/* How the tile kernel's workgroups are dealt to the GPU's eight XCDs for large resident batches: the library measures two
+ * mappings on the first launches on a new set of buffers (which one is faster depends on where those buffers lie in
+ * physical memory) and keeps the faster.  Returns the choice made for the current buffers: the length of the runs in
+ * workgroups (0: the grid in eight parts), -1 while it is still measuring or nothing was measured (small or host-memory
+ * batches use runs of 128).  Environment MCRAW_XCD_CHUNK pins the mapping (then always -1 here). */
+int mcraw_ctx_xcd_runs(mcraw_ctx *ctx);
 
 /* Optional stage fused behind the decode, for consumers that take the mosaic further on the
  * device or ship it as a DNG strip (what example.cpp:80-92 hands to the DNG writer: the raw strip,

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "mcraw_ctx_profile_every", "mcraw_legacy_launch_order", "mcraw_shard_of", "mcraw_shard_count", "mcraw_pool_create", "mcraw_pool_destroy", "mcraw_pool_last_error",
     "mcraw_pool_size", "mcraw_pool_device", "mcraw_pool_numa_cpus", "mcraw_pool_ctx", "mcraw_pool_set_post",
     "mcraw_pool_host_alloc", "mcraw_pool_decode_batch", "mcraw_pool_decode_batch_async", "mcraw_pool_ticket_wait",
-    "mcraw_pool_decode_batch_device",
+    "mcraw_pool_decode_batch_device", "mcraw_ctx_xcd_runs",
 ]
 
 POST_BLACK, POST_PACK12, POST_PACK10, POST_PACK14 = 1, 2, 4, 8
@@ -144,6 +144,8 @@ def load():
     lib.mcraw_pool_host_alloc.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
     lib.mcraw_pool_decode_batch.restype = C.c_int
     lib.mcraw_pool_decode_batch.argtypes = [C.c_void_p, C.POINTER(Frame), C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
+    lib.mcraw_ctx_xcd_runs.restype = C.c_int
+    lib.mcraw_ctx_xcd_runs.argtypes = [C.c_void_p]
     lib.mcraw_pool_decode_batch_device.restype = C.c_int
     lib.mcraw_pool_decode_batch_device.argtypes = [C.c_void_p, C.POINTER(Frame), C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
     lib.mcraw_pool_decode_batch_async.restype = C.c_int
@@ -254,6 +256,10 @@ class Context:
         if rc != 0 or not h.value:
             raise McrawError("mcraw_ctx_create failed (%d): %s" % (rc, self._lib.mcraw_last_error().decode()))
         self._h = h
+
+    def xcd_runs(self):
+        """The XCD mapping the library chose for the current large resident batches (mcraw_ctx_xcd_runs)."""
+        return self._lib.mcraw_ctx_xcd_runs(self._h)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -1355,6 +1355,14 @@ int mcraw_ctx_profile(mcraw_ctx *c, int enable)
     return 0;
 }
 
+int mcraw_ctx_xcd_runs(mcraw_ctx *c)
+{
+    if (!c)
+        return -2;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return c->tune.decided >= 0 ? static_cast<int>(TUNE_CHUNKS[c->tune.decided]) : -1;
+}
+
 int mcraw_ctx_profile_every(mcraw_ctx *c, int n)
 {
     if (!c || n < 1)
