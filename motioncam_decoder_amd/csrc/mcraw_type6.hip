@@ -44,7 +44,11 @@ __device__ __forceinline__ uint32_t stride4(uint32_t hdr4)
 // complete in itself, so publishing one is a single relaxed store at device scope and needs no fence.
 constexpr uint32_t RES_AGG = 1u, RES_PREFIX = 2u; // Look6::res payload: state << 30 | records << 5 | exit phase
 constexpr uint32_t EX_PHASE = 1u, EX_MAP = 2u;    // Look6::ex payload: kind << 30 | exit phase (kind 1)
+#ifdef MCRAW_INJECT_LOST // test builds (tests/test_gpu_lookback_fault.py): segment 3 of the batch's first legacy frame never publishes
+constexpr uint32_t SPIN6 = 1u << 12;
+#else
 constexpr uint32_t SPIN6 = 1u << 20;              // polls before a workgroup gives the frame up (never seen; a hang is worse)
+#endif
 
 __device__ __forceinline__ void look_put(uint64_t *w, uint32_t epoch, uint32_t v)
 {
@@ -539,7 +543,11 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         // first record index: records of the frame's earlier segments, 64 of them per poll
         uint32_t base = 0;
         if (seg) {
+#ifdef MCRAW_INJECT_LOST
+            if (lane == 0 && !(f == 0u && seg == 3u))
+#else
             if (lane == 0)
+#endif
                 look_put(res, epoch, (RES_AGG << 30) | (total << 5) | lastp);
             int32_t jn = static_cast<int32_t>(seg) - 1; // nearest segment of the window (lane 0)
             while (!lost) {
@@ -576,7 +584,11 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         // entries carry the record index in 24 bits: a stream with more records than that (the frame itself has
         // fewer, the host checks) saturates instead of wrapping back into the frame
         const uint32_t endn = min(base + total, 0xFFFFFFu);
+#ifdef MCRAW_INJECT_LOST
+        if (lane == 0 && !(f == 0u && seg == 3u))
+#else
         if (lane == 0)
+#endif
             look_put(res, epoch, (RES_PREFIX << 30) | (endn << 5) | (lost ? DEAD : lastp));
         const uint32_t qi = min(base + qfirst, 0xFFFFFFu); // index of my quarter's first record
         s_ent4[lane] = qp | (qi << 8);
