@@ -147,7 +147,10 @@ struct mcraw_ctx {
             int cand;
         };
         std::vector<Pending> pending;
-    } tune;
+        unsigned long long used = 0; // (least recently used entry is replaced)
+    } tunes[4]; // a few buffer sets at a time: a caller that alternates between two sets of frame buffers keeps both choices
+    unsigned long long tune_clock = 0;
+    int tune_last = -1; // entry of the last tunable batch (mcraw_ctx_xcd_runs)
     // last device-memory batch, for mcraw_ctx_synchronize
     int last_slot = -1;
     int last_n = 0;
@@ -242,12 +245,20 @@ struct Layout { // byte offsets inside the slot arena / upload image
 constexpr uint32_t TUNE_CHUNKS[mcraw_ctx::Tune::NC] = {128u, 0u};
 
 // Which candidate the next k7_tiles launch of a large resident batch runs with: -1 = the choice is made
-// (c->tune.decided), else the candidate to time.  Never blocks: finished event pairs are collected as they come.
+// (the entry's `decided`), else the candidate to time.  Never blocks: finished event pairs are collected as they come.
 int tune_pick(mcraw_ctx *c, const void *out0, int n7, uint32_t R)
 {
-    mcraw_ctx::Tune &t = c->tune;
-    constexpr int NC = mcraw_ctx::Tune::NC, SAMPLES = 2;
-    if (t.key_out != out0 || t.key_n != n7 || t.key_R != R) { // another set of buffers: measure again
+    constexpr int NC = mcraw_ctx::Tune::NC, SAMPLES = 2, NT = static_cast<int>(sizeof(c->tunes) / sizeof(c->tunes[0]));
+    int e = -1, lru = 0;
+    for (int i = 0; i < NT; i++) {
+        if (c->tunes[i].key_out == out0 && c->tunes[i].key_n == n7 && c->tunes[i].key_R == R)
+            e = i;
+        if (c->tunes[i].used < c->tunes[lru].used)
+            lru = i;
+    }
+    if (e < 0) { // another set of buffers: measure again, in the entry that was not used for the longest time
+        e = lru;
+        mcraw_ctx::Tune &t = c->tunes[e];
         for (auto &p : t.pending) { // (their results belong to the old buffers)
             (void)hipEventSynchronize(p.b);
             c->event_pool.push_back(p.a);
@@ -261,6 +272,9 @@ int tune_pick(mcraw_ctx *c, const void *out0, int n7, uint32_t R)
         for (int k = 0; k < NC; k++)
             t.issued[k] = t.done[k] = 0, t.best[k] = 0.f;
     }
+    mcraw_ctx::Tune &t = c->tunes[e];
+    t.used = ++c->tune_clock;
+    c->tune_last = e;
     for (size_t i = 0; i < t.pending.size();) {
         if (hipEventQuery(t.pending[i].b) != hipSuccess) {
             (void)hipGetLastError(); // (hipErrorNotReady is no error)
@@ -527,7 +541,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         uint32_t xcd_chunk = xcd_env >= 0 ? static_cast<uint32_t>(xcd_env) : 128u;
         if (tunable) {
             tune_cand = tune_pick(c, B.p7[0].out, n7, static_cast<uint32_t>(Rmax));
-            xcd_chunk = TUNE_CHUNKS[tune_cand >= 0 ? tune_cand : std::max(c->tune.decided, 0)];
+            xcd_chunk = TUNE_CHUNKS[tune_cand >= 0 ? tune_cand : std::max(c->tunes[c->tune_last].decided, 0)];
         }
         W.xcd_chunk = xcd_chunk;
         W.nclasses = nclasses;
@@ -549,7 +563,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
             }
             if (ta && tb) {
                 (void)hipEventRecord(tb, st);
-                c->tune.pending.push_back({ta, tb, tune_cand});
+                c->tunes[c->tune_last].pending.push_back({ta, tb, tune_cand});
             }
         }
     }
@@ -1172,10 +1186,11 @@ void mcraw_ctx_destroy(mcraw_ctx *c)
             (void)hipEventDestroy(p.first);
             (void)hipEventDestroy(p.second);
         }
-    for (auto &p : c->tune.pending) {
-        (void)hipEventDestroy(p.a);
-        (void)hipEventDestroy(p.b);
-    }
+    for (auto &t : c->tunes)
+        for (auto &p : t.pending) {
+            (void)hipEventDestroy(p.a);
+            (void)hipEventDestroy(p.b);
+        }
     for (hipEvent_t e : c->event_pool)
         (void)hipEventDestroy(e);
     if (c->stream)
@@ -1360,7 +1375,7 @@ int mcraw_ctx_xcd_runs(mcraw_ctx *c)
     if (!c)
         return -2;
     std::lock_guard<std::mutex> lk(c->mu);
-    return c->tune.decided >= 0 ? static_cast<int>(TUNE_CHUNKS[c->tune.decided]) : -1;
+    return c->tune_last >= 0 && c->tunes[c->tune_last].decided >= 0 ? static_cast<int>(TUNE_CHUNKS[c->tunes[c->tune_last].decided]) : -1;
 }
 
 int mcraw_ctx_profile_every(mcraw_ctx *c, int n)

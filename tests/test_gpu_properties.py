@@ -172,3 +172,40 @@ def test_bench_multi_rank_path_on_one_gpu(tmp_path):
     assert d["roofline"]["step_frac"] > 0 and d["roofline"]["frac"] > 0
     p = d["pcie_inclusive"]
     assert p["bit_exact"] is True and p["frames_per_rank"] == 24 and abs(p["frames_per_s"] - 2 * p["frames_per_s_per_rank"]) < 1.0
+
+
+def test_xcd_mapping_is_measured_per_buffer_set_and_kept(gpu_ctx):
+    """Large resident batches: the library times two mappings of the tile kernel's workgroups on the first launches on a
+    new set of buffers and keeps the faster (mcraw_ctx_xcd_runs).  A caller that alternates between two sets of frame
+    buffers (double buffering) gets a choice for each, once; every launch on the way is bit-exact whatever it ran with."""
+    import torch
+    import motioncam_decoder_amd as M
+    dev = torch.device("cuda:0")
+    imgs = [L.natural_image_np(256, 32, 12, 12.0, 7700 + i) for i in range(40)]
+    bufs = [L.encode7(im) for im in imgs]
+    tin = [torch.from_numpy(b).to(dev) for b in bufs]
+    sets = []
+    for k in range(2):
+        touts = [torch.zeros(im.size * 2, dtype=torch.uint8, device=dev) for im in imgs]
+        frames = M.Context.make_frames([(tin[i].data_ptr(), tin[i].numel(), 256, 32, 7, touts[i].data_ptr(), imgs[i].size)
+                                        for i in range(len(imgs))])
+        sets.append((touts, frames))
+    seen = [set(), set()]
+    for rnd in range(16):
+        k = rnd & 1
+        touts, frames = sets[k]
+        for t in touts:
+            t.zero_()
+        written, status = gpu_ctx.decode_batch(frames)
+        assert all(s == 0 for s in status)
+        for im, t in zip(imgs, touts):
+            assert np.array_equal(t.cpu().numpy().view(np.uint16).reshape(im.shape), im), rnd
+        seen[k].add(gpu_ctx.xcd_runs())
+    last = [None, None]
+    for rnd in range(4):  # the choices are made by now and stay
+        k = rnd & 1
+        gpu_ctx.decode_batch(sets[k][1])
+        r = gpu_ctx.xcd_runs()
+        assert r in (0, 128), r
+        assert last[k] in (None, r)
+        last[k] = r
