@@ -478,6 +478,17 @@ def pool_leg(torch, M, L, wl, devices, link=None, nframes=240, reps=2):
         res["resident"] = {"frames": n, "ms_per_batch": round(t * 1e3, 4), "frames_per_s": round(n / t, 1),
                            "mpix_s": round(n * wl.w * wl.h / t / 1e6, 1), "bit_exact": bool(ok),
                            "note": "synchronous call: host hand-off, kernels and status read-back of every member"}
+        # the same batches queued back to back (no status asked for), one mcraw_pool_synchronize behind them
+        for _ in range(8):
+            pool.decode_batch_device(frames, want_status=False)
+        st = pool.synchronize(n)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            pool.decode_batch_device(frames, want_status=False)
+        st = pool.synchronize(n)
+        t = (time.perf_counter() - t0) / 20
+        res["resident_queued"] = {"frames": n, "ms_per_batch": round(t * 1e3, 4), "frames_per_s": round(n / t, 1),
+                                  "mpix_s": round(n * wl.w * wl.h / t / 1e6, 1), "bit_exact": bool(ok and all(x == 0 for x in st))}
     finally:
         pool.close()
     return res

@@ -139,9 +139,13 @@ void *mcraw_pool_host_alloc(mcraw_pool *pool, int member, size_t bytes);
 int mcraw_pool_decode_batch(mcraw_pool *pool, const mcraw_frame *frames, int nframes, size_t *written, int32_t *status);
 /* The same for buffers that are already resident: frames[i].in / .out are device pointers in the HBM of the GPU that
  * decodes frame i, mcraw_pool_device(pool, i % mcraw_pool_size(pool)) -- BASELINE config 5's form (a clip sharded over
- * the node's GPUs by frame index; lib/Decoder.cpp:184-235 run as one batch).  Synchronous: returns when every member's
- * share is decoded. */
+ * the node's GPUs by frame index; lib/Decoder.cpp:184-235 run as one batch).  With `written` or `status` it returns when
+ * every member's share is decoded. */
 int mcraw_pool_decode_batch_device(mcraw_pool *pool, const mcraw_frame *frames, int nframes, size_t *written, int32_t *status);
+/* With `written` and `status` both NULL the call above only queues every member's share (each on its context's own stream)
+ * and returns; mcraw_pool_synchronize waits for everything the members have queued and fetches the statuses of the last
+ * resident batch (status may be NULL) -- several batches in a row then run back to back on every GPU. */
+int mcraw_pool_synchronize(mcraw_pool *pool, int32_t *status, int nframes);
 int mcraw_pool_decode_batch_async(mcraw_pool *pool, const mcraw_frame *frames, int nframes, mcraw_pool_ticket **ticket);
 int mcraw_pool_ticket_wait(mcraw_pool_ticket *ticket, size_t *written, int32_t *status);
 

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "mcraw_ctx_profile_every", "mcraw_legacy_launch_order", "mcraw_shard_of", "mcraw_shard_count", "mcraw_pool_create", "mcraw_pool_destroy", "mcraw_pool_last_error",
     "mcraw_pool_size", "mcraw_pool_device", "mcraw_pool_numa_cpus", "mcraw_pool_ctx", "mcraw_pool_set_post",
     "mcraw_pool_host_alloc", "mcraw_pool_decode_batch", "mcraw_pool_decode_batch_async", "mcraw_pool_ticket_wait",
-    "mcraw_pool_decode_batch_device", "mcraw_ctx_xcd_runs",
+    "mcraw_pool_decode_batch_device", "mcraw_ctx_xcd_runs", "mcraw_pool_synchronize",
 ]
 
 POST_BLACK, POST_PACK12, POST_PACK10, POST_PACK14 = 1, 2, 4, 8
@@ -144,6 +144,8 @@ def load():
     lib.mcraw_pool_host_alloc.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
     lib.mcraw_pool_decode_batch.restype = C.c_int
     lib.mcraw_pool_decode_batch.argtypes = [C.c_void_p, C.POINTER(Frame), C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
+    lib.mcraw_pool_synchronize.restype = C.c_int
+    lib.mcraw_pool_synchronize.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
     lib.mcraw_ctx_xcd_runs.restype = C.c_int
     lib.mcraw_ctx_xcd_runs.argtypes = [C.c_void_p]
     lib.mcraw_pool_decode_batch_device.restype = C.c_int
@@ -208,16 +210,24 @@ class Pool:
         if rc != 0:  # (a rejected stage must not decode plain mosaics silently)
             raise McrawError("mcraw_pool_set_post failed (%d): %s" % (rc, self._lib.mcraw_last_error().decode()))
 
-    def decode_batch_device(self, frames):
+    def decode_batch_device(self, frames, want_status=True):
         """frames: ctypes array from Context.make_frames whose in / out pointers live in the HBM of the GPU that decodes
-        the frame: frame i on ``devices()[i % size]``.  Returns (written, status)."""
+        the frame: frame i on ``devices()[i % size]``.  Returns (written, status); with want_status=False the members
+        only queue their shares (synchronize() waits and returns the statuses)."""
         n = len(frames)
         written = (C.c_size_t * max(n, 1))()
         status = (C.c_int32 * max(n, 1))()
-        rc = self._lib.mcraw_pool_decode_batch_device(self._h, frames, n, written, status)
+        rc = self._lib.mcraw_pool_decode_batch_device(self._h, frames, n, written if want_status else None, status if want_status else None)
         if rc != 0:
             raise McrawError("mcraw_pool_decode_batch_device failed (%d): %s" % (rc, self._lib.mcraw_pool_last_error().decode()))
-        return list(written)[:n], list(status)[:n]
+        return (list(written)[:n], list(status)[:n]) if want_status else None
+
+    def synchronize(self, n):
+        status = (C.c_int32 * max(n, 1))()
+        rc = self._lib.mcraw_pool_synchronize(self._h, status, n)
+        if rc != 0:
+            raise McrawError("mcraw_pool_synchronize failed (%d): %s" % (rc, self._lib.mcraw_pool_last_error().decode()))
+        return list(status)[:n]
 
     def decode_batch(self, frames):
         """frames: ctypes array from Context.make_frames (host pointers).  Returns (written, status)."""

@@ -155,6 +155,8 @@ thread_local std::string g_pool_err;
 struct mcraw_pool {
     std::vector<Member *> members;
     std::mutex mu; // one batch at a time
+    std::vector<std::vector<int>> last_device_index; // per member: caller's indices of its frames in the last resident batch
+    int last_device_n = 0;
 };
 
 // A sharded batch in flight.
@@ -435,8 +437,11 @@ int mcraw_pool_decode_batch_device(mcraw_pool *p, const mcraw_frame *frames, int
     std::vector<int> rcs(G, 0);
     std::vector<std::string> errs(G);
     std::vector<uint64_t> seq(G, 0);
+    const bool async = !written && !status; // nobody asks: the members only queue their shares (mcraw_pool_synchronize waits)
     {
         std::lock_guard<std::mutex> lk(p->mu);
+        p->last_device_index = index;
+        p->last_device_n = nframes;
         for (int m = 0; m < G; m++) {
             wr[m].assign(sub[m].size(), 0);
             st[m].assign(sub[m].size(), 0);
@@ -445,7 +450,7 @@ int mcraw_pool_decode_batch_device(mcraw_pool *p, const mcraw_frame *frames, int
                 if (sub[m].empty())
                     return;
                 rcs[m] = mcraw_decode_batch(mem->ctx, sub[m].data(), static_cast<int>(sub[m].size()), MCRAW_MEM_DEVICE, nullptr,
-                                            wr[m].data(), st[m].data());
+                                            async ? nullptr : wr[m].data(), async ? nullptr : st[m].data());
                 if (rcs[m] != 0)
                     errs[m] = mcraw_last_error();
             });
@@ -464,6 +469,45 @@ int mcraw_pool_decode_batch_device(mcraw_pool *p, const mcraw_frame *frames, int
             if (status)
                 status[index[m][k]] = st[m][k];
         }
+    }
+    return rc;
+}
+
+int mcraw_pool_synchronize(mcraw_pool *p, int32_t *status, int nframes)
+{
+    if (!p)
+        return -1;
+    const int G = static_cast<int>(p->members.size());
+    std::vector<std::vector<int>> index;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        index = p->last_device_index;
+    }
+    index.resize(G);
+    std::vector<std::vector<int32_t>> st(G);
+    std::vector<int> rcs(G, 0);
+    std::vector<std::string> errs(G);
+    std::vector<uint64_t> seq(G, 0);
+    for (int m = 0; m < G; m++) {
+        st[m].assign(index[m].size(), 0);
+        Member *mem = p->members[m];
+        seq[m] = mem->run([&, m, mem] {
+            rcs[m] = mcraw_ctx_synchronize(mem->ctx, st[m].empty() ? nullptr : st[m].data(), static_cast<int>(st[m].size()));
+            if (rcs[m] != 0)
+                errs[m] = mcraw_last_error();
+        });
+    }
+    int rc = 0;
+    for (int m = 0; m < G; m++) {
+        p->members[m]->wait(seq[m]);
+        if (rcs[m] != 0 && rc == 0) {
+            rc = rcs[m];
+            g_pool_err = errs[m];
+        }
+        if (status)
+            for (size_t k = 0; k < index[m].size(); k++)
+                if (index[m][k] < nframes)
+                    status[index[m][k]] = st[m][k];
     }
     return rc;
 }

@@ -147,11 +147,20 @@ def test_pool_decodes_batches_that_are_resident_in_hbm(devices):
             outs.append(to)
             descs.append((ti.data_ptr(), ti.numel(), img.shape[1], img.shape[0], typ, to.data_ptr(), img.size))
         torch.cuda.synchronize()
-        written, status = pool.decode_batch_device(M.Context.make_frames(descs))
+        frames = M.Context.make_frames(descs)
+        written, status = pool.decode_batch_device(frames)
         assert status == [0] * len(items) and written == [it[1].size for it in items]
         for (typ, img, buf), to in zip(items, outs):
             a = to.cpu().numpy()
             assert np.array_equal(a[: img.size * 2].view(np.uint16).reshape(img.shape), img) and (a[img.size * 2:] == 0xA5).all()
+        # queued form: nobody asks for statuses, the members' shares run back to back; one synchronize behind three batches
+        for to in outs:
+            to.zero_()
+        for _ in range(3):
+            assert pool.decode_batch_device(frames, want_status=False) is None
+        assert pool.synchronize(len(items)) == [0] * len(items)
+        for (typ, img, buf), to in zip(items, outs):
+            assert np.array_equal(to.cpu().numpy()[: img.size * 2].view(np.uint16).reshape(img.shape), img)
     finally:
         pool.close()
 
