@@ -159,6 +159,11 @@ int mcraw_pool_ticket_wait(mcraw_pool_ticket *ticket, size_t *written, int32_t *
  * tab[n + 1 + t] + (b - tab[t]) / (n - t). */
 void mcraw_legacy_launch_order(const uint32_t *nseg, int n, uint32_t *tab);
 
+/* The order the tile kernel's workgroups take their work in: block `b` of a grid of `n` blocks works on logical workgroup
+ * mcraw_tile_order(b, n, runs) -- runs of `runs` consecutive workgroups per XCD (0: the grid in eight parts; see
+ * mcraw_ctx_xcd_runs).  A permutation of 0..n-1 for every n and runs; exported so that this can be checked without a GPU. */
+uint32_t mcraw_tile_order(uint32_t b, uint32_t n, uint32_t runs);
+
 /* ---- measurement -------------------------------------------------------- */
 
 /* Kernel ids for mcraw_ctx_kernel_ms. */

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "mcraw_ctx_profile_every", "mcraw_legacy_launch_order", "mcraw_shard_of", "mcraw_shard_count", "mcraw_pool_create", "mcraw_pool_destroy", "mcraw_pool_last_error",
     "mcraw_pool_size", "mcraw_pool_device", "mcraw_pool_numa_cpus", "mcraw_pool_ctx", "mcraw_pool_set_post",
     "mcraw_pool_host_alloc", "mcraw_pool_decode_batch", "mcraw_pool_decode_batch_async", "mcraw_pool_ticket_wait",
-    "mcraw_pool_decode_batch_device", "mcraw_ctx_xcd_runs", "mcraw_pool_synchronize",
+    "mcraw_pool_decode_batch_device", "mcraw_ctx_xcd_runs", "mcraw_pool_synchronize", "mcraw_tile_order",
 ]
 
 POST_BLACK, POST_PACK12, POST_PACK10, POST_PACK14 = 1, 2, 4, 8
@@ -144,6 +144,8 @@ def load():
     lib.mcraw_pool_host_alloc.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
     lib.mcraw_pool_decode_batch.restype = C.c_int
     lib.mcraw_pool_decode_batch.argtypes = [C.c_void_p, C.POINTER(Frame), C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
+    lib.mcraw_tile_order.restype = C.c_uint32
+    lib.mcraw_tile_order.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
     lib.mcraw_pool_synchronize.restype = C.c_int
     lib.mcraw_pool_synchronize.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
     lib.mcraw_ctx_xcd_runs.restype = C.c_int

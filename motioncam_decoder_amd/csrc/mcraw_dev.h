@@ -73,7 +73,7 @@ __device__ __forceinline__ int find_frame(uint32_t item, const uint32_t *__restr
 
 // Consecutive logical work items on one XCD: workgroups are dealt round-robin
 // over the 8 XCDs, so blocks b and b+8 share an L2.  Bijective for any grid size.
-__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n)
+__host__ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n)
 {
     const uint32_t q = n >> 3, r = n & 7u, x = b & 7u, i = b >> 3;
     return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + i;
@@ -81,7 +81,7 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n)
 
 // The same in chunks: every run of 8 * c consecutive logical items is dealt to the 8 XCDs in pieces of c (c = n / 8 is
 // xcd_remap, c = 1 the identity); the tail that does not fill a run keeps its order.  Bijective for any grid size.
-__device__ __forceinline__ uint32_t xcd_chunked(uint32_t b, uint32_t n, uint32_t c)
+__host__ __device__ __forceinline__ uint32_t xcd_chunked(uint32_t b, uint32_t n, uint32_t c)
 {
     const uint32_t group = 8u * c, g = b / group, r = b - g * group;
     if ((g + 1u) * group > n)

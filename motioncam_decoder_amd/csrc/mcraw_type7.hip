@@ -975,6 +975,13 @@ extern "C" void mcraw_diag_side_prof(unsigned long long *out, int reset)
 }
 #endif
 
+// The order k7_tiles takes its workgroups' work in (block b of a grid of n -> logical workgroup), exported so that the rule
+// -- a permutation for every grid size and run length -- can be checked without a GPU (tests/test_abi_library.py).
+extern "C" uint32_t mcraw_tile_order(uint32_t b, uint32_t n, uint32_t runs)
+{
+    return runs ? xcd_chunked(b, n, runs) : xcd_remap(b, n);
+}
+
 void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st)
 {
     const uint32_t n7 = static_cast<uint32_t>(W.n7);

@@ -90,3 +90,19 @@ def test_c_program_decodes(lib, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "ctx=yes" in r.stdout and "decode7 returned 256 first=0" in r.stdout
     assert "set_post rc=0" in r.stdout and "set_post(NULL) rc=0" in r.stdout
+
+
+def test_tile_order_is_a_permutation_for_every_grid_and_run_length(lib):
+    """k7_tiles' block -> logical workgroup mapping (mcraw_tile_order; runs of c workgroups per XCD, or the grid in eight
+    parts): every logical workgroup exactly once, whatever the grid size -- a gap or a repeat would be pixels never
+    written or written twice.  Within a full run group, XCD x (blocks x, x + 8, ...) gets c consecutive workgroups."""
+    import numpy as np
+    f = lib.mcraw_tile_order
+    for runs in (0, 1, 3, 8, 64, 128, 512):
+        for n in (1, 2, 7, 8, 9, 63, 64, 65, 1023, 1024, 1025, 4 * 1024 + 5, 8 * 128 * 3, 8 * 128 * 3 + 77):
+            got = np.array([f(b, n, runs) for b in range(n)], dtype=np.int64)
+            assert got.min() == 0 and got.max() == n - 1 and np.unique(got).size == n, (runs, n)
+    n, c = 8 * 128 * 4, 128
+    for x in range(8):
+        mine = [f(b, n, c) for b in range(x, 8 * c, 8)]   # XCD x's blocks of the first group
+        assert mine == list(range(x * c, (x + 1) * c))
