@@ -117,9 +117,11 @@ static_assert(ROWS_CAP <= 1024u && ROWS_CAP % 2u == 0u, "the division-free row a
 constexpr uint32_t DEC_CH = 4 * ROWS_CH;  // chunks per workgroup: four unpacking waves
 constexpr uint32_t DEC_T = 320;           // ... and a fifth wave: (DEC_CH + 1) * 17 = 289 map walks need five
 constexpr uint32_t RUN6 = 16;              // table entry at the first of sixteen 2-byte records in a row: jump over them (no record has this stride)
-constexpr uint32_t QTAB = HALF6 / 4 + 32;  // byte walk table of a quarter chunk: 128 strides, then 32 zeros
-constexpr uint32_t TABQ = 4 * QTAB + 32;  // ... of a chunk (+ 32: the tables of neighbouring chunks, which one wave walks at about the same
-                                          // positions, start 8 LDS banks apart)
+constexpr uint32_t QTAB = HALF6 / 4;      // byte walk table of a quarter chunk: 128 strides (a walk that has left its quarter is held
+                                          // by a select in the walk, not by zeros behind the table: those 2.7 KB decide whether five or six
+                                          // workgroups fit a CU)
+constexpr uint32_t TABQ = 4 * QTAB + 16;  // ... of a chunk (+ 16: the tables of neighbouring chunks, which one wave walks at about the same
+                                          // positions, start 4 LDS banks apart)
 static_assert((DEC_CH + 1) * PHASES6 <= DEC_T, "one thread per (chunk, phase)");
 
 #ifdef MCRAW_DIAG // phase stamps of every workgroup (timing experiments only; not in the product library)
@@ -159,11 +161,15 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     // walk tables of the DEC_CH + 1 chunks, a quarter chunk at a time: 128 strides, then 32 zeros where a walk that
     // has left the quarter stays; dead once the records are counted: the record lists take their place
     __shared__ __attribute__((aligned(16))) uint8_t s_tab[(DEC_CH + 1) * TABQ];
-    __shared__ uint8_t s_qx[(DEC_CH + 1) * 4 * PHASES6]; // [chunk][quarter][entry phase] = phase at which the quarter is left
+    __shared__ __attribute__((aligned(4))) uint8_t s_qx[(DEC_CH + 1) * 4 * PHASES6]; // [chunk][quarter][entry phase] = phase at which the quarter is left
     __shared__ uint8_t s_cx[(DEC_CH + 1) * PHASES6];     // [chunk][entry phase] = exit phase: the four composed
-    __shared__ uint32_t s_ent[DEC_CH + 1];  // entry of my chunks and of the one behind them: phase | first record << 8
-    __shared__ uint32_t s_ent4[DEC_CH * 4]; // ... of every quarter of my chunks
     __shared__ uint32_t s_exits[DEC_CH + 1]; // per chunk: the set of exit phases its 17 walks reach, one bit each
+    // entry of my chunks and of the one behind them (phase | first record << 8), and of every quarter of my chunks: written
+    // behind the look-back, when the exit sets and the quarters' maps have served -- they take their LDS (six workgroups per CU
+    // need every one of the 27 136 bytes)
+    uint32_t *const s_ent = s_exits;
+    uint32_t *const s_ent4 = reinterpret_cast<uint32_t *>(s_qx);
+    static_assert(sizeof(s_qx) >= DEC_CH * 4 * sizeof(uint32_t), "the quarters' entries fit where their maps were");
     __shared__ uint32_t s_ticket, s_coop, s_runs;
     // the list of a round, one of two layouts: every record r at [r - wlo] (up to ROWS_CAP / 2 records: the
     // common case, one LDS read gives both records of a pair), or one entry per PAIR at [(r - wlo) / 2]
@@ -268,9 +274,6 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         if (dst)
             *reinterpret_cast<uint2 *>(dst) = make_uint2(lo, hi);
     }
-    if (tid < (DEC_CH + 1u) * 8u) // 32 zeros behind every quarter
-        *reinterpret_cast<uint4 *>(s_tab + (tid >> 3) * TABQ + ((tid >> 1) & 3u) * QTAB + HALF6 / 4u + (tid & 1u) * 16u) =
-            make_uint4(0u, 0u, 0u, 0u);
     if (tid <= DEC_CH)
         s_exits[tid] = 0u;
     __syncthreads();
@@ -291,8 +294,11 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         do { // until no walk of the wave moved any more: each has left its quarter, or stands in front of the chain's
              // last record (stride 0)
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const uint32_t t0 = s_tab[A0], t1 = s_tab[A1], t2 = s_tab[A2], t3 = s_tab[A3];
+            for (int u = 0; u < 2; u++) { // (a walk that has left its quarter stays where it is)
+                // (the reads are unconditional -- what lies behind a quarter is LDS of this workgroup -- and a select drops them)
+                const uint32_t r0 = s_tab[A0], r1 = s_tab[A1], r2 = s_tab[A2], r3 = s_tab[A3];
+                const uint32_t t0 = A0 < end0 ? r0 : 0u, t1 = A1 < end0 + QTAB ? r1 : 0u, t2 = A2 < end0 + 2u * QTAB ? r2 : 0u,
+                               t3 = A3 < end0 + 3u * QTAB ? r3 : 0u;
                 A0 += t0, A1 += t1, A2 += t2, A3 += t3;
                 moved = t0 | t1 | t2 | t3;
             }
@@ -490,13 +496,14 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         bool notes_ok = s_runs == 0u;
         {
             const uint32_t qb = (uj + 1u) * TABQ + ur * QTAB;
-            uint32_t A = qb + (qp == DEAD ? HALF6 / 4u : qp); // (DEAD: starts on the zeros)
+            const uint32_t qe = qb + HALF6 / 4u;  // a walk that has left its quarter stays where it is
+            uint32_t A = qp == DEAD ? qe : qb + qp; // (DEAD: nothing to count)
             uint32_t t;
             if (s_runs) { // (some walk of this segment may meet a jump over sixteen records)
                 do {
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
-                        t = s_tab[A];
+                        t = s_tab[A]; t = A < qe ? t : 0u; // (unconditional read, then the select)
                         qn += t == RUN6 ? RUN6 : (t ? 1u : 0u);
                         A += t;
                     }
@@ -507,7 +514,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                 for (uint32_t st = 0; st < NOTES6; st += 2u) {
 #pragma unroll
                     for (uint32_t u = 0; u < 2u; u++) {
-                        t = s_tab[A];
+                        t = s_tab[A]; t = A < qe ? t : 0u; // (unconditional read, then the select)
                         nb[(st + u) >> 2] |= (A - qb) << (8u * ((st + u) & 3u)); // (< 256; bytes behind a lane's last record are never used)
                         qn += t ? 1u : 0u;
                         A += t;
@@ -522,7 +529,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                     do {
 #pragma unroll
                         for (int u = 0; u < 2; u++) {
-                            t = s_tab[A];
+                            t = s_tab[A]; t = A < qe ? t : 0u; // (unconditional read, then the select)
                             qn += t ? 1u : 0u;
                             A += t;
                         }
