@@ -162,9 +162,9 @@ def run_timed(torch, comm, ctx, M, wl, args):
     torch.cuda.synchronize()
     for t in wl.t_outs:
         t.zero_()
-    # timed: only the roofline kernel carries events, and only every fourth launch of it (a bracket is two event
+    # timed: only the roofline kernel carries events, and only every eighth launch of it (a bracket is two event
     # records in the stream, several microseconds; the sampled launches give the same average duration)
-    ctx.profile(only=("k7_tiles",), every=4)
+    ctx.profile(only=("k7_tiles",), every=8)
     ctx.kernel_ms("k7_tiles", reset=True)
     counted = [0]
 
@@ -762,7 +762,7 @@ def main():
                          "avg_launch_ms": round(s["tiles_ms_per_launch"], 4),
                          "launches_per_step": 1.0, "kernel_launches_per_step": 2,
                          "xcd_runs": s["kernels_ms_per_step"].get("xcd_runs"),
-                         "timed_with": "HIP events on the launch stream around every 4th k7_tiles launch of the timed rounds"},
+                         "timed_with": "HIP events on the launch stream around every 8th k7_tiles launch of the timed rounds"},
             "kernels_ms_per_step": {k: round(v, 4) for k, v in s["kernels_ms_per_step"].items() if k != "xcd_runs"},
         }
         calib_after = box_calibration(torch, dev)
