@@ -23,6 +23,14 @@ __device__ __forceinline__ uint32_t cls7_of(uint32_t b)
     return b <= 6u ? b : (b <= 8u ? 7u : (b <= 10u ? 8u : 9u));
 }
 
+// 0x00 / 0xFF in every byte lane where `g` holds 0 / 1: one addition and one v_perm_b32 (selector bytes 12 and 13 are
+// the constants 0x00 and 0xFF).  Written as (g << 8) - g the compiler emits a v_mul_lo_u32 by 255, which issues at a
+// quarter of the rate.
+__device__ __forceinline__ uint32_t byte_mask(uint32_t g)
+{
+    return __builtin_amdgcn_perm(0u, 0u, 0x0C0C0C0Cu + g);
+}
+
 // Bounds-checked byte-buffer descriptor over one frame buffer: reads past
 // `len` return 0 instead of faulting (corrupt offsets cannot leave the frame).
 // The range check of a raw buffer works on whole dwords, so the record count is

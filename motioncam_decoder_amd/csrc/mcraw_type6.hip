@@ -35,8 +35,17 @@ __device__ __forceinline__ uint32_t stride4(uint32_t hdr4)
 {
     const uint32_t x = (hdr4 >> 4) & 0x0F0F0F0Fu;
     const uint32_t g = ((x + 0x05050505u) >> 4) & 0x01010101u;
-    const uint32_t big = (g << 8) - g; // 0xFF in the byte lanes where bits >= 11
+    const uint32_t big = byte_mask(g); // 0xFF in the byte lanes where bits >= 11
     return (big & 0x11111111u) | (~big & (x + 0x01010101u));
+}
+
+// 24-bit x 24-bit multiply, low 32 bits (full rate).  __umul24 of a per-lane and a uniform operand comes out of the compiler as
+// v_and + v_mul_lo_u32, which issues at a quarter of the rate.
+__device__ __forceinline__ uint32_t mul_u24(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 // Look-back state words are 64 bits: the launch's epoch in the high half (the state buffer is never cleared: words
@@ -767,7 +776,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
             quad6(bytes, roa, qt, va, &refa);
             quad6(bytes, rob, qt, vb, &refb);
             const uint32_t n = r0 + q;
-            const uint32_t dy = widerow ? (n >= ppr ? 1u : 0u) : __umul24(n, m20) >> 20;
+            const uint32_t dy = widerow ? (n >= ppr ? 1u : 0u) : mul_u24(n, m20) >> 20;
             const uint32_t x = (n - __umul24(dy, ppr)) * 32u + 8u * qt; // RawData_Legacy.cpp:479-486
             const u16x2 refs = __builtin_bit_cast(u16x2, refa | (refb << 16));
             uint32_t o[4];

@@ -202,7 +202,7 @@ __device__ __forceinline__ uint2 side_strides(const uint4 v, uint32_t odd)
         const uint32_t lo = __builtin_amdgcn_perm(0x08060504u, 0x03020100u, sel); // LEN/8, hbits 0..7
         const uint32_t hi = __builtin_amdgcn_perm(0x10101010u, 0x100A0A08u, sel); // LEN/8, hbits 8..15
         const uint32_t g = (hb >> 3) & 0x01010101u;
-        const uint32_t m = (g << 8) - g;
+        const uint32_t m = byte_mask(g);
         st[i] = (((hi & m) | (lo & ~m)) << 2) + 0x01010101u;
     }
     return make_uint2(st[0], st[1]);
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                     const uint32_t lo = __builtin_amdgcn_perm(0x08060504u, 0x03020100u, sel); // v = 0..7
                     const uint32_t hi = __builtin_amdgcn_perm(0x10101010u, 0x100A0A08u, sel); // v = 8..15
                     const uint32_t g = (v4 >> 3) & 0x01010101u;
-                    const uint32_t m = (g << 8) - g;
+                    const uint32_t m = byte_mask(g);
                     const uint32_t l4 = ((hi & m) | (lo & ~m)) | (v4 & 0x10101010u);
                     l8 = __builtin_amdgcn_sad_u8(l4, 0u, l8);
                 }
