@@ -18,6 +18,8 @@
 // and crops the padded row (:490).
 #include "mcraw_dev.h"
 
+#include <cstdlib>
+
 #include "../../include/mcraw_hip.h"
 
 namespace mcraw {
@@ -119,7 +121,7 @@ constexpr uint32_t ROWS_CAP = 256u * ROWS_CH; // records per round (typical: ~70
 static_assert(ROWS_CAP <= 1024u && ROWS_CAP % 2u == 0u, "the division-free row arithmetic of the unpack assumes at most 512 pairs per round");
 
 #ifndef K6_ABL
-#define K6_ABL 0 // timing experiments only: 1 no stores, 3 no walk
+#define K6_ABL 0 // timing experiments only: 1 no stores, 3 no walk, 5 the front alone (no bytes in LDS, waves 0-3 leave behind the maps, no unpack), 6 the same with the waves staying
 #endif
 
 // ------------------------------------------------------------------ k6_decode
@@ -135,7 +137,8 @@ static_assert((DEC_CH + 1) * PHASES6 <= DEC_T, "one thread per (chunk, phase)");
 
 #ifdef MCRAW_DIAG // phase stamps of every workgroup (timing experiments only; not in the product library)
 constexpr int K6_PROF_WG = 1 << 16;
-__device__ uint32_t g_k6_prof[K6_PROF_WG][16];
+constexpr int K6_PROF_N = 20;
+__device__ uint32_t g_k6_prof[K6_PROF_WG][K6_PROF_N]; // [16], [17]: s_memrealtime (100 MHz) at a workgroup's start and end
 #define K6_STAMP(slot, who)                                                                                            \
     do {                                                                                                               \
         if (threadIdx.x == (who) && blockIdx.x < K6_PROF_WG) {                                                         \
@@ -145,6 +148,11 @@ __device__ uint32_t g_k6_prof[K6_PROF_WG][16];
         }                                                                                                              \
     } while (0)
 #define K6_COUNT(slot, v) (blockIdx.x < K6_PROF_WG ? (void)(g_k6_prof[blockIdx.x][slot] = static_cast<uint32_t>(v)) : (void)0)
+// what would a map stage without vector work be worth?  mode 1: every workgroup records its maps; mode 2: the maps are read back
+// instead of walked (same data, same launch geometry: tools/k6_replay.sh)
+constexpr uint32_t K6_MAPS_SLOT = 1536;
+__device__ uint32_t g_k6_mode;
+__device__ uint8_t *g_k6_maps;
 #else
 #define K6_STAMP(slot, who)
 #define K6_COUNT(slot, v)
@@ -190,8 +198,10 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
 
 #ifdef MCRAW_DIAG
     unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
-    if (threadIdx.x == 0 && blockIdx.x < K6_PROF_WG)
+    if (threadIdx.x == 0 && blockIdx.x < K6_PROF_WG) {
         g_k6_prof[blockIdx.x][6] = static_cast<uint32_t>(stamp_);
+        g_k6_prof[blockIdx.x][16] = static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime());
+    }
 #endif
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     // Which frame this workgroup works on, and the segment it will most likely be given: the launch goes over the
@@ -233,6 +243,22 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     if (cfirst >= nchunks)
         return; // whole workgroup
 
+#ifdef MCRAW_DIAG
+    const uint32_t kmode = g_k6_mode;
+    uint8_t *const kslot = g_k6_maps + (static_cast<size_t>(f) * smax + seg) * K6_MAPS_SLOT;
+    uint8_t kpre[5] = {0, 0, 0, 0, 0};
+    uint32_t kpre4 = 0;
+    if (kmode == 3u) {
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++)
+            if (tid + u * DEC_T < sizeof(s_qx))
+                kpre[u] = kslot[tid + u * DEC_T];
+        if (tid < sizeof(s_cx))
+            kpre[4] = kslot[sizeof(s_qx) + tid];
+        if (tid <= DEC_CH)
+            kpre4 = reinterpret_cast<const uint32_t *>(kslot + 1460)[tid];
+    }
+#endif
     // ---- stage the stream and turn it into the walk tables (one byte per even position: the record stride in half
     // positions; 32 zeros behind every chunk, where a walk that has left the chunk stays)
 #pragma unroll
@@ -242,7 +268,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         uint8_t *dst = nullptr;
         bool ones = false;
         if (i < NPIECE && (seg || i >= CHUNK6 / 16u)) {
-            if (i >= CHUNK6 / 16u)
+            if (K6_ABL < 5 && i >= CHUNK6 / 16u)
                 *reinterpret_cast<uint4 *>(s_own + (i - CHUNK6 / 16u) * 16u) = v[r];
             if (i < (DEC_CH + 1u) * (CHUNK6 / 16u)) {
                 // header candidates are bytes 0 and 2 of every dword
@@ -295,7 +321,21 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     const bool mapper = tid < (DEC_CH + 1u) * PHASES6;
     const uint32_t mk = tid / PHASES6, mph = tid - mk * PHASES6; // (mk = 0: the chunk in front of the segment)
     const bool mapped = mapper && (mk || seg) && cfirst + mk - 1u < nchunks;
+#ifdef MCRAW_DIAG
+    if (kmode >= 2u) { // (mode 3: the loads were issued in front of the table stage)
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++)
+            if (tid + u * DEC_T < sizeof(s_qx))
+                s_qx[tid + u * DEC_T] = kmode == 3u ? kpre[u] : kslot[tid + u * DEC_T];
+        for (uint32_t i = tid; i < sizeof(s_cx); i += DEC_T)
+            s_cx[i] = kmode == 3u ? kpre[4] : kslot[sizeof(s_qx) + i];
+        if (tid <= DEC_CH)
+            s_exits[tid] = kmode == 3u ? kpre4 : reinterpret_cast<const uint32_t *>(kslot + 1460)[tid];
+    }
+    if (mapped && kmode < 2u) {
+#else
     if (mapped) {
+#endif
         const uint32_t q0 = mk * TABQ + mph;
         uint32_t A0 = q0, A1 = q0 + QTAB, A2 = q0 + 2u * QTAB, A3 = q0 + 3u * QTAB;
         const uint32_t end0 = mk * TABQ + HALF6 / 4u; // (end of quarter r: end0 + r * QTAB)
@@ -320,7 +360,11 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     }
     __syncthreads();
     K6_STAMP(2, 0);
+#ifdef MCRAW_DIAG
+    if (mapped && kmode < 2u) {
+#else
     if (mapped) {
+#endif
         const uint8_t *qx = s_qx + mk * 4u * PHASES6;
         uint32_t x = mph;
 #pragma unroll
@@ -330,7 +374,19 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         atomicOr(&s_exits[mk], 1u << x);
     }
     __syncthreads();
+#ifdef MCRAW_DIAG
+    if (kmode == 1u) {
+        for (uint32_t i = tid; i < sizeof(s_qx); i += DEC_T)
+            kslot[i] = s_qx[i];
+        for (uint32_t i = tid; i < sizeof(s_cx); i += DEC_T)
+            kslot[sizeof(s_qx) + i] = s_cx[i];
+        if (tid <= DEC_CH)
+            reinterpret_cast<uint32_t *>(kslot + 1460)[tid] = s_exits[tid];
+    }
+#endif
 
+    if (K6_ABL == 5 && wave < 4u)
+        return;
     // ---- entries of my chunks (wave DEC_T / 64 - 1; the others wait at the barrier below)
     const uint32_t cnt = min(static_cast<uint32_t>(DEC_CH), nchunks - cfirst);
     // What unpacking wave w has to do, from the entries in s_ent (valid once the fifth wave has written them).
@@ -677,7 +733,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
             // ends on an even one; a lane whose records end on a group boundary has stored nothing behind them)
             if (j == ROWS_CH - 1u && r == 3u)
                 lp[qn] = static_cast<uint16_t>(ROWS_CH * CHUNK6 + 2u * (ent_of(uw * ROWS_CH + ROWS_CH) & 255u));
-        } else if (K6_ABL != 3 && coop) {
+        } else if (K6_ABL != 3 && K6_ABL < 5 && coop) {
             const uint32_t ej = s_ent4[lane], first = rg.R0;
             const uint8_t *base = s_own + uw * (ROWS_CH * CHUNK6);
             const uint8_t *p = base + j * CHUNK6 + r * (CHUNK6 / 4u) + 2u * (ej & 255u);
@@ -726,7 +782,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     }
     __syncthreads();
     K6_STAMP(3, 0);
-    if (wave >= 4u)
+    if (wave >= 4u || K6_ABL >= 5)
         return; // (the fifth wave has no chunks of its own)
 
     const Range6 mine = range_of(wave);
@@ -815,8 +871,10 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         unpack_round(R0, R1, pairmode);
         K6_STAMP(5, 0);
 #ifdef MCRAW_DIAG
-        if (threadIdx.x == 0 && blockIdx.x < K6_PROF_WG)
+        if (threadIdx.x == 0 && blockIdx.x < K6_PROF_WG) {
             g_k6_prof[blockIdx.x][7] = static_cast<uint32_t>(stamp_);
+            g_k6_prof[blockIdx.x][17] = static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime());
+        }
 #endif
         return;
     }
@@ -867,10 +925,28 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
 // ------------------------------------------------------------------ launchers
 
 #ifdef MCRAW_DIAG
+extern "C" int mcraw_diag_k6_occupancy(int dyn_lds)
+{
+    int n = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k6_decode<0>, DEC_T, static_cast<size_t>(dyn_lds));
+    return n;
+}
+extern "C" void mcraw_diag_k6_maps(int mode)
+{
+    static uint8_t *buf = nullptr;
+    (void)hipDeviceSynchronize();
+    if (!buf) {
+        (void)hipMalloc(reinterpret_cast<void **>(&buf), size_t(1) << 27);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_k6_maps), &buf, sizeof(buf));
+    }
+    const uint32_t m = static_cast<uint32_t>(mode);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_k6_mode), &m, sizeof(m));
+    (void)hipDeviceSynchronize();
+}
 extern "C" void mcraw_diag_k6_prof(uint32_t *out, int nwg, int reset)
 {
     (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k6_prof), sizeof(uint32_t) * 16 * nwg);
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k6_prof), sizeof(uint32_t) * K6_PROF_N * nwg);
     if (reset) {
         void *p = nullptr;
         (void)hipGetSymbolAddress(&p, HIP_SYMBOL(g_k6_prof));
@@ -890,7 +966,12 @@ void launch_k6_decode(const Plan6 *plans, const uint32_t *wg_tab, uint32_t stage
     const dim3 grid(nwg), block(DEC_T);
     const uint32_t nf = static_cast<uint32_t>(nframes);
     if (post.mode == 0u) {
+#ifdef MCRAW_DIAG // occupancy experiments: extra LDS per workgroup (tools/k6_occ.sh)
+        static const uint32_t pad = getenv("MCRAW_K6_LDSPAD") ? static_cast<uint32_t>(atoi(getenv("MCRAW_K6_LDSPAD"))) : 0u;
+        hipLaunchKernelGGL(k6_decode<0>, grid, block, pad, st, plans, wg_tab, stage0, look, tickets, epoch, nf, smax, post);
+#else
         hipLaunchKernelGGL(k6_decode<0>, grid, block, 0, st, plans, wg_tab, stage0, look, tickets, epoch, nf, smax, post);
+#endif
         return;
     }
     switch (post_bits(post.mode)) { // one kernel instance per row format

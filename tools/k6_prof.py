@@ -25,7 +25,7 @@ lib = M.load()
 written, status = ctx.decode_batch(frames)
 assert all(s == 0 for s in status)
 NWG = 1 << 16
-prof = np.zeros((NWG, 16), np.uint32)
+prof = np.zeros((NWG, 20), np.uint32)
 pp = prof.ctypes.data_as(C.POINTER(C.c_uint32))
 lib.mcraw_diag_k6_prof(pp, NWG, 1)
 ctx.profile(True)
@@ -41,6 +41,13 @@ names = {0: "w0 ticket+load", 1: "w0 stage+table", 2: "w0 map walks", 3: "w0 com
 for i, nm in names.items():
     print("%-30s mean %8.0f  p50 %8.0f  p90 %8.0f ticks" % (nm, P[:, i].mean(), np.median(P[:, i]), np.percentile(P[:, i], 90)))
 print("workgroups", live.sum(), "lifetime mean", P[:, 0:6].sum(axis=1).mean(), "spins/wg", P[:, 15].mean(), "max", P[:, 15].max())
-Q = P[P[:, 7] > 0]; t0 = Q[:, 6].min(); span = ((Q[:, 7] - t0) % 2**32).max()
-print("kernel span ticks", span, "-> concurrency", P[:, 0:6].sum() / span, "wgs in flight; tick rate MHz ~", span / (ctx.kernel_ms("k6_decode")[0] / reps * 1e3))
+Q = P[P[:, 7] > 0]
+dt = (Q[:, 7] - Q[:, 6]) % 2**32          # s_memtime ticks of a workgroup's life
+dr = (Q[:, 17] - Q[:, 16]) % 2**32        # the same in 100 MHz ticks
+ok = dr > 0
+clk = np.median(dt[ok] / dr[ok]) * 100.0
+ms = ctx.kernel_ms("k6_decode")[0] / reps
+life_us = np.mean(dr[ok]) / 100.0
+print("in-kernel clock MHz (median of workgroups)", clk, " workgroup life us", life_us, " -> workgroups in flight", life_us * live.sum() / (ms * 1e3),
+      "= per CU", life_us * live.sum() / (ms * 1e3) / 256)
 print("ms/launch", ctx.kernel_ms("k6_decode")[0] / reps)
