@@ -137,8 +137,10 @@ static_assert((DEC_CH + 1) * PHASES6 <= DEC_T, "one thread per (chunk, phase)");
 
 #ifdef MCRAW_DIAG // phase stamps of every workgroup (timing experiments only; not in the product library)
 constexpr int K6_PROF_WG = 1 << 16;
-constexpr int K6_PROF_N = 20;
-__device__ uint32_t g_k6_prof[K6_PROF_WG][K6_PROF_N]; // [16], [17]: s_memrealtime (100 MHz) at a workgroup's start and end
+// [0..13]: stage stamps (s_memtime), [14] live, [15] look-back spins; [16], [17]: s_memrealtime (100 MHz) at wave 0's start and end;
+// [18 + w]: at wave w's end, its stores landed; [23], [24]: HW_ID, XCC_ID of wave 0; [27 + w]: HW_ID of wave w
+constexpr int K6_PROF_N = 32;
+__device__ uint32_t g_k6_prof[K6_PROF_WG][K6_PROF_N];
 #define K6_STAMP(slot, who)                                                                                            \
     do {                                                                                                               \
         if (threadIdx.x == (who) && blockIdx.x < K6_PROF_WG) {                                                         \
@@ -148,11 +150,6 @@ __device__ uint32_t g_k6_prof[K6_PROF_WG][K6_PROF_N]; // [16], [17]: s_memrealti
         }                                                                                                              \
     } while (0)
 #define K6_COUNT(slot, v) (blockIdx.x < K6_PROF_WG ? (void)(g_k6_prof[blockIdx.x][slot] = static_cast<uint32_t>(v)) : (void)0)
-// what would a map stage without vector work be worth?  mode 1: every workgroup records its maps; mode 2: the maps are read back
-// instead of walked (same data, same launch geometry: tools/k6_replay.sh)
-constexpr uint32_t K6_MAPS_SLOT = 1536;
-__device__ uint32_t g_k6_mode;
-__device__ uint8_t *g_k6_maps;
 #else
 #define K6_STAMP(slot, who)
 #define K6_COUNT(slot, v)
@@ -201,7 +198,18 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     if (threadIdx.x == 0 && blockIdx.x < K6_PROF_WG) {
         g_k6_prof[blockIdx.x][6] = static_cast<uint32_t>(stamp_);
         g_k6_prof[blockIdx.x][16] = static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime());
+        g_k6_prof[blockIdx.x][23] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_REG_HW_ID, all 32 bits
+        g_k6_prof[blockIdx.x][24] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); // HW_REG_XCC_ID
     }
+    if ((threadIdx.x & 63u) == 0u && blockIdx.x < K6_PROF_WG)
+        g_k6_prof[blockIdx.x][27 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+#define K6_END()                                                                                                       \
+    do {                                                                                                               \
+        if ((threadIdx.x & 63u) == 0u && blockIdx.x < K6_PROF_WG)                                                     \
+            g_k6_prof[blockIdx.x][18 + (threadIdx.x >> 6)] = static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime());  \
+    } while (0)
+#else
+#define K6_END()
 #endif
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     // Which frame this workgroup works on, and the segment it will most likely be given: the launch goes over the
@@ -243,22 +251,6 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     if (cfirst >= nchunks)
         return; // whole workgroup
 
-#ifdef MCRAW_DIAG
-    const uint32_t kmode = g_k6_mode;
-    uint8_t *const kslot = g_k6_maps + (static_cast<size_t>(f) * smax + seg) * K6_MAPS_SLOT;
-    uint8_t kpre[5] = {0, 0, 0, 0, 0};
-    uint32_t kpre4 = 0;
-    if (kmode == 3u) {
-#pragma unroll
-        for (uint32_t u = 0; u < 4u; u++)
-            if (tid + u * DEC_T < sizeof(s_qx))
-                kpre[u] = kslot[tid + u * DEC_T];
-        if (tid < sizeof(s_cx))
-            kpre[4] = kslot[sizeof(s_qx) + tid];
-        if (tid <= DEC_CH)
-            kpre4 = reinterpret_cast<const uint32_t *>(kslot + 1460)[tid];
-    }
-#endif
     // ---- stage the stream and turn it into the walk tables (one byte per even position: the record stride in half
     // positions; 32 zeros behind every chunk, where a walk that has left the chunk stays)
 #pragma unroll
@@ -321,21 +313,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     const bool mapper = tid < (DEC_CH + 1u) * PHASES6;
     const uint32_t mk = tid / PHASES6, mph = tid - mk * PHASES6; // (mk = 0: the chunk in front of the segment)
     const bool mapped = mapper && (mk || seg) && cfirst + mk - 1u < nchunks;
-#ifdef MCRAW_DIAG
-    if (kmode >= 2u) { // (mode 3: the loads were issued in front of the table stage)
-#pragma unroll
-        for (uint32_t u = 0; u < 4u; u++)
-            if (tid + u * DEC_T < sizeof(s_qx))
-                s_qx[tid + u * DEC_T] = kmode == 3u ? kpre[u] : kslot[tid + u * DEC_T];
-        for (uint32_t i = tid; i < sizeof(s_cx); i += DEC_T)
-            s_cx[i] = kmode == 3u ? kpre[4] : kslot[sizeof(s_qx) + i];
-        if (tid <= DEC_CH)
-            s_exits[tid] = kmode == 3u ? kpre4 : reinterpret_cast<const uint32_t *>(kslot + 1460)[tid];
-    }
-    if (mapped && kmode < 2u) {
-#else
     if (mapped) {
-#endif
         const uint32_t q0 = mk * TABQ + mph;
         uint32_t A0 = q0, A1 = q0 + QTAB, A2 = q0 + 2u * QTAB, A3 = q0 + 3u * QTAB;
         const uint32_t end0 = mk * TABQ + HALF6 / 4u; // (end of quarter r: end0 + r * QTAB)
@@ -360,11 +338,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     }
     __syncthreads();
     K6_STAMP(2, 0);
-#ifdef MCRAW_DIAG
-    if (mapped && kmode < 2u) {
-#else
     if (mapped) {
-#endif
         const uint8_t *qx = s_qx + mk * 4u * PHASES6;
         uint32_t x = mph;
 #pragma unroll
@@ -374,16 +348,6 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         atomicOr(&s_exits[mk], 1u << x);
     }
     __syncthreads();
-#ifdef MCRAW_DIAG
-    if (kmode == 1u) {
-        for (uint32_t i = tid; i < sizeof(s_qx); i += DEC_T)
-            kslot[i] = s_qx[i];
-        for (uint32_t i = tid; i < sizeof(s_cx); i += DEC_T)
-            kslot[sizeof(s_qx) + i] = s_cx[i];
-        if (tid <= DEC_CH)
-            reinterpret_cast<uint32_t *>(kslot + 1460)[tid] = s_exits[tid];
-    }
-#endif
 
     if (K6_ABL == 5 && wave < 4u)
         return;
@@ -782,8 +746,10 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     }
     __syncthreads();
     K6_STAMP(3, 0);
-    if (wave >= 4u || K6_ABL >= 5)
+    if (wave >= 4u || K6_ABL >= 5) {
+        K6_END();
         return; // (the fifth wave has no chunks of its own)
+    }
 
     const Range6 mine = range_of(wave);
     const uint32_t c0 = cfirst + wave * ROWS_CH, cs0 = c0 * CHUNK6;
@@ -875,6 +841,8 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
             g_k6_prof[blockIdx.x][7] = static_cast<uint32_t>(stamp_);
             g_k6_prof[blockIdx.x][17] = static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime());
         }
+        __builtin_amdgcn_s_waitcnt(0); // (the end stamp is taken when the wave's stores have landed)
+        K6_END();
 #endif
         return;
     }
@@ -930,18 +898,6 @@ extern "C" int mcraw_diag_k6_occupancy(int dyn_lds)
     int n = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k6_decode<0>, DEC_T, static_cast<size_t>(dyn_lds));
     return n;
-}
-extern "C" void mcraw_diag_k6_maps(int mode)
-{
-    static uint8_t *buf = nullptr;
-    (void)hipDeviceSynchronize();
-    if (!buf) {
-        (void)hipMalloc(reinterpret_cast<void **>(&buf), size_t(1) << 27);
-        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_k6_maps), &buf, sizeof(buf));
-    }
-    const uint32_t m = static_cast<uint32_t>(mode);
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_k6_mode), &m, sizeof(m));
-    (void)hipDeviceSynchronize();
 }
 extern "C" void mcraw_diag_k6_prof(uint32_t *out, int nwg, int reset)
 {

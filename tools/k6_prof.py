@@ -25,7 +25,7 @@ lib = M.load()
 written, status = ctx.decode_batch(frames)
 assert all(s == 0 for s in status)
 NWG = 1 << 16
-prof = np.zeros((NWG, 20), np.uint32)
+prof = np.zeros((NWG, 32), np.uint32)
 pp = prof.ctypes.data_as(C.POINTER(C.c_uint32))
 lib.mcraw_diag_k6_prof(pp, NWG, 1)
 ctx.profile(True)
@@ -51,3 +51,29 @@ life_us = np.mean(dr[ok]) / 100.0
 print("in-kernel clock MHz (median of workgroups)", clk, " workgroup life us", life_us, " -> workgroups in flight", life_us * live.sum() / (ms * 1e3),
       "= per CU", life_us * live.sum() / (ms * 1e3) / 256)
 print("ms/launch", ctx.kernel_ms("k6_decode")[0] / reps)
+
+# residency: workgroups per CU over time, from the stamps of every wave's end and the hardware ids of wave 0
+R = prof[live].astype(np.int64)
+start = R[:, 16]
+end = R[:, 18:23].max(axis=1)
+t0 = start.min()
+start = (start - t0) % 2**32
+end = (end - t0) % 2**32
+good = (end > start) & (end - start < 10**6)
+cu = (R[:, 24] & 15) * 65536 + (R[:, 23] & 0xFF00)          # XCC, then SE / SH / CU bits of HW_ID
+ids = np.unique(cu[good])
+tot_busy = 0.0; peak = []; span = (end[good].max() - start[good].min())
+for c in ids:
+    m = good & (cu == c)
+    ev = np.concatenate([np.stack([start[m], np.ones(m.sum(), np.int64)], 1), np.stack([end[m], -np.ones(m.sum(), np.int64)], 1)])
+    ev = ev[np.lexsort((ev[:, 1], ev[:, 0]))]
+    conc = np.cumsum(ev[:, 1])
+    dt = np.diff(ev[:, 0])
+    tot_busy += float((conc[:-1] * dt).sum())
+    peak.append(conc.max())
+print("distinct CU ids", len(ids), " mean resident workgroups per CU %.2f" % (tot_busy / span / len(ids)), " peak per CU: min %d median %d max %d" % (min(peak), np.median(peak), max(peak)),
+      " workgroup life incl. store drain us: mean %.2f" % ((end[good] - start[good]).mean() / 100.0))
+hw = prof[live][:, 27:32]
+print("wave slot ids seen (all waves):", np.bincount((hw & 15).ravel(), minlength=10), " SIMD ids:", np.bincount(((hw >> 4) & 3).ravel()))
+if os.environ.get("K6_PROF_SAVE"):
+    np.save(os.environ["K6_PROF_SAVE"], prof[live])
