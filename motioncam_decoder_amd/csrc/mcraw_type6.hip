@@ -125,6 +125,7 @@ static_assert(ROWS_CAP <= 1024u && ROWS_CAP % 2u == 0u, "the division-free row a
 #endif
 
 // ------------------------------------------------------------------ k6_decode
+constexpr uint32_t TAIL6 = 128;           // tasks (8 pixels each) of every unpacking wave's list that the fifth wave takes over
 constexpr uint32_t DEC_CH = 4 * ROWS_CH;  // chunks per workgroup: four unpacking waves
 constexpr uint32_t DEC_T = 320;           // ... and a fifth wave: (DEC_CH + 1) * 17 = 289 map walks need five
 constexpr uint32_t RUN6 = 16;              // table entry at the first of sixteen 2-byte records in a row: jump over them (no record has this stride)
@@ -746,20 +747,19 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     }
     __syncthreads();
     K6_STAMP(3, 0);
-    if (wave >= 4u || K6_ABL >= 5) {
+    const bool coop = s_coop != 0u;
+    if ((wave >= 4u && !coop) || K6_ABL >= 5) {
         K6_END();
-        return; // (the fifth wave has no chunks of its own)
+        return; // (the fifth wave has no chunks of its own; on the lean path it takes a share of every wave's pairs)
     }
 
-    const Range6 mine = range_of(wave);
+    const Range6 mine = range_of(wave & 3u);
     const uint32_t c0 = cfirst + wave * ROWS_CH, cs0 = c0 * CHUNK6;
     const uint32_t R0 = mine.R0, R1 = mine.R1, N = mine.N;
     const bool live = mine.live, pairmode = mine.pairmode;
     // entries of my chunks (lane j) and of the chunk after them (lane ROWS_CH): the general path walks from them
-    const uint32_t e = lane <= ROWS_CH ? ent_of(wave * ROWS_CH + lane) : DEAD;
-    const bool coop = s_coop != 0u;
+    const uint32_t e = lane <= ROWS_CH ? ent_of((wave & 3u) * ROWS_CH + lane) : DEAD;
 
-    const uint8_t *bytes = s_own + wave * (ROWS_CH * CHUNK6);
     // (the walk tables are dead: from here on their LDS holds the record lists)
     const uint32_t width = static_cast<uint32_t>(P->width);
     const bool fast = P->fast_store != 0u;
@@ -771,17 +771,18 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     const bool widerow = ppr >= 512u;
     const uint32_t m20 = widerow ? 0u : ((1u << 20) + ppr - 1u) / ppr;
 
-    // Unpack the pairs of records [wlo, whi) (both even) listed in s_pos[wave]: four lanes per pair
-    auto unpack_round = [&](uint32_t wlo, uint32_t whi, bool by_pair) {
+    // Unpack the pairs of records [wlo, whi) (both even) of unpacking wave uw, listed in s_pos[uw]: four lanes per pair; of
+    // its 2 * (whi - wlo) tasks, those in [tb, te)
+    auto unpack_round = [&](uint32_t uw, uint32_t wlo, uint32_t whi, bool by_pair, uint32_t tb, uint32_t te) {
+        const uint8_t *bytes = s_own + uw * (ROWS_CH * CHUNK6);
         const uint32_t pair0 = wlo >> 1;
-        const uint16_t *pairs = s_pos[wave];
-        const uint32_t *both = reinterpret_cast<const uint32_t *>(s_pos[wave]);
+        const uint16_t *pairs = s_pos[uw];
+        const uint32_t *both = reinterpret_cast<const uint32_t *>(s_pos[uw]);
         const uint32_t y0 = pair0 / ppr, r0 = pair0 - y0 * ppr; // wave-uniform
         const uint32_t row0 = y0 * width;
-        const uint32_t ntask = 2u * (whi - wlo);
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
-        for (uint32_t t = lane; t < ntask; t += 64u) {
+        for (uint32_t t = tb + lane; t < te; t += 64u) {
             // one task: 8 pixels (even columns from record A, odd columns from record B, uint16 wrap
             // on the reference add) and where they go
             const uint32_t q = t >> 2, qt = t & 3u;
@@ -833,8 +834,21 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     };
 
     if (coop) {
+        // The wave that resolved the entries has no chunks of its own: it takes the last TAIL6 tasks of each of the four
+        // lists (whole passes of 64 lanes: a wave's 580 tasks were nine passes and a tenth of 8 lanes; now seven or eight,
+        // and eight for the fifth wave).
         K6_STAMP(4, 0);
-        unpack_round(R0, R1, pairmode);
+        auto tail_of = [&](uint32_t ntask) { return ntask >= 3u * TAIL6 ? ntask - TAIL6 : ntask; }; // first task of the fifth wave's share
+        if (wave < 4u) {
+            unpack_round(wave, R0, R1, pairmode, 0u, tail_of(2u * (R1 - R0)));
+        } else {
+#pragma unroll 1
+            for (uint32_t uw = 0; uw < 4u; uw++) {
+                const Range6 rg = range_of(uw);
+                const uint32_t ntask = 2u * (rg.R1 - rg.R0);
+                unpack_round(uw, rg.R0, rg.R1, rg.pairmode, tail_of(ntask), ntask);
+            }
+        }
         K6_STAMP(5, 0);
 #ifdef MCRAW_DIAG
         if (threadIdx.x == 0 && blockIdx.x < K6_PROF_WG) {
@@ -848,6 +862,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     }
     if (!live)
         return;
+    const uint8_t *bytes = s_own + wave * (ROWS_CH * CHUNK6);
     const bool walker = lane < ROWS_CH && (e & 255u) != DEAD && c0 + lane < nchunks;
     // a walker keeps its place from round to round (restarting at the chunk entry every round made a
     // run of 2-byte records cost rounds x 512 steps per lane)
@@ -884,7 +899,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
-        unpack_round(wlo, whi, true);
+        unpack_round(wave, wlo, whi, true, 0u, 2u * (whi - wlo));
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier(); // the list is rewritten by the next round
     }
