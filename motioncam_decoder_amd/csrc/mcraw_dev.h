@@ -117,6 +117,23 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t lane, ui
     return inc - v;
 }
 
+// Lane i's value of lane i - 1 (lane 0: `first`) / of lane i + 1 (lane 63: `last`), all 64 lanes active: one DPP move across
+// the whole wave (gfx9 wave_shr:1 / wave_shl:1) instead of a ds_bpermute round trip through the LDS (~120 cycles when the
+// next instruction needs the result).
+__device__ __forceinline__ uint32_t wave_prev(uint32_t v, uint32_t first)
+{
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(first), static_cast<int>(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ uint32_t wave_next(uint32_t v, uint32_t last)
+{
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(last), static_cast<int>(v), 0x130, 0xf, 0xf, false));
+}
+// Lane k's value (k wave-uniform) for every lane: v_readlane instead of ds_bpermute.
+__device__ __forceinline__ uint32_t wave_lane(uint32_t v, uint32_t k)
+{
+    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), static_cast<int>(k)));
+}
+
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 {
 #pragma unroll

@@ -363,10 +363,10 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         bool pairmode;      // which list layout its single round uses
     };
     auto ent_of = [&](uint32_t j) { return cfirst + j < nchunks ? s_ent[j] : DEAD; }; // (no entry behind the last chunk)
-    auto range_of = [&](uint32_t w) {
+    // (e0, enext: the entries of the wave's first chunk and of the chunk behind its last)
+    auto range_from = [&](uint32_t w, uint32_t e0, uint32_t enext) {
         constexpr uint32_t STAGE = ROWS_CH * CHUNK6 + 64 + 16; // what a wave may touch: its chunks + the reach of a record 32 bytes past them
         const uint32_t c0 = cfirst + w * ROWS_CH;
-        const uint32_t e0 = ent_of(w * ROWS_CH), enext = ent_of(w * ROWS_CH + ROWS_CH);
         const bool inner = c0 + ROWS_CH < nchunks && (enext & 255u) != DEAD && (enext >> 8) <= nrec;
         // records that start in the wave's chunks: [I0, Iend); nrec is even (two records per 32 columns)
         const uint32_t I0 = e0 >> 8;
@@ -380,6 +380,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         g.pairmode = g.N > ROWS_CAP / 2u;
         return g;
     };
+    auto range_of = [&](uint32_t w) { return range_from(w, ent_of(w * ROWS_CH), ent_of(w * ROWS_CH + ROWS_CH)); };
     if (wave == DEC_T / 64u - 1u) {
         const size_t lme = static_cast<size_t>(f) * smax + seg;
         uint64_t *const res = look.res + lme; // mine; res[-k]: k segments before me
@@ -405,8 +406,8 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         }
         auto propagate = [&]() { // (rare; at most cnt rounds)
             for (;;) {
-                const uint32_t pp = __shfl_up(myp, 1, 64);
-                const uint32_t kk = __shfl_up(known ? 1u : 0u, 1, 64); // (every lane takes part in the shuffle)
+                const uint32_t pp = wave_prev(myp, DEAD);
+                const uint32_t kk = wave_prev(known ? 1u : 0u, 0u); // (DPP moves across the wave: no LDS round trip)
                 const bool pk = lane != 0u && kk != 0u;
                 const bool now = !known && pk;
                 if (now) {
@@ -422,9 +423,9 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         // unanimous (whatever I am entered at myself), else -- a stream whose every chunk keeps its 17 chains apart --
         // the map from my entry phase to it, for my successors to go through while I still wait for mine.
         const bool full = cnt == DEC_CH;
-        const bool exit_known = __shfl(known ? 1u : 0u, static_cast<int>(DEC_CH), 64) != 0u;
+        const bool exit_known = wave_lane(known ? 1u : 0u, DEC_CH) != 0u;
         if (full && exit_known) {
-            const uint32_t xp = __shfl(myp, static_cast<int>(DEC_CH), 64);
+            const uint32_t xp = wave_lane(myp, DEC_CH);
             if (lane == 0)
                 look_put(look.ex + lme, epoch, (EX_PHASE << 30) | xp);
         } else if (full) {
@@ -499,14 +500,14 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
             }
             propagate();
         }
-        const uint32_t lastp = full ? __shfl(myp, static_cast<int>(DEC_CH), 64) : DEAD; // the segment's exit phase: what the next one is entered at
+        const uint32_t lastp = full ? wave_lane(myp, DEC_CH) : DEAD; // the segment's exit phase: what the next one is entered at
         K6_STAMP(10, 256);
 
         // ---- the true chain, a quarter chunk per lane (chunk j = lane / 4, quarter r = lane % 4): where it crosses into
         // the quarter (its chunk's entry through the quarters in front), then how many records it starts there
         const uint32_t uj = lane >> 2, ur = lane & 3u;
         const uint32_t cph = __shfl(myp, static_cast<int>(uj), 64);             // entry phase of my chunk
-        const uint32_t aph = __shfl(myp, static_cast<int>(DEC_CH), 64);         // ... of the chunk behind a full segment
+        const uint32_t aph = wave_lane(myp, DEC_CH);                            // ... of the chunk behind a full segment
         uint32_t qp = cph;
         {
             const uint8_t *qx = s_qx + (uj + 1u) * 4u * PHASES6;
@@ -569,14 +570,8 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         }
         K6_STAMP(11, 256);
         // records in front of my quarter within the segment, and those of the whole segment
-        uint32_t incl = qn;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t o = __shfl_up(incl, d, 64);
-            incl += lane >= static_cast<uint32_t>(d) ? o : 0u;
-        }
-        const uint32_t qfirst = incl - qn;
-        const uint32_t total = __shfl(incl, 63, 64); // (quarters behind the stream add nothing)
+        uint32_t total; // (quarters behind the stream add nothing)
+        const uint32_t qfirst = wave_excl_scan(qn, lane, &total);
         // first record index: records of the frame's earlier segments, 64 of them per poll
         uint32_t base = 0;
         if (seg) {
@@ -600,10 +595,8 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                     __builtin_amdgcn_s_sleep(2);
                     continue;
                 }
-                uint32_t add = lane <= np ? (w >> 5) & 0xFFFFFFu : 0u;
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1)
-                    add += __shfl_xor(add, d, 64);
+                uint32_t add;
+                (void)wave_excl_scan(lane <= np ? (w >> 5) & 0xFFFFFFu : 0u, lane, &add);
                 base = min(base + add, 0xFFFFFFu);
                 if (np < 64u)
                     break;
@@ -628,11 +621,14 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
 #endif
             look_put(res, epoch, (RES_PREFIX << 30) | (endn << 5) | (lost ? DEAD : lastp));
         const uint32_t qi = min(base + qfirst, 0xFFFFFFu); // index of my quarter's first record
-        s_ent4[lane] = qp | (qi << 8);
+        const uint32_t ent4v = qp | (qi << 8);
+        const uint32_t entv = uj <= cnt && !lost ? (cph | (qi << 8)) : DEAD;            // (lanes with ur == 0: chunk uj's)
+        const uint32_t ent16 = cnt == DEC_CH && !lost ? (aph | (endn << 8)) : DEAD;     // ... and of the chunk behind a full segment
+        s_ent4[lane] = ent4v;
         if (ur == 0u)
-            s_ent[uj] = uj <= cnt && !lost ? (cph | (qi << 8)) : DEAD;
-        if (lane == 0) // ... and of the chunk behind a full segment
-            s_ent[DEC_CH] = cnt == DEC_CH && !lost ? (aph | (endn << 8)) : DEAD;
+            s_ent[uj] = entv;
+        if (lane == 0)
+            s_ent[DEC_CH] = ent16;
         // fewer records than height * recs_per_row inside `len`: the reference would
         // skip the rest and return stale rows (RawData_Legacy.cpp:387-388)
         if (lane == 0 && cfirst + cnt >= nchunks && endn < nrec && !lost)
@@ -643,10 +639,17 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         // chunk from where the true chain crosses into it -- 18 dependent steps instead of a chunk's 70, on ONE wave
         // (a walk costs a wave its issue slots whatever the number of walking lanes).  The walk tables are dead by now:
         // their LDS holds the lists.
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
+        // (what this wave needs of the entries it has just stored, it takes from its registers: a wait for the LDS here would
+        // also wait for the look-back words' way to memory -- stores count on the same counter)
         const uint32_t uw = lane / (4u * ROWS_CH), j = (lane >> 2) & (ROWS_CH - 1u), r = lane & 3u;
-        const Range6 rg = range_of(uw);
+        static_assert(ROWS_CH == 4, "an unpacking wave's chunks are sixteen lanes of this wave");
+        const uint32_t ew0 = wave_lane(entv, 0u), ew1 = wave_lane(entv, 16u), ew2 = wave_lane(entv, 32u), ew3 = wave_lane(entv, 48u);
+        auto ent_reg = [&](uint32_t w) { // entry of chunk w * ROWS_CH, as ent_of() will read it
+            const uint32_t v = w == 0u ? ew0 : w == 1u ? ew1 : w == 2u ? ew2 : w == 3u ? ew3 : ent16;
+            return cfirst + w * ROWS_CH < nchunks ? v : DEAD;
+        };
+        const uint32_t enext_reg = ent_reg(uw + 1u);
+        const Range6 rg = range_from(uw, ent_reg(uw), enext_reg);
         const bool coop = __ballot(!rg.lean) == 0ull;
         if (lane == 0)
             s_coop = coop ? 1u : 0u;
@@ -666,7 +669,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                 const uint32_t kb = qn & 7u, gp = qn >> 3;
                 // the next quarter's first eight notes, 128 half positions further on (lane 63: the chunk behind the segment
                 // is entered at phase `aph`)
-                uint32_t x0 = __shfl_down(nb[0], 1, 64), x1 = __shfl_down(nb[1], 1, 64);
+                uint32_t x0 = wave_next(nb[0], 0u), x1 = wave_next(nb[1], 0u);
                 x0 = (lane == 63u ? aph & 31u : x0) | 0x80808080u;
                 x1 |= 0x80808080u;
                 const uint64_t nx = (static_cast<uint64_t>(x1) << 32) | x0;
@@ -697,9 +700,9 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
             // behind a wave's last record: the next wave's first one (the partner of the wave's last record when its range
             // ends on an even one; a lane whose records end on a group boundary has stored nothing behind them)
             if (j == ROWS_CH - 1u && r == 3u)
-                lp[qn] = static_cast<uint16_t>(ROWS_CH * CHUNK6 + 2u * (ent_of(uw * ROWS_CH + ROWS_CH) & 255u));
+                lp[qn] = static_cast<uint16_t>(ROWS_CH * CHUNK6 + 2u * (enext_reg & 255u));
         } else if (K6_ABL != 3 && K6_ABL < 5 && coop) {
-            const uint32_t ej = s_ent4[lane], first = rg.R0;
+            const uint32_t ej = ent4v, first = rg.R0;
             const uint8_t *base = s_own + uw * (ROWS_CH * CHUNK6);
             const uint8_t *p = base + j * CHUNK6 + r * (CHUNK6 / 4u) + 2u * (ej & 255u);
             const uint8_t *const pe = base + j * CHUNK6 + (r + 1u) * (CHUNK6 / 4u);
