@@ -440,7 +440,7 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         // two: wrong lanes are few and seldom neighbours, and a corrected lane mostly leaves its segment where it did before.
         uint32_t src = SEG_NONE; // where a lane that walked again started from (its chain may end right there)
         for (uint32_t round = 0; round < 64u; round++) { // (the lowest wrong lane is right after every round)
-            const uint32_t want = static_cast<uint32_t>(__shfl_up(static_cast<int>(ex), 1, 64));
+            const uint32_t want = wave_prev(ex, ex); // (lane 0: its own, never looked at -- it is on the chain)
             const uint32_t claim = src != SEG_NONE ? src : ent != SEG_NONE ? ent : ex;
             const bool bad = act && !on_chain && claim != want;
             if (__ballot(bad) == 0ull)
