@@ -130,8 +130,7 @@ constexpr uint32_t DEC_CH = 4 * ROWS_CH;  // chunks per workgroup: four unpackin
 constexpr uint32_t DEC_T = 320;           // ... and a fifth wave: (DEC_CH + 1) * 17 = 289 map walks need five
 constexpr uint32_t RUN6 = 16;              // table entry at the first of sixteen 2-byte records in a row: jump over them (no record has this stride)
 constexpr uint32_t QTAB = HALF6 / 4;      // byte walk table of a quarter chunk: 128 strides (a walk that has left its quarter is held
-                                          // by a select in the walk, not by zeros behind the table: those 2.7 KB decide whether five or six
-                                          // workgroups fit a CU)
+                                          // by a select in the walk, not by zeros behind the table)
 constexpr uint32_t TABQ = 4 * QTAB + 16;  // ... of a chunk (+ 16: the tables of neighbouring chunks, which one wave walks at about the same
                                           // positions, start 4 LDS banks apart)
 static_assert((DEC_CH + 1) * PHASES6 <= DEC_T, "one thread per (chunk, phase)");
@@ -180,8 +179,8 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     __shared__ uint8_t s_cx[(DEC_CH + 1) * PHASES6];     // [chunk][entry phase] = exit phase: the four composed
     __shared__ uint32_t s_exits[DEC_CH + 1]; // per chunk: the set of exit phases its 17 walks reach, one bit each
     // entry of my chunks and of the one behind them (phase | first record << 8), and of every quarter of my chunks: written
-    // behind the look-back, when the exit sets and the quarters' maps have served -- they take their LDS (six workgroups per CU
-    // need every one of the 27 136 bytes)
+    // behind the look-back, when the exit sets and the quarters' maps have served -- they take their LDS (26 996 bytes in all: LDS is
+    // handed out in units of 1 280 bytes, five workgroups per CU up to 32 768; six would need <= 26 880 and are no faster)
     uint32_t *const s_ent = s_exits;
     uint32_t *const s_ent4 = reinterpret_cast<uint32_t *>(s_qx);
     static_assert(sizeof(s_qx) >= DEC_CH * 4 * sizeof(uint32_t), "the quarters' entries fit where their maps were");
