@@ -180,6 +180,27 @@ def test_flat_frames_densest_chains(gpu_ctx):
     _check(gpu_ctx, items, expect)
 
 
+def test_legacy_frames_of_one_record_size_each_over_several_segments(gpu_ctx):
+    # every record of a frame has the same size (header nibble forced): the lists of k6_decode's unpacking waves then hold
+    # 120 .. 2048 records per wave, on both sides of every threshold of the lean path -- single-round lists with and
+    # without the fifth wave's share of the tasks (384 tasks), one entry per record pair (512 records), several rounds
+    # (1024) -- and frames of 5 .. 40 segments, the last one partly filled
+    items, expect = [], []
+    rng = np.random.default_rng(66)
+    for nib in range(16):
+        nb = nib if nib <= 10 else 16
+        w = 1024 + 32 * nib
+        h = max(96, int(6 * 16384 / (2 + 2 * nb) * 16 / w) + 1 + nib) # at least six segments of 16 KiB
+        img = rng.integers(0, 1 << max(nb, 1), size=(h, w), dtype=np.uint16) if nb else np.full((h, w), 321, np.uint16)
+        nrec = ((w + 31) // 32) * 2 * h
+        buf = L.encode6(img, np.full(nrec, nib, np.uint8))
+        ret, out = L.oracle_decode6(buf, w, h)
+        assert ret == w * h and np.array_equal(out, img)
+        items.append((6, w, h, buf))
+        expect.append((ret, out))
+    _check(gpu_ctx, items, expect)
+
+
 def test_flat_and_textured_bands_mix_dense_and_sparse_chunks(gpu_ctx):
     # bands of constant rows between bands of noise: the side streams alternate between runs of
     # 2-byte records (dense chunks, listed by pointer doubling) and ordinary records (sparse chunks,
