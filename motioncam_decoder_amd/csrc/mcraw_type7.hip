@@ -238,7 +238,11 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     __shared__ uint2 s_seg[64]; // segment walkers: {first record of the segment | records in it << 16, records of the piece in front of it}
     __shared__ int32_t s_err;
 
-    const uint32_t fs = blockIdx.x, f = fs >> 1, s = fs & 1u;
+    // First one side stream of every frame, then the other.  At 240 frames two workgroups share a CU, and they are the ones
+    // 256 apart in the launch: with the streams of a frame side by side (2 f + s) those were two of the same kind -- two long
+    // ones on half of the CUs --, now they are one of each: k7_side 71 -> 67 us (six interleaved pairs of runs, tools/ab.sh).
+    const uint32_t nfr = static_cast<uint32_t>(W.n7);
+    const uint32_t s = blockIdx.x >= nfr ? 1u : 0u, f = blockIdx.x - (s ? nfr : 0u), fs = 2u * f + s;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef MCRAW_DIAG
