@@ -236,7 +236,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
 #pragma unroll
         for (uint32_t r = 0; r < NROUND; r++) {
             const uint32_t i = tid + r * DEC_T;
-            v[r] = (seg || i >= CHUNK6 / 16u) ? ld_b128(rs, seg * (DEC_CH * CHUNK6) - CHUNK6 + i * 16u) : make_uint4(0u, 0u, 0u, 0u);
+            v[r] = (seg || i >= CHUNK6 / 16u) ? ld_b128_nt(rs, seg * (DEC_CH * CHUNK6) - CHUNK6 + i * 16u) : make_uint4(0u, 0u, 0u, 0u);
         }
     };
     fetch();
