@@ -160,7 +160,7 @@ __device__ uint32_t g_k6_prof[K6_PROF_WG][K6_PROF_N];
 // workgroups that are running or done, whatever order the hardware starts workgroups in.  (One counter per frame,
 // each in its own 256 bytes: one counter for the batch serialised the launch -- 31 000 device-scope atomics on one
 // address took 0.37 ms.)  Five waves: 17 x 17 map walks need 289 threads; the fifth wave then resolves the entries
-// while the other four wait, and leaves; those four unpack.
+// while the other four wait; those four unpack their chunks, and the fifth a share of every list (TAIL6).
 template <int POST> // 0 = the plain mosaic, else bits per sample of the post stage's rows
 __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ plans, const uint32_t *__restrict__ wg_tab,
                                                    uint32_t stage0, const Look6 look, uint32_t *__restrict__ tickets,
