@@ -251,7 +251,7 @@ def link_probe(torch, dev, nbytes=256 << 20, reps=3):
     return {"h2d_GBs": round(up, 1), "d2h_GBs": round(down, 1), "each_way_when_both_GBs": round(duplex, 1)}
 
 
-def mixed64_leg(torch, ctx, M, L, dev, reps=5):
+def mixed64_leg(torch, ctx, M, L, dev, reps=40):
     """BASELINE config 4, timed: 64 frames, 14-bit type 7 (U and Nat) interleaved with legacy frames (10/12/14-bit,
     one width with w % 32 != 0), 1920x1080 and 12 MP; verified against the images the encoder was given."""
     items = []
@@ -273,17 +273,21 @@ def mixed64_leg(torch, ctx, M, L, dev, reps=5):
     ok = all(s == 0 for s in status)
     for i, it in enumerate(items):
         ok = ok and np.array_equal(tout[i].cpu().numpy().view(np.uint16).reshape(it[1].shape), it[1])
+    ctx.profile(False) # (no events between the batches: they follow each other on the stream, as the bench line's steps do)
+    for _ in range(3):
+        ctx.decode_batch(frames, want_status=False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
         ctx.decode_batch(frames, want_status=False)
     torch.cuda.synchronize()
     t = (time.perf_counter() - t0) / reps
+    ctx.profile(True)
     px = sum(it[1].size for it in items)
     byts = sum(it[2].size for it in items) + 2 * px
     return {"workload": "config 4: 64 frames, type 7 (14-bit U/Nat) and type 6 (10/12/14-bit) interleaved, 1920x1080 / 4032x3024 / 4000x3000",
-            "ms_per_batch": round(t * 1e3, 4), "mpix_s": round(px / t / 1e6, 1), "in_plus_out_GBs": round(byts / t / 1e9, 1),
-            "bit_exact": bool(ok)}
+            "ms_per_batch": round(t * 1e3, 4), "batches_timed": reps, "mpix_s": round(px / t / 1e6, 1),
+            "in_plus_out_GBs": round(byts / t / 1e9, 1), "bit_exact": bool(ok)}
 
 
 def cpu_baseline(L, wl, seconds):
@@ -532,7 +536,7 @@ def post_stage(torch, ctx, M, L, wl, steps):
         ctx.profile(True)
 
 
-def legacy_leg(torch, ctx, M, L, dev, n=32, w=4000, h=3000, nbits=12, sigma=12.0, reps=10):
+def legacy_leg(torch, ctx, M, L, dev, n=32, w=4000, h=3000, nbits=12, sigma=12.0, reps=40):
     """The legacy (type 6) encoding on a BASELINE config 4 geometry (width % 32 != 0): not the bench line,
     reported so that both codecs of the path are measured by the same program."""
     imgs = [L.synth_image(w, h, nbits, 1, sigma, 6000 + i) for i in range(4)]
@@ -546,18 +550,29 @@ def legacy_leg(torch, ctx, M, L, dev, n=32, w=4000, h=3000, nbits=12, sigma=12.0
     for i in (0, n - 1):
         got = tout[i * w * h * 2:(i + 1) * w * h * 2].cpu().numpy().view(np.uint16).reshape(h, w)
         ok = ok and np.array_equal(got, imgs[i % 4])
-    ctx.profile(True)
-    for k in M.KERNELS:
-        ctx.kernel_ms(k, reset=True)
+    # wall time of batches that follow each other on the stream, no events between them (as the bench line's steps are
+    # timed); then the kernel alone from a sample of launches bracketed by events (every 4th: an event pair costs the stream
+    # a few microseconds and keeps the next launch from starting while the previous one drains)
+    ctx.profile(False)
+    for _ in range(3):
+        ctx.decode_batch(frames, want_status=False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
         ctx.decode_batch(frames, want_status=False)
     torch.cuda.synchronize()
     t = (time.perf_counter() - t0) / reps
-    kms = {k: round(ctx.kernel_ms(k, reset=True)[0] / reps, 4) for k in ("k6_decode",)}
+    ctx.profile(only=("k6_decode",), every=4)
+    ctx.kernel_ms("k6_decode", reset=True)
+    for _ in range(16):
+        ctx.decode_batch(frames, want_status=False)
+    torch.cuda.synchronize()
+    kt, kn = ctx.kernel_ms("k6_decode", reset=True)
+    kms = {"k6_decode": round(kt / max(kn, 1), 4)}
+    ctx.profile(True)
     byts = sum(bufs[i % 4].size for i in range(n)) + n * w * h * 2
     out = {"workload": "%d x %dx%d %d-bit type-6 frames, Nat" % (n, w, h, nbits), "ms_per_batch": round(t * 1e3, 4),
+           "batches_timed": reps, "kernel_launches_sampled": kn,
            "mpix_s": round(n * w * h / t / 1e6, 1), "in_plus_out_GBs": round(byts / t / 1e9, 1),
            "input_bpp": round(8.0 * bufs[0].size / (w * h), 2), "kernels_ms": kms, "bit_exact": bool(ok)}
     # the same roofline figures as for the bench line: the batch (wall) and its one kernel against the HBM peak, and the
