@@ -220,6 +220,21 @@ __device__ __forceinline__ MCRAW_GLOBAL V *gptr(T *p)
     return (MCRAW_GLOBAL V *)p;
 }
 
+// The decoded rows are written once and never read again by these kernels: 16 (12) bytes per lane as a write-through,
+// streaming store (`sc1 nt`: the line does not stay in the XCD's L2, which then holds more of what is being READ; with `nt`
+// alone the line stays -- MI355X_MICROARCH.md, "stores of each flavour").  k7_tiles: 0.971 -> 0.958 ms on one box, six
+// interleaved pairs of fresh processes (tools/store_sc.sh); `sc1` without `nt` is no faster than `nt`.
+typedef uint32_t mcraw_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t mcraw_u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ void store_stream16(void *dst, mcraw_u32x4 v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(dst), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store_stream12(void *dst, mcraw_u32x3 v)
+{
+    asm volatile("global_store_dwordx3 %0, %1, off sc1 nt" ::"v"(dst), "v"(v) : "memory");
+}
+
 // Bytes [0, nb) of the dwords o[] to dst, the last one masked by `last` (the cropped end of a strip row).
 __device__ __forceinline__ void post_store_bytes(uint8_t *dst, const uint32_t *o, uint32_t nb, uint32_t last, uint32_t maxb)
 {
@@ -274,7 +289,7 @@ __device__ __forceinline__ void post_store8(uint16_t *out, const Post &post, uin
             typedef uint32_t u32x3 __attribute__((ext_vector_type(3), aligned(4)));
             const u32x3 v = {o[0], o[1], o[2]};
             if (NT)
-                __builtin_nontemporal_store(v, gptr<u32x3>(dst));
+                store_stream12(dst, v);
             else
                 *gptr<u32x3>(dst) = v;
         } else if (n == 8u) { // a strip row off the dword grid: one unaligned 12-byte store
@@ -299,7 +314,7 @@ __device__ __forceinline__ void post_store8(uint16_t *out, const Post &post, uin
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         const u32x4 v = {p[0], p[1], p[2], p[3]};
         if (NT)
-            __builtin_nontemporal_store(v, gptr<u32x4>(dst));
+            store_stream16(dst, v);
         else
             *gptr<u32x4>(dst) = v;
     } else if (n == 8u) { // rows off the 16-byte grid: one unaligned 16-byte store

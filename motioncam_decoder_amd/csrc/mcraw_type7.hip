@@ -818,7 +818,7 @@ __device__ __forceinline__ void store_px8(const ItemS &I, const Post &post, uint
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         const u32x4 v = {p[0], p[1], p[2], p[3]};
         if (NT)
-            __builtin_nontemporal_store(v, gptr<u32x4>(dst));
+            store_stream16(dst, v);
         else
             *gptr<u32x4>(dst) = v;
     } else if (x + 8u <= width) {
