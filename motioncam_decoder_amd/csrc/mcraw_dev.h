@@ -224,15 +224,18 @@ __device__ __forceinline__ MCRAW_GLOBAL V *gptr(T *p)
 // streaming store (`sc1 nt`: the line does not stay in the XCD's L2, which then holds more of what is being READ; with `nt`
 // alone the line stays -- MI355X_MICROARCH.md, "stores of each flavour").  k7_tiles: 0.971 -> 0.958 ms on one box, six
 // interleaved pairs of fresh processes (tools/store_sc.sh); `sc1` without `nt` is no faster than `nt`.
+#ifndef MCRAW_STORE_POLICY
+#define MCRAW_STORE_POLICY "sc1 nt" // (tools/store_sc.sh builds the library with others)
+#endif
 typedef uint32_t mcraw_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t mcraw_u32x3 __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ void store_stream16(void *dst, mcraw_u32x4 v)
 {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(dst), "v"(v) : "memory");
+    asm volatile("global_store_dwordx4 %0, %1, off " MCRAW_STORE_POLICY ::"v"(dst), "v"(v) : "memory");
 }
 __device__ __forceinline__ void store_stream12(void *dst, mcraw_u32x3 v)
 {
-    asm volatile("global_store_dwordx3 %0, %1, off sc1 nt" ::"v"(dst), "v"(v) : "memory");
+    asm volatile("global_store_dwordx3 %0, %1, off " MCRAW_STORE_POLICY ::"v"(dst), "v"(v) : "memory");
 }
 
 // Bytes [0, nb) of the dwords o[] to dst, the last one masked by `last` (the cropped end of a strip row).
