@@ -231,11 +231,13 @@ typedef uint32_t mcraw_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t mcraw_u32x3 __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ void store_stream16(void *dst, mcraw_u32x4 v)
 {
-    asm volatile("global_store_dwordx4 %0, %1, off " MCRAW_STORE_POLICY ::"v"(dst), "v"(v) : "memory");
+    // (the string ends with s_nop 1: nothing inside an asm statement is padded, and the compiler's next instruction may
+    // otherwise overwrite the data registers of a store of more than 8 bytes before the store has read them)
+    asm volatile("global_store_dwordx4 %0, %1, off " MCRAW_STORE_POLICY "\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
 }
 __device__ __forceinline__ void store_stream12(void *dst, mcraw_u32x3 v)
 {
-    asm volatile("global_store_dwordx3 %0, %1, off " MCRAW_STORE_POLICY ::"v"(dst), "v"(v) : "memory");
+    asm volatile("global_store_dwordx3 %0, %1, off " MCRAW_STORE_POLICY "\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
 }
 
 // Bytes [0, nb) of the dwords o[] to dst, the last one masked by `last` (the cropped end of a strip row).
