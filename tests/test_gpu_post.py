@@ -35,6 +35,7 @@ def _run(ctx, items, black, pack12, misalign=0, mem=M.MEM_DEVICE, bits=None):
                 keep += [a_in, a_out]
                 descs.append((a_in.ctypes.data, a_in.size, w, h, typ, a_out.ctypes.data + misalign, cap16))
                 outs.append(a_out)
+        torch.cuda.synchronize() # (the fills above run on torch's stream, the batch on the context's own)
         written, status = ctx.decode_batch(M.Context.make_frames(descs), mem=mem)
         torch.cuda.synchronize()
         res = []
@@ -141,3 +142,38 @@ def test_at_most_one_strip_width(gpu_ctx):
     p.flags = M.POST_PACK10 | M.POST_PACK12
     assert gpu_ctx._lib.mcraw_ctx_set_post(gpu_ctx._h, C.byref(p)) != 0
     gpu_ctx.set_post()
+
+
+@pytest.mark.parametrize("bits", [12, None])
+def test_post_stage_large_batch_under_load(gpu_ctx, bits):
+    """120 UHD frames per batch, every frame checked (on the GPU, against an upload of the oracle's rows): what goes wrong only
+    when the memory pipeline is backed up -- a store whose data registers are overwritten before it has read them wrote wrong
+    12-bit strips for the bench's 240-frame batch while every small-frame test passed."""
+    dev = torch.device("cuda:0")
+    w, h, n, distinct = 3840, 2160, 120, 4
+    black = [64, 60, 68, 72]
+    imgs = [L.synth_image(w, h, 12, 1, 12.0, 900 + i) for i in range(distinct)]
+    bufs = [L.encode7(im) for im in imgs]
+    want = [torch.from_numpy(np.ascontiguousarray(L.oracle_post(im, black, bits == 12))).to(dev) for im in imgs]
+    rb = L.post_row_bytes(w, bits == 12)
+    cap16 = (h * rb + 1) // 2
+    t_in = [torch.from_numpy(b).to(dev) for b in bufs]
+    t_out = torch.zeros(n * cap16 * 2, dtype=torch.uint8, device=dev)
+    descs = [(t_in[i % distinct].data_ptr(), t_in[i % distinct].numel(), w, h, 7, t_out.data_ptr() + i * cap16 * 2, cap16) for i in range(n)]
+    frames = M.Context.make_frames(descs)
+    gpu_ctx.set_post(black=black, bits=bits)
+    try:
+        for rnd in range(3):
+            t_out.zero_()
+            torch.cuda.synchronize() # (the batch runs on the context's own stream, not on torch's)
+            written, status = gpu_ctx.decode_batch(frames)
+            torch.cuda.synchronize()
+            assert all(s == 0 for s in status) and all(wr == w * h for wr in written)
+            for i in range(n):
+                got = t_out[i * cap16 * 2: i * cap16 * 2 + h * rb].view(h, rb)
+                if not torch.equal(got, want[i % distinct]):
+                    bad = (got != want[i % distinct]).nonzero()
+                    raise AssertionError("bits %s round %d frame %d: %d bytes differ, first at (row, byte) %s" %
+                                         (bits, rnd, i, bad.shape[0], bad[:4].tolist()))
+    finally:
+        gpu_ctx.set_post()
