@@ -4,18 +4,17 @@
 //
 // The legacy stream is ONE chain of 16-sample records with inline 2-byte
 // headers (RawData_Legacy.cpp:377-442): record i+1 starts where record i ends.
-// A frame holds ~w*h/16 of them, so the chain is resolved in parallel with
-// transition maps: record strides are even and <= 34 bytes, so a fixed 1 KiB
-// chunk of the stream can be entered at only 17 offsets ("phases" 0,2,..,32).
+// A frame holds ~w*h/16 of them.  Record strides are even and <= 34 bytes, so a chain
+// can cross any given byte of the stream at only 17 offsets ("phases" 0,2,..,32), and a chain that
+// starts on a byte that is no record start reads payload bytes as headers and falls onto the true
+// chain within a few hundred bytes.
 //
-// One kernel, one pass over the stream (k6_decode): a workgroup stages 16 chunks, walks all 17 phases of
-// each (and of the chunk in front of them) over a byte table of record strides -> per chunk and phase the exit
-// phase and the records started; finds where the TRUE chain enters its chunks -- the map of the chunk in front of a
-// chunk almost always sends all 17 phases to one exit, because a wrong chain reads payload bytes as headers and
-// falls onto the true one within a few hundred bytes -- and the index of its first record by decoupled look-back
-// over the frame's earlier workgroups; lists the records of its chunks from those entries and unpacks them
-// (MSB-first bitstreams, RawData_Legacy.cpp:38-370), adds the references, interleaves even/odd columns (:483-486)
-// and crops the padded row (:490).
+// One kernel, one pass over the stream (k6_decode): a workgroup stages 16 KiB of it (and the KiB in front),
+// lets 64 lanes walk it speculatively -- a quarter KiB each, from a start half a KiB further up --, verifies the
+// lanes against each other and against the one chain that the 17 possible chains of the KiB in front have become,
+// gets the index of its first record by decoupled look-back over the frame's earlier workgroups, lists the records
+// and unpacks them (MSB-first bitstreams, RawData_Legacy.cpp:38-370), adds the references, interleaves even/odd
+// columns (:483-486) and crops the padded row (:490).
 #include "mcraw_dev.h"
 
 #include <cstdlib>
@@ -28,18 +27,6 @@ constexpr uint32_t DEAD = 31; // phase value: the chain ended (a record crossed 
 
 // Payload bytes of a record whose header nibble is `b` (RawData_Legacy.cpp:13-32).
 __device__ __forceinline__ uint32_t len6_of(uint32_t b) { return b <= 10u ? 2u * b : 32u; }
-
-constexpr uint32_t HALF6 = CHUNK6 / 2; // even byte positions ("half positions") per chunk
-
-// Stride of the record whose header byte is `b`, in half positions: (2 + LEN)/2 = 1 + bits for
-// bits <= 10, 17 above (RawData_Legacy.cpp:13-32).  Four header bytes per call, one per byte lane.
-__device__ __forceinline__ uint32_t stride4(uint32_t hdr4)
-{
-    const uint32_t x = (hdr4 >> 4) & 0x0F0F0F0Fu;
-    const uint32_t g = ((x + 0x05050505u) >> 4) & 0x01010101u;
-    const uint32_t big = byte_mask(g); // 0xFF in the byte lanes where bits >= 11
-    return (big & 0x11111111u) | (~big & (x + 0x01010101u));
-}
 
 // 24-bit x 24-bit multiply, low 32 bits (full rate).  __umul24 of a per-lane and a uniform operand comes out of the compiler as
 // v_and + v_mul_lo_u32, which issues at a quarter of the rate.
@@ -121,24 +108,105 @@ constexpr uint32_t ROWS_CAP = 256u * ROWS_CH; // records per round (typical: ~70
 static_assert(ROWS_CAP <= 1024u && ROWS_CAP % 2u == 0u, "the division-free row arithmetic of the unpack assumes at most 512 pairs per round");
 
 #ifndef K6_ABL
-#define K6_ABL 0 // timing experiments only: 1 no stores, 3 no walk, 5 the front alone (no bytes in LDS, waves 0-3 leave behind the maps, no unpack), 6 the same with the waves staying
+#define K6_ABL 0 // timing experiments only (wrong pixels): 1 no stores, 2 no unpack, 3 no record lists, 4 load + stage only, 8 no ticket
 #endif
 
 // ------------------------------------------------------------------ k6_decode
-constexpr uint32_t TAIL6 = 128;           // tasks (8 pixels each) of every unpacking wave's list that the fifth wave takes over
+constexpr uint32_t TAIL6 = 128;           // (five-wave form) tasks (8 pixels each) of every unpacking wave's list that the fifth wave takes over
 constexpr uint32_t DEC_CH = 4 * ROWS_CH;  // chunks per workgroup: four unpacking waves
-constexpr uint32_t DEC_T = 320;           // ... and a fifth wave: (DEC_CH + 1) * 17 = 289 map walks need five
-constexpr uint32_t RUN6 = 16;              // table entry at the first of sixteen 2-byte records in a row: jump over them (no record has this stride)
-constexpr uint32_t QTAB = HALF6 / 4;      // byte walk table of a quarter chunk: 128 strides (a walk that has left its quarter is held
-                                          // by a select in the walk, not by zeros behind the table)
-constexpr uint32_t TABQ = 4 * QTAB + 16;  // ... of a chunk (+ 16: the tables of neighbouring chunks, which one wave walks at about the same
-                                          // positions, start 4 LDS banks apart)
-static_assert((DEC_CH + 1) * PHASES6 <= DEC_T, "one thread per (chunk, phase)");
+#ifndef MCRAW_K6_WAVES
+#define MCRAW_K6_WAVES 4
+#endif
+// Waves per workgroup.  Four: the last wave resolves the chain, then unpacks its chunks like the others (seven workgroups fit a CU:
+// the kernel is a chain of latencies -- load, walk, look-back, lists, unpack --, and what hides them is the number of
+// segments in flight).  Five (rounds 2 and 3): a wave of its own resolves and then takes a share of every list.
+constexpr uint32_t DEC_T = 64 * MCRAW_K6_WAVES;
+constexpr bool FIFTH6 = DEC_T == 320;
+static_assert(DEC_T == 256 || DEC_T == 320, "four unpacking waves; the resolving wave is the last one");
+constexpr uint32_t FRONT6 = CHUNK6;       // bytes staged in front of the segment: the chains that cross into them have become one by the segment's start
+#ifndef MCRAW_WARM6
+#define MCRAW_WARM6 512
+#endif
+constexpr uint32_t WARM6 = MCRAW_WARM6;   // bytes in front of its quarter chunk at which a speculative walker starts (tools/k6_warm.sh)
+constexpr uint32_t QUART6 = CHUNK6 / 4;   // bytes of stream per walker
+constexpr uint32_t NQ6 = 4 * DEC_CH;      // walkers = quarter chunks per segment
+constexpr uint32_t NOFRONT = 255;         // s_front's boundary: the chains never became one inside this segment
+static_assert(NQ6 == 64, "one walker per lane of the resolving wave");
+static_assert(WARM6 <= FRONT6 && WARM6 % 2u == 0u && WARM6 >= 64u, "the walkers of the first quarter start inside the staged front");
+
+// Bytes from a record's header to the next record's (RawData_Legacy.cpp:13-32,377-442); `b` = the header's first byte.
+__device__ __forceinline__ uint32_t stride6(uint32_t b)
+{
+    const uint32_t hb = b >> 4;
+    return hb <= 10u ? 2u * hb + 2u : 34u;
+}
+
+// Where the record behind the one at byte P of the staged stream starts.  What can be computed from P alone (P + 2, P + 34) is
+// computed while the header byte is on its way from the LDS: behind the read the dependent chain is three instructions
+// (nibble, shift-add, select).
+__device__ __forceinline__ uint32_t next6(const uint8_t *st, uint32_t P)
+{
+    const uint32_t b = st[P];
+    uint32_t big = P + 34u, small = P + 2u;
+    asm volatile("" : "+v"(big), "+v"(small)); // (computed here, in front of the wait for the byte)
+    uint32_t n; // (both values exist: the select below stays a select -- as a branch over two arms it cost the walk half its speed)
+    asm volatile("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(n) : "v"(__builtin_amdgcn_ubfe(b, 4u, 4u)), "v"(small));
+    return b >= 0xB0u ? big : n;
+}
+
+// One step of a chain walk over the staged stream, the careful form, for segments that need it (wave-uniform): the record at
+// byte P -> bytes to the next one, 0 for a walk that has reached `bound` (it stays where it arrived: P - bound is the phase at
+// which the chain crosses the bound); a record that would reach the end of the stream is the chain's end
+// (RawData_Legacy.cpp:387-388,398-399: stride 0, the walk stays in front of it; `limP` = the stage position of `len`), and a
+// walk that stands on the first byte of a 16-byte piece made of eight 2-byte records (flat or clipped image regions: one bit
+// per piece in `flat`) passes all eight at once.  *n = records passed.
+__device__ __forceinline__ uint32_t step6(const uint8_t *st, const uint64_t *flat, uint32_t P, uint32_t bound, uint32_t limP, uint32_t *n)
+{
+    uint32_t t = stride6(st[P]);
+    const bool jump = (P & 15u) == 0u && P + 16u <= bound && ((flat[P >> 10] >> ((P >> 4) & 63u)) & 1ull) != 0ull;
+    t = jump ? 16u : t;
+    const uint32_t c = jump ? 8u : 1u;
+    t = P + t >= limP ? 0u : t;
+    t = P < bound ? t : 0u;
+    *n = t ? c : 0u;
+    return t;
+}
+
+// All lanes of a wave walk until every walk has reached its `bound` (or has died in front of the end of the stream).
+// Returns where the walk arrived: the first record start at or behind the bound (a dead walk: in front of it).
+// The fast form runs free -- nothing in the dependent chain holds a walk that has arrived; it notes its arrival and walks on
+// until the slowest lane is there, clamped to the stage.
+template <uint32_t CLAMP>
+__device__ __forceinline__ uint32_t walk_to6(bool careful, const uint8_t *st, const uint64_t *flat, uint32_t P, uint32_t bound, uint32_t limP)
+{
+    if (careful) {
+        uint32_t t, n;
+        do {
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                t = step6(st, flat, P, bound, limP, &n);
+                P += t;
+            }
+        } while (__any(t != 0u)); // (a walk that does not move never moves again)
+        return P;
+    }
+    uint32_t arr = P;
+    do {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint32_t Pn = next6(st, P);
+            arr = P < bound ? Pn : arr;
+            P = Pn;
+        }
+        P = min(P, CLAMP);
+    } while (__any(P < bound));
+    return arr;
+}
 
 #ifdef MCRAW_DIAG // phase stamps of every workgroup (timing experiments only; not in the product library)
 constexpr int K6_PROF_WG = 1 << 16;
 // [0..13]: stage stamps (s_memtime), [14] live, [15] look-back spins; [16], [17]: s_memrealtime (100 MHz) at wave 0's start and end;
-// [18 + w]: at wave w's end, its stores landed; [23], [24]: HW_ID, XCC_ID of wave 0; [27 + w]: HW_ID of wave w
+// [18 + w]: at wave w's end, its stores landed; [23], [24]: HW_ID, XCC_ID of wave 0; [25]: walk rounds of the resolving wave; [27 + w]: HW_ID of wave w
 constexpr int K6_PROF_N = 32;
 __device__ uint32_t g_k6_prof[K6_PROF_WG][K6_PROF_N];
 #define K6_STAMP(slot, who)                                                                                            \
@@ -159,39 +227,44 @@ __device__ uint32_t g_k6_prof[K6_PROF_WG][K6_PROF_N];
 // it) and takes its segment -- DEC_CH chunks -- from the frame's ticket counter: the segments it may have to wait on were all taken by
 // workgroups that are running or done, whatever order the hardware starts workgroups in.  (One counter per frame,
 // each in its own 256 bytes: one counter for the batch serialised the launch -- 31 000 device-scope atomics on one
-// address took 0.37 ms.)  Five waves: 17 x 17 map walks need 289 threads; the fifth wave then resolves the entries
-// while the other four wait; those four unpack their chunks, and the fifth a share of every list (TAIL6).
+// address took 0.37 ms.)
+//
+// Where the records of the segment start (round 4; rounds 1-3 built a table of record strides and walked all 17 phases of
+// every chunk over it: 17 walks per byte of stream).  A chain that starts on a byte that is no record start reads payload
+// bytes as headers and falls onto the true chain within a few hundred bytes, so:
+//  * SPECULATIVE WALKERS (fifth wave, lane = quarter chunk): every lane starts WARM6 bytes in front of its quarter on the
+//    stream bytes themselves (no table), notes at which phase it arrives, then walks its quarter: phase at which it leaves,
+//    records started, where they start.  Nothing is taken on trust: lane j's arrival must be lane j - 1's exit; every lane for
+//    which that fails walks its quarter again from where its predecessor says, all of them side by side, until nothing
+//    changes -- the lowest wrong lane is right for good after each round.
+//  * THE SURE ENTRY (fourth wave, 17 lanes): every chain that crosses into the KiB in front of the segment starts a record
+//    at one of 17 phases there; the 17 walks almost always arrive at the segment as ONE chain -- that arrival is the
+//    induction's start.  Where they do not (0.5 % of the segments of natural frames), they walk on, quarter by quarter, until
+//    they are one: the lanes behind that boundary are verified from there (the segment then says its exit phase at once),
+//    the ones in front of it wait for the segment in front to say at which phase it ends.  A stream whose chains never
+//    meet publishes the map entry phase -> exit phase instead, and its segments resolve in wave fronts of 64.
 template <int POST> // 0 = the plain mosaic, else bits per sample of the post stage's rows
 __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ plans, const uint32_t *__restrict__ wg_tab,
                                                    uint32_t stage0, const Look6 look, uint32_t *__restrict__ tickets,
                                                    uint32_t epoch, uint32_t nframes, uint32_t smax, const Post post)
 {
-    // the segment's stream: its DEC_CH chunks and the reach of a record that starts 32 bytes past them (the chunk in
-    // front of them, whose map tells where the segment is entered, only becomes a walk table)
+    // the segment's stream: the KiB in front of it, its DEC_CH chunks and the reach of a record that starts 32 bytes past them
     constexpr uint32_t OWN = DEC_CH * CHUNK6, SLACK = 64 + 32;
-    constexpr uint32_t NPIECE = (CHUNK6 + OWN + SLACK) / 16; // 16-byte pieces, piece 0 at stream offset (cfirst - 1) * CHUNK6
+    constexpr uint32_t NPIECE = (FRONT6 + OWN + SLACK) / 16; // 16-byte pieces, piece 0 at stream offset (cfirst - 1) * CHUNK6
     constexpr uint32_t NROUND = (NPIECE + DEC_T - 1) / DEC_T;
-    __shared__ __attribute__((aligned(16))) uint8_t s_own[OWN + SLACK];
-    // walk tables of the DEC_CH + 1 chunks, a quarter chunk at a time: 128 strides, then 32 zeros where a walk that
-    // has left the quarter stays; dead once the records are counted: the record lists take their place
-    __shared__ __attribute__((aligned(16))) uint8_t s_tab[(DEC_CH + 1) * TABQ];
-    __shared__ __attribute__((aligned(4))) uint8_t s_qx[(DEC_CH + 1) * 4 * PHASES6]; // [chunk][quarter][entry phase] = phase at which the quarter is left
-    __shared__ uint8_t s_cx[(DEC_CH + 1) * PHASES6];     // [chunk][entry phase] = exit phase: the four composed
-    __shared__ uint32_t s_exits[DEC_CH + 1]; // per chunk: the set of exit phases its 17 walks reach, one bit each
-    // entry of my chunks and of the one behind them (phase | first record << 8), and of every quarter of my chunks: written
-    // behind the look-back, when the exit sets and the quarters' maps have served -- they take their LDS (26 996 bytes in all: LDS is
-    // handed out in units of 1 280 bytes, five workgroups per CU up to 32 768; six would need <= 26 880 and are no faster)
-    uint32_t *const s_ent = s_exits;
-    uint32_t *const s_ent4 = reinterpret_cast<uint32_t *>(s_qx);
-    static_assert(sizeof(s_qx) >= DEC_CH * 4 * sizeof(uint32_t), "the quarters' entries fit where their maps were");
-    __shared__ uint32_t s_ticket, s_coop, s_runs;
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[FRONT6 + OWN + SLACK];
+    uint8_t *const s_own = s_stage + FRONT6;
+    __shared__ uint64_t s_flat[NROUND * (DEC_T / 64u)]; // one bit per staged piece: eight 2-byte records (piece i: bit i % 64 of word i / 64)
     // the list of a round, one of two layouts: every record r at [r - wlo] (up to ROWS_CAP / 2 records: the
     // common case, one LDS read gives both records of a pair), or one entry per PAIR at [(r - wlo) / 2]
     // holding the even record only (up to ROWS_CAP records; the unpacking lane finds the odd one behind it)
     typedef uint16_t PosList[ROWS_CAP / 2 + 2];
-    static_assert(sizeof(PosList) * 4 <= sizeof(s_tab), "the lists live where the walk tables were");
-    static_assert((DEC_CH + 1) * TABQ < 65536u, "table addresses fit the walkers' 16 bits");
-    PosList *const s_pos = reinterpret_cast<PosList *>(s_tab);
+    static_assert(sizeof(PosList) % 4u == 0u, "the lists are read as dwords");
+    __shared__ __attribute__((aligned(4))) PosList s_pos[4];
+    // entry of my chunks and of the one behind them (phase | first record << 8), and of every quarter of my chunks
+    __shared__ uint32_t s_ent[DEC_CH + 1], s_ent4[NQ6];
+    __shared__ uint8_t s_fmap[32]; // (only for streams whose chains never meet) my entry phase -> my exit phase
+    __shared__ uint32_t s_ticket, s_coop, s_front;
 
 #ifdef MCRAW_DIAG
     unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
@@ -212,6 +285,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
 #define K6_END()
 #endif
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    constexpr uint32_t RESOLVER = DEC_T / 64u - 1u; // the wave that resolves the chain
     // Which frame this workgroup works on, and the segment it will most likely be given: the launch goes over the
     // frames round by round -- round r = segment r of every frame that has one --, so a frame's segments start in order
     // and far apart, and no workgroup is launched for nothing however the frames' sizes differ (the host's table: the
@@ -221,139 +295,337 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     const uint32_t stage = all_in ? 0u : static_cast<uint32_t>(find_frame(blockIdx.x, wg_tab, static_cast<int>(nframes)));
     const uint32_t inplay = nframes - stage, wrel = all_in ? blockIdx.x : blockIdx.x - wg_tab[stage];
     const uint32_t f = all_in ? wrel % inplay : wg_tab[2u * nframes + 1u + wrel % inplay];
-    if (tid == 0) {
-        s_runs = 0u;
-        s_ticket = atomicAdd(tickets + f * TICKET_STRIDE6, 1u);
-    }
     const Plan6 *P = plans + f;
     const uint32_t nchunks = P->nchunks, nrec = P->nrec, len = P->len;
     const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
     // the ticket takes a round trip to the frame's counter: start loading what it will almost certainly say
     // (workgroups start in order), and load again if it says otherwise
+    if (tid == 0)
+        s_ticket = K6_ABL >= 8 ? 0u : atomicAdd(tickets + f * TICKET_STRIDE6, 1u);
     uint32_t seg = (all_in ? 0u : wg_tab[nframes + 1u + stage]) + wrel / inplay;
     uint4 v[NROUND];
     auto fetch = [&]() { // piece i at stream offset (seg * DEC_CH - 1) * CHUNK6 + 16 i; past `len`: reads 0
 #pragma unroll
         for (uint32_t r = 0; r < NROUND; r++) {
             const uint32_t i = tid + r * DEC_T;
-            v[r] = (seg || i >= CHUNK6 / 16u) ? ld_b128_nt(rs, seg * (DEC_CH * CHUNK6) - CHUNK6 + i * 16u) : make_uint4(0u, 0u, 0u, 0u);
+            // (streamed, but for the segment's last chunk: the next segment of this frame -- on this XCD when frames and XCDs
+            // go round in step -- reads it again as its front and then finds it in the L2)
+            const uint32_t off = seg * OWN - FRONT6 + i * 16u;
+            if (!(seg || i >= FRONT6 / 16u))
+                v[r] = make_uint4(0u, 0u, 0u, 0u);
+            else if (i >= (FRONT6 + OWN - CHUNK6) / 16u)
+                v[r] = ld_b128(rs, off);
+            else
+                v[r] = ld_b128_nt(rs, off);
         }
     };
     fetch();
     __syncthreads();
     K6_STAMP(0, 0);
-    K6_STAMP(8, 256);
-    if (s_ticket != seg) {
+    K6_STAMP(8, RESOLVER * 64u);
+    if (K6_ABL < 8 && s_ticket != seg) {
         seg = s_ticket;
         fetch();
     }
+
+    // ---- what the resolving wave finds out (lane = quarter chunk: chunk uj, quarter ur)
+    const uint32_t uj = lane >> 2, ur = lane & 3u;
+    const uint32_t qb = FRONT6 + lane * QUART6, qe = qb + QUART6;
+    constexpr uint32_t NOTES6 = 32;
+    uint32_t nb[NOTES6 / 4u] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}; // where my quarter's records start (half positions, a byte each)
+    uint32_t a = DEAD, x = DEAD, qn = 0u; // phases at which the chain enters and leaves my quarter; records it starts there
+    bool notes_ok = false, lost = false;
+    uint32_t spins = 0;
     const uint32_t cfirst = seg * DEC_CH;
     if (cfirst >= nchunks)
         return; // whole workgroup
+    const uint32_t cnt = min(static_cast<uint32_t>(DEC_CH), nchunks - cfirst);
+    const bool full = cnt == DEC_CH;
+    // stage position of the stream's end (the stage starts FRONT6 bytes in front of the segment; cfirst * CHUNK6 < len)
+    const uint32_t limP = len - cfirst * CHUNK6 + FRONT6;
+    {
+        const bool near_end = limP < FRONT6 + OWN + SLACK + 64u; // a record this workgroup walks over can reach `len`
 
-    // ---- stage the stream and turn it into the walk tables (one byte per even position: the record stride in half
-    // positions; 32 zeros behind every chunk, where a walk that has left the chunk stays)
+        // ---- stage the stream; note which pieces are eight 2-byte records in a row (a flat or clipped image region would
+        // otherwise cost a step per record, 128 per quarter)
 #pragma unroll
-    for (uint32_t r = 0; r < NROUND; r++) {
-        const uint32_t i = tid + r * DEC_T;
-        uint32_t lo = 0, hi = 0;
-        uint8_t *dst = nullptr;
-        bool ones = false;
-        if (i < NPIECE && (seg || i >= CHUNK6 / 16u)) {
-            if (K6_ABL < 5 && i >= CHUNK6 / 16u)
-                *reinterpret_cast<uint4 *>(s_own + (i - CHUNK6 / 16u) * 16u) = v[r];
-            if (i < (DEC_CH + 1u) * (CHUNK6 / 16u)) {
-                // header candidates are bytes 0 and 2 of every dword
-                lo = stride4(__builtin_amdgcn_perm(v[r].y, v[r].x, 0x06040200u));
-                hi = stride4(__builtin_amdgcn_perm(v[r].w, v[r].z, 0x06040200u));
-                const uint32_t k = i / (CHUNK6 / 16u), j = i % (CHUNK6 / 16u);
-                // RawData_Legacy.cpp:387-388,398-399: a record must end before len-1, i.e. the record at half position
-                // q of its chunk with stride d is the chain's end when cs + 2*(q + d) >= len: its stride becomes 0,
-                // the walk stays in front of it
-                const uint32_t cs = (cfirst + k - 1u) * CHUNK6;
-                const uint32_t limq = len > cs ? (len - cs + 1u) >> 1 : 0u;
-                if (limq <= HALF6 + 17u) {
-#pragma unroll
-                    for (uint32_t u = 0; u < 8u; u++) {
-                        uint32_t &wd = u < 4u ? lo : hi;
-                        const uint32_t sh = 8u * (u & 3u);
-                        if (j * 8u + u + ((wd >> sh) & 255u) >= limq)
-                            wd &= ~(255u << sh);
+        for (uint32_t r = 0; r < NROUND; r++) {
+            const uint32_t i = tid + r * DEC_T;
+            bool ones = false;
+            if (i < NPIECE && (seg || i >= FRONT6 / 16u)) {
+                *reinterpret_cast<uint4 *>(s_stage + i * 16u) = v[r];
+                // every even byte has a zero high nibble: a walk that arrives on the piece's first byte passes eight records of
+                // two bytes; none of them may be the chain's end (RawData_Legacy.cpp:387-388: the last one ends at 16 i + 16)
+                ones = ((v[r].x | v[r].y | v[r].z | v[r].w) & 0x00F000F0u) == 0u && i * 16u + 16u < limP;
+            }
+            const unsigned long long om = __ballot(ones);
+            if (lane == 0u)
+                s_flat[r * (DEC_T / 64u) + wave] = om;
+        }
+        if (tid < 32u)
+            s_fmap[tid] = static_cast<uint8_t>(DEAD);
+        __syncthreads();
+        K6_STAMP(1, 0);
+        K6_STAMP(9, RESOLVER * 64u);
+        if (K6_ABL == 4)
+            return;
+        // (wave-uniform: which walk loop this workgroup runs)
+        const bool careful = near_end || __ballot(lane < NROUND * (DEC_T / 64u) && s_flat[lane < NROUND * (DEC_T / 64u) ? lane : 0u] != 0ull) != 0ull;
+        constexpr uint32_t CLAMP = FRONT6 + OWN + SLACK - 2u; // (free-running walks stay inside the stage)
+
+        // ---- the sure entry (wave RESOLVER - 1): the 17 chains that can cross into the staged front -- every chain starts a record
+        // at one of 17 phases there --, walked to the segment's start in two halves side by side (34 lanes: half as many steps;
+        // the second half's 17 walks map the first half's exits to arrivals); and, while the arrivals are not yet one chain,
+        // on to the next quarter's start
+        if (wave == RESOLVER - 1u) {
+            uint32_t fr = 0u; // boundary (quarters into the segment) << 8 | phase of THE chain there; segment 0 starts with a record at byte 0 (RawData_Legacy.cpp:476)
+            if (seg) {
+                const bool w17 = lane < PHASES6, w34 = lane < 2u * PHASES6;
+                const uint32_t b0 = w17 ? FRONT6 / 2u : FRONT6;
+                uint32_t Pf = w17 ? 2u * lane : w34 ? FRONT6 / 2u + 2u * (lane - PHASES6) : FRONT6 + OWN; // (the other lanes stand behind every bound)
+                Pf = walk_to6<CLAMP>(careful, s_stage, s_flat, Pf, b0, limP);
+                uint32_t ph = Pf >= b0 ? (Pf - b0) >> 1 : DEAD; // (a chain that has died in front of the bound stays dead)
+                { // lanes 0..16: through the second half
+                    const uint32_t ph2 = __shfl(ph, static_cast<int>(PHASES6 + (ph < PHASES6 ? ph : 0u)), 64);
+                    ph = w17 ? (ph == DEAD ? DEAD : ph2) : DEAD;
+                }
+                const uint32_t a0 = ph;
+                Pf = w17 && ph != DEAD ? FRONT6 + 2u * ph : FRONT6 + OWN; // (a dead chain takes no further part: it cannot be the frame's)
+                const bool alive = w17 && ph != DEAD;
+                for (uint32_t kb = 0u;; kb++) {
+                    const uint32_t bound = FRONT6 + kb * QUART6;
+                    if (kb) {
+                        Pf = walk_to6<CLAMP>(careful, s_stage, s_flat, Pf, alive ? bound : 0u, limP);
+                        ph = Pf >= bound ? (Pf - bound) >> 1 : DEAD;
+                    }
+                    const unsigned long long am = __ballot(alive && ph != DEAD);
+                    const uint32_t ph0 = am ? wave_lane(ph, static_cast<uint32_t>(__builtin_ctzll(am))) : DEAD;
+                    if (kb < 4u * cnt && __ballot(alive && ph != DEAD && ph != ph0) == 0ull) {
+                        fr = (kb << 8) | ph0;
+                        break;
+                    }
+                    if (kb >= 4u * cnt) { // the segment's end, and still several chains: my entry phase -> my exit phase
+                        if (alive)
+                            s_fmap[a0] = static_cast<uint8_t>(ph);
+                        fr = NOFRONT << 8;
+                        break;
                     }
                 }
-                // sixteen 2-byte records in a row (a flat or clipped image region would otherwise cost a step per record,
-                // 128 per quarter): a walk that arrives at the first one jumps over all sixteen.  No record has that
-                // stride, so the entry also tells the record count what it stands for.
-                ones = limq > HALF6 + 17u && lo == 0x01010101u && hi == 0x01010101u;
-                dst = s_tab + k * TABQ + (j >> 4) * QTAB + (j & 15u) * 8u;
             }
+            if (lane == 0u)
+                s_front = fr;
         }
-        // (pieces i and i + 1 sit in neighbouring lanes; an even piece and its successor share a quarter; most waves
-        // hold no such piece at all and skip this)
-        const unsigned long long om = __ballot(ones);
-        if (om & (om >> 1)) {
-            const bool next_ones = ((om >> (lane & 63u)) >> 1) & 1ull;
-            if (ones && next_ones && (i & 1u) == 0u) {
-                lo = 0x01010100u | RUN6;
-                s_runs = 1u;
+
+        if (wave != RESOLVER) {
+            __syncthreads(); // (the resolving wave's twin of this barrier sits in its verification loop: s_front is there)
+            K6_STAMP(2, 0);
+        } else {
+            // ---- speculative walkers
+            const bool inq = uj < cnt; // (quarters behind the stream's last chunk: nothing to walk)
+            {
+                const uint32_t s0 = seg ? 0u : FRONT6; // (segment 0: the stream starts with a record at byte 0, RawData_Legacy.cpp:476)
+                // (how far in front a walker starts: a wrong chain meets the true one after a number of STEPS that grows with the
+                // records' size -- the longer the records, the fewer of the even bytes are record starts)
+                const uint32_t warm = len <= nrec * 18u ? WARM6 : len <= nrec * 26u ? min(WARM6 + QUART6, FRONT6) : FRONT6;
+                const uint32_t Pw = walk_to6<CLAMP>(careful, s_stage, s_flat, inq ? max(qb - warm, s0) : qe, qb, limP);
+                a = inq && Pw >= qb ? (Pw - qb) >> 1 : DEAD;
             }
+            K6_STAMP(10, RESOLVER * 64u);
+            // ... then walks its quarter from there and notes where its records start: a lane finds one record per step until its
+            // walk is over, so its n-th record is the one of step n -- its half position goes to byte n of eight registers
+            // (steps are unrolled: static indices).  The record lists below are made from these notes, without a second walk
+            // along the chain.
+            x = DEAD, qn = 0u;
+            notes_ok = !careful;
+            bool act = a != DEAD;           // lanes that walk their quarter in the coming round
+            uint32_t from = 0u, efrom = 0u; // verification: lane `from` is entered at phase `efrom`, every lane behind it where its predecessor ends
+            uint32_t vstage = 0u;           // 0: the lanes against each other (lane 0 believes itself), 1: from the sure entry, 2: from the segment in front
+            uint32_t rounds = 0u;
+            (void)rounds;
+            for (;;) {
+                // ---- (re)walk the quarters of the lanes whose entry has changed
+                if (!careful) { // fast form: notes in registers
+                    uint32_t Pw = act ? qb + 2u * a : qe, xc = Pw, cn = 0u;
+                    uint32_t nn[NOTES6 / 4u] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+                    bool more = true;
+#pragma unroll
+                    for (uint32_t st = 0; st < NOTES6; st += 2u) {
+#pragma unroll
+                        for (uint32_t u = 0; u < 2u; u++) {
+                            const uint32_t Pn = next6(s_stage, Pw);
+                            const bool in = Pw < qe;
+                            nn[(st + u) >> 2] |= __builtin_amdgcn_ubfe(Pw - qb, 1u, 8u) << (8u * ((st + u) & 3u)); // (bytes behind a lane's last record are never used)
+                            cn += in ? 1u : 0u;
+                            xc = in ? Pn : xc;
+                            Pw = Pn;
+                        }
+                        Pw = min(Pw, CLAMP);
+                        if (!__any(Pw < qe)) {
+                            more = false;
+                            break;
+                        }
+                    }
+                    if (more) { // records of less than 8 bytes on average: counted on, listed by a walk of their own below
+                        notes_ok = false;
+                        do {
+#pragma unroll
+                            for (uint32_t u = 0; u < 2u; u++) {
+                                const uint32_t Pn = next6(s_stage, Pw);
+                                const bool in = Pw < qe;
+                                cn += in ? 1u : 0u;
+                                xc = in ? Pn : xc;
+                                Pw = Pn;
+                            }
+                            Pw = min(Pw, CLAMP);
+                        } while (__any(Pw < qe));
+                    }
+                    if (act) {
+                        x = (xc - qe) >> 1;
+                        qn = cn;
+#pragma unroll
+                        for (uint32_t g = 0; g < NOTES6 / 4u; g++)
+                            nb[g] = nn[g];
+                    }
+                } else { // segments that need the careful walk: counts only
+                    uint32_t Pw = act ? qb + 2u * a : qe, t, n, cn = 0u;
+                    do {
+#pragma unroll
+                        for (int u = 0; u < 2; u++) {
+                            t = step6(s_stage, s_flat, Pw, qe, limP, &n);
+                            cn += n;
+                            Pw += t;
+                        }
+                    } while (__any(t != 0u));
+                    if (act) {
+                        x = Pw >= qe ? (Pw - qe) >> 1 : DEAD;
+                        qn = cn;
+                    }
+                }
+                rounds++;
+                // ---- verify: lane j is entered where lane j - 1 is left
+                bool again = false;
+                for (;;) {
+                    const uint32_t xp = wave_prev(x, DEAD);
+                    const uint32_t e = lane == from ? efrom : xp;
+                    const bool bad = inq && lane >= from && (vstage != 0u || lane != 0u) && e != a;
+                    if (__ballot(bad) != 0ull) {
+                        if (bad) {
+                            a = e;
+                            if (e == DEAD) { // (the chain ends in front of my quarter)
+                                x = DEAD;
+                                qn = 0u;
+                            }
+                        }
+                        act = bad && e != DEAD;
+                        again = true;
+                        break;
+                    }
+                    if (vstage == 0u) {
+                        __syncthreads(); // (twin of the other waves' barrier above: wave RESOLVER - 1 has said where the sure chain is)
+                        K6_STAMP(11, RESOLVER * 64u);
+                        const uint32_t fr = s_front;
+                        from = fr >> 8;
+                        efrom = fr & 255u;
+                        vstage = from == NOFRONT ? 2u : 1u;
+                        if (from != NOFRONT)
+                            continue;
+                    }
+                    if (vstage == 1u && from == 0u)
+                        break; // the common case: every lane verified from the segment's own sure entry
+                    if (vstage == 1u || from == NOFRONT) {
+                        // My entry is not known from my own bytes.  What the NEXT segment is entered at is said as early as it
+                        // can be said: a phase when my chains have become one inside me (the lanes behind that boundary are verified),
+                        // else -- a stream whose chains never meet -- the map from my entry phase to it, for my successors to go
+                        // through while I still wait for mine.
+                        const size_t lme = static_cast<size_t>(f) * smax + seg;
+                        if (full && from != NOFRONT) {
+                            const uint32_t xp63 = wave_lane(x, NQ6 - 1u);
+                            if (lane == 0)
+                                look_put(look.ex + lme, epoch, (EX_PHASE << 30) | xp63);
+                        } else if (full) {
+                            const uint32_t xm = lane < PHASES6 ? s_fmap[lane] : DEAD;
+                            uint32_t hw = 0;
+#pragma unroll
+                            for (uint32_t k = 0; k < 6u; k++) {
+                                const uint32_t src = lane * 6u + k;
+                                const uint32_t xe = __shfl(xm, static_cast<int>(src & 63u), 64);
+                                hw |= (src < PHASES6 ? xe : DEAD) << (5u * k);
+                            }
+                            if (lane < 3u)
+                                look_put(look.hm + 3u * lme + lane, epoch, hw);
+                            if (lane == 0)
+                                look_put(look.ex + lme, epoch, EX_MAP << 30);
+                        }
+                        // The nearest segment in front whose exit is known -- it has resolved and published its records, or said a
+                        // phase above --, and from there through the maps of the segments in between (64 segments per poll; the
+                        // frame itself is entered at phase 0).
+                        uint32_t ep = DEAD;
+                        bool got = false;
+                        while (!got && !lost) {
+                            const int32_t k = static_cast<int32_t>(seg) - 1 - static_cast<int32_t>(lane); // segment of this lane
+                            bool kn = false, mp = false;
+                            uint32_t ph = DEAD, h0 = 0, h1 = 0, h2 = 0;
+                            if (k == -1) {
+                                kn = true;
+                                ph = 0u;
+                            } else if (k >= 0) {
+                                uint32_t vr = 0, vx = 0;
+                                const size_t ks = lme - seg + static_cast<uint32_t>(k);
+                                const bool rok = look_get(look.res + ks, epoch, &vr) && (vr >> 30) != 0u;
+                                const bool xok = look_get(look.ex + ks, epoch, &vx);
+                                if (rok) {
+                                    kn = true;
+                                    ph = vr & 31u;
+                                } else if (xok && (vx >> 30) == EX_PHASE) {
+                                    kn = true;
+                                    ph = vx & 31u;
+                                } else if (xok && (vx >> 30) == EX_MAP) {
+                                    const bool m0 = look_get(look.hm + 3u * ks, epoch, &h0), m1 = look_get(look.hm + 3u * ks + 1u, epoch, &h1),
+                                               m2 = look_get(look.hm + 3u * ks + 2u, epoch, &h2);
+                                    mp = m0 && m1 && m2;
+                                }
+                            }
+                            const uint64_t km = __ballot(kn), mm = __ballot(mp);
+                            const uint32_t i0 = km ? static_cast<uint32_t>(__builtin_ctzll(km)) : 64u;
+                            const uint64_t front = i0 >= 64u ? ~0ull : (1ull << i0) - 1ull; // the segments between that one and me
+                            if (i0 < 64u && (mm & front) == front) {
+                                uint32_t p = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ph), static_cast<int>(i0)));
+                                for (uint32_t t = i0; t-- > 0u && p != DEAD;) {
+                                    const uint32_t w0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(h0), static_cast<int>(t)));
+                                    const uint32_t w1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(h1), static_cast<int>(t)));
+                                    const uint32_t w2 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(h2), static_cast<int>(t)));
+                                    const uint32_t hw = p < 6u ? w0 : p < 12u ? w1 : w2;
+                                    p = (hw >> (5u * (p % 6u))) & 31u;
+                                }
+                                ep = p;
+                                got = true;
+                            } else {
+                                if (++spins > SPIN6)
+                                    lost = true;
+                                __builtin_amdgcn_s_sleep(2);
+                            }
+                        }
+                        if (lost) { // (a predecessor never said anything: the frame fails below)
+                            a = DEAD;
+                            x = DEAD;
+                            qn = 0u;
+                            break;
+                        }
+                        vstage = 2u;
+                        from = 0u;
+                        efrom = ep;
+                        continue;
+                    }
+                    break; // (vstage 2, nothing bad: verified from the frame's own chain)
+                }
+                if (!again)
+                    break;
+            }
+            K6_COUNT(25, rounds);
         }
-        if (dst)
-            *reinterpret_cast<uint2 *>(dst) = make_uint2(lo, hi);
     }
-    if (tid <= DEC_CH)
-        s_exits[tid] = 0u;
-    __syncthreads();
-    K6_STAMP(1, 0);
-    K6_STAMP(9, 256);
 
-    // ---- transition maps, phases only: thread (chunk k, phase) walks the four quarters of its chunk, each from its
-    // phase, side by side -- a step is one LDS read and one addition per walk, four independent walks in flight -- and
-    // notes at which phase each is left; three lookups then compose the chunk's map from the quarters'.
-    const bool mapper = tid < (DEC_CH + 1u) * PHASES6;
-    const uint32_t mk = tid / PHASES6, mph = tid - mk * PHASES6; // (mk = 0: the chunk in front of the segment)
-    const bool mapped = mapper && (mk || seg) && cfirst + mk - 1u < nchunks;
-    if (mapped) {
-        const uint32_t q0 = mk * TABQ + mph;
-        uint32_t A0 = q0, A1 = q0 + QTAB, A2 = q0 + 2u * QTAB, A3 = q0 + 3u * QTAB;
-        const uint32_t end0 = mk * TABQ + HALF6 / 4u; // (end of quarter r: end0 + r * QTAB)
-        uint32_t moved;
-        do { // until no walk of the wave moved any more: each has left its quarter, or stands in front of the chain's
-             // last record (stride 0)
-#pragma unroll
-            for (int u = 0; u < 2; u++) { // (a walk that has left its quarter stays where it is)
-                // (the reads are unconditional -- what lies behind a quarter is LDS of this workgroup -- and a select drops them)
-                const uint32_t r0 = s_tab[A0], r1 = s_tab[A1], r2 = s_tab[A2], r3 = s_tab[A3];
-                const uint32_t t0 = A0 < end0 ? r0 : 0u, t1 = A1 < end0 + QTAB ? r1 : 0u, t2 = A2 < end0 + 2u * QTAB ? r2 : 0u,
-                               t3 = A3 < end0 + 3u * QTAB ? r3 : 0u;
-                A0 += t0, A1 += t1, A2 += t2, A3 += t3;
-                moved = t0 | t1 | t2 | t3;
-            }
-        } while (__any(moved != 0u));
-        uint8_t *qx = s_qx + mk * 4u * PHASES6 + mph;
-        qx[0] = static_cast<uint8_t>(A0 < end0 ? DEAD : A0 - end0);
-        qx[PHASES6] = static_cast<uint8_t>(A1 < end0 + QTAB ? DEAD : A1 - (end0 + QTAB));
-        qx[2 * PHASES6] = static_cast<uint8_t>(A2 < end0 + 2u * QTAB ? DEAD : A2 - (end0 + 2u * QTAB));
-        qx[3 * PHASES6] = static_cast<uint8_t>(A3 < end0 + 3u * QTAB ? DEAD : A3 - (end0 + 3u * QTAB));
-    }
-    __syncthreads();
-    K6_STAMP(2, 0);
-    if (mapped) {
-        const uint8_t *qx = s_qx + mk * 4u * PHASES6;
-        uint32_t x = mph;
-#pragma unroll
-        for (uint32_t r = 0; r < 4u; r++)
-            x = x == DEAD ? DEAD : qx[r * PHASES6 + x];
-        s_cx[mk * PHASES6 + mph] = static_cast<uint8_t>(x);
-        atomicOr(&s_exits[mk], 1u << x);
-    }
-    __syncthreads();
-
-    if (K6_ABL == 5 && wave < 4u)
-        return;
-    // ---- entries of my chunks (wave DEC_T / 64 - 1; the others wait at the barrier below)
-    const uint32_t cnt = min(static_cast<uint32_t>(DEC_CH), nchunks - cfirst);
-    // What unpacking wave w has to do, from the entries in s_ent (valid once the fifth wave has written them).
+    // What unpacking wave w has to do, from the entries in s_ent (valid once the resolving wave has written them).
     struct Range6 {
         uint32_t R0, R1, N; // records it decodes: the pairs whose even record starts in its chunks
         bool live;          // the chain reaches its chunks and there are pairs for it
@@ -380,194 +652,18 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         return g;
     };
     auto range_of = [&](uint32_t w) { return range_from(w, ent_of(w * ROWS_CH), ent_of(w * ROWS_CH + ROWS_CH)); };
-    if (wave == DEC_T / 64u - 1u) {
+
+    if (wave == RESOLVER) {
+        const bool inq = uj < cnt;
         const size_t lme = static_cast<size_t>(f) * smax + seg;
         uint64_t *const res = look.res + lme; // mine; res[-k]: k segments before me
-        uint32_t spins = 0, w = 0;
-        bool lost = false;
-        // Entry phase of chunk j (lane j; lane cnt: of the chunk behind the segment): the map of the chunk in front
-        // of it almost always sends all 17 phases to ONE exit (a wrong chain reads payload bytes as headers and falls
-        // onto the true one within a few hundred bytes), so every lane knows its own at once; a lane whose map is
-        // not unanimous takes the entry of the chunk in front through that map.
-        uint32_t myp = DEAD;
-        bool known = false;
-        if (lane <= cnt) {
-            if (lane == 0u && seg == 0u) {
-                myp = 0u; // the stream starts with a record at byte 0 (RawData_Legacy.cpp:476)
-                known = true;
-            } else {
-                const uint32_t xs = s_exits[lane]; // (chunk k = lane is the one in front of chunk j = lane)
-                myp = xs ? static_cast<uint32_t>(__builtin_ctz(xs)) : DEAD;
-                known = (xs & (xs - 1u)) == 0u; // one exit for all 17 phases
-            }
-        } else {
-            known = true;
-        }
-        auto propagate = [&]() { // (rare; at most cnt rounds)
-            for (;;) {
-                const uint32_t pp = wave_prev(myp, DEAD);
-                const uint32_t kk = wave_prev(known ? 1u : 0u, 0u); // (DPP moves across the wave: no LDS round trip)
-                const bool pk = lane != 0u && kk != 0u;
-                const bool now = !known && pk;
-                if (now) {
-                    myp = pp == DEAD ? DEAD : s_cx[lane * PHASES6 + pp];
-                    known = true;
-                }
-                if (__ballot(now) == 0ull)
-                    break;
-            }
-        };
-        propagate();
-        // What the NEXT segment is entered at, said as early as it can be said: a phase when one of my chunks' maps is
-        // unanimous (whatever I am entered at myself), else -- a stream whose every chunk keeps its 17 chains apart --
-        // the map from my entry phase to it, for my successors to go through while I still wait for mine.
-        const bool full = cnt == DEC_CH;
-        const bool exit_known = wave_lane(known ? 1u : 0u, DEC_CH) != 0u;
-        if (full && exit_known) {
-            const uint32_t xp = wave_lane(myp, DEC_CH);
-            if (lane == 0)
-                look_put(look.ex + lme, epoch, (EX_PHASE << 30) | xp);
-        } else if (full) {
-            uint32_t x = lane < PHASES6 ? lane : DEAD;
-            for (uint32_t k = 1; k <= DEC_CH; k++)
-                x = x == DEAD ? DEAD : s_cx[k * PHASES6 + x];
-            uint32_t hw = 0;
-#pragma unroll
-            for (uint32_t e = 0; e < 6u; e++) {
-                const uint32_t src = lane * 6u + e;
-                const uint32_t xe = __shfl(x, static_cast<int>(src & 63u), 64);
-                hw |= (src < PHASES6 ? xe : DEAD) << (5u * e);
-            }
-            if (lane < 3u)
-                look_put(look.hm + 3u * lme + lane, epoch, hw);
-            if (lane == 0)
-                look_put(look.ex + lme, epoch, EX_MAP << 30);
-        }
-        if (!__builtin_amdgcn_readfirstlane(known ? 1u : 0u)) {
-            // Lane 0 does not know the segment's own entry: the nearest segment in front whose exit is known -- it has
-            // resolved and published its records, or said a phase above --, and from there through the maps of the
-            // segments in between (64 segments per poll; the frame itself is entered at phase 0).
-            uint32_t ep = DEAD;
-            bool got = false;
-            while (!got && !lost) {
-                const int32_t k = static_cast<int32_t>(seg) - 1 - static_cast<int32_t>(lane); // segment of this lane
-                bool kn = false, mp = false;
-                uint32_t ph = DEAD, h0 = 0, h1 = 0, h2 = 0;
-                if (k == -1) {
-                    kn = true;
-                    ph = 0u;
-                } else if (k >= 0) {
-                    uint32_t vr = 0, vx = 0;
-                    const size_t ks = lme - seg + static_cast<uint32_t>(k);
-                    const bool rok = look_get(look.res + ks, epoch, &vr) && (vr >> 30) != 0u;
-                    const bool xok = look_get(look.ex + ks, epoch, &vx);
-                    if (rok) {
-                        kn = true;
-                        ph = vr & 31u;
-                    } else if (xok && (vx >> 30) == EX_PHASE) {
-                        kn = true;
-                        ph = vx & 31u;
-                    } else if (xok && (vx >> 30) == EX_MAP) {
-                        const bool m0 = look_get(look.hm + 3u * ks, epoch, &h0), m1 = look_get(look.hm + 3u * ks + 1u, epoch, &h1),
-                                   m2 = look_get(look.hm + 3u * ks + 2u, epoch, &h2);
-                        mp = m0 && m1 && m2;
-                    }
-                }
-                const uint64_t km = __ballot(kn), mm = __ballot(mp);
-                const uint32_t i0 = km ? static_cast<uint32_t>(__builtin_ctzll(km)) : 64u;
-                const uint64_t front = i0 >= 64u ? ~0ull : (1ull << i0) - 1ull; // the segments between that one and me
-                if (i0 < 64u && (mm & front) == front) {
-                    uint32_t p = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(ph), static_cast<int>(i0)));
-                    for (uint32_t t = i0; t-- > 0u && p != DEAD;) {
-                        const uint32_t w0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(h0), static_cast<int>(t)));
-                        const uint32_t w1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(h1), static_cast<int>(t)));
-                        const uint32_t w2 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(h2), static_cast<int>(t)));
-                        const uint32_t hw = p < 6u ? w0 : p < 12u ? w1 : w2;
-                        p = (hw >> (5u * (p % 6u))) & 31u;
-                    }
-                    ep = p;
-                    got = true;
-                } else {
-                    if (++spins > SPIN6)
-                        lost = true;
-                    __builtin_amdgcn_s_sleep(2);
-                }
-            }
-            if (lane == 0u) {
-                myp = lost ? DEAD : ep;
-                known = true;
-            }
-            propagate();
-        }
-        const uint32_t lastp = full ? wave_lane(myp, DEC_CH) : DEAD; // the segment's exit phase: what the next one is entered at
-        K6_STAMP(10, 256);
-
-        // ---- the true chain, a quarter chunk per lane (chunk j = lane / 4, quarter r = lane % 4): where it crosses into
-        // the quarter (its chunk's entry through the quarters in front), then how many records it starts there
-        const uint32_t uj = lane >> 2, ur = lane & 3u;
-        const uint32_t cph = __shfl(myp, static_cast<int>(uj), 64);             // entry phase of my chunk
-        const uint32_t aph = wave_lane(myp, DEC_CH);                            // ... of the chunk behind a full segment
-        uint32_t qp = cph;
-        {
-            const uint8_t *qx = s_qx + (uj + 1u) * 4u * PHASES6;
-#pragma unroll
-            for (uint32_t r = 0; r < 3u; r++)
-                if (r < ur)
-                    qp = qp == DEAD ? DEAD : qx[r * PHASES6 + qp];
-        }
-        if (uj >= cnt)
-            qp = DEAD;
-        uint32_t qn = 0;
-        // ... and notes where: a lane finds one record per step until its walk is over, so its n-th record is the one of
-        // step n -- its half position goes to byte n of eight registers (steps are unrolled: static indices).  The record
-        // lists below are made from these notes, without a second walk along the chain.
-        constexpr uint32_t NOTES6 = 32;
-        uint32_t nb[NOTES6 / 4u] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-        bool notes_ok = s_runs == 0u;
-        {
-            const uint32_t qb = (uj + 1u) * TABQ + ur * QTAB;
-            const uint32_t qe = qb + HALF6 / 4u;  // a walk that has left its quarter stays where it is
-            uint32_t A = qp == DEAD ? qe : qb + qp; // (DEAD: nothing to count)
-            uint32_t t;
-            if (s_runs) { // (some walk of this segment may meet a jump over sixteen records)
-                do {
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        t = s_tab[A]; t = A < qe ? t : 0u; // (unconditional read, then the select)
-                        qn += t == RUN6 ? RUN6 : (t ? 1u : 0u);
-                        A += t;
-                    }
-                } while (__any(t != 0u));
-            } else {
-                bool more = true;
-#pragma unroll
-                for (uint32_t st = 0; st < NOTES6; st += 2u) {
-#pragma unroll
-                    for (uint32_t u = 0; u < 2u; u++) {
-                        t = s_tab[A]; t = A < qe ? t : 0u; // (unconditional read, then the select)
-                        nb[(st + u) >> 2] |= (A - qb) << (8u * ((st + u) & 3u)); // (< 256; bytes behind a lane's last record are never used)
-                        qn += t ? 1u : 0u;
-                        A += t;
-                    }
-                    if (!__any(t != 0u)) {
-                        more = false;
-                        break;
-                    }
-                }
-                if (more) { // records of less than 8 bytes on average: counted on, listed by a walk of their own below
-                    notes_ok = false;
-                    do {
-#pragma unroll
-                        for (int u = 0; u < 2; u++) {
-                            t = s_tab[A]; t = A < qe ? t : 0u; // (unconditional read, then the select)
-                            qn += t ? 1u : 0u;
-                            A += t;
-                        }
-                    } while (__any(t != 0u));
-                }
-            }
-        }
-        K6_STAMP(11, 256);
+        uint32_t w = 0;
+        // the segment's exit phase: what the next one is entered at
+        const uint32_t aph = wave_lane(x, NQ6 - 1u); // entry phase of the chunk behind a full segment
+        const uint32_t lastp = full ? aph : DEAD;
+        const uint32_t cph = __shfl(a, static_cast<int>(lane & ~3u), 64); // entry phase of my chunk
+        uint32_t qp = a;                                                   // ... of my quarter
+        K6_STAMP(26, RESOLVER * 64u);
         // records in front of my quarter within the segment, and those of the whole segment
         uint32_t total; // (quarters behind the stream add nothing)
         const uint32_t qfirst = wave_excl_scan(qn, lane, &total);
@@ -579,7 +675,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
 #else
             if (lane == 0)
 #endif
-                look_put(res, epoch, (RES_AGG << 30) | (total << 5) | lastp);
+                look_put(res, epoch, (RES_AGG << 30) | (total << 5) | (lost ? DEAD : lastp));
             int32_t jn = static_cast<int32_t>(seg) - 1; // nearest segment of the window (lane 0)
             while (!lost) {
                 const int32_t k = jn - static_cast<int32_t>(lane);
@@ -602,7 +698,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                 jn -= 64;
             }
         }
-        K6_STAMP(12, 256);
+        K6_STAMP(12, RESOLVER * 64u);
         K6_COUNT(14, 1);
         K6_COUNT(15, spins);
         if (lost) { // (a predecessor never published: fail the frame rather than wait for ever)
@@ -621,8 +717,8 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
             look_put(res, epoch, (RES_PREFIX << 30) | (endn << 5) | (lost ? DEAD : lastp));
         const uint32_t qi = min(base + qfirst, 0xFFFFFFu); // index of my quarter's first record
         const uint32_t ent4v = qp | (qi << 8);
-        const uint32_t entv = uj <= cnt && !lost ? (cph | (qi << 8)) : DEAD;            // (lanes with ur == 0: chunk uj's)
-        const uint32_t ent16 = cnt == DEC_CH && !lost ? (aph | (endn << 8)) : DEAD;     // ... and of the chunk behind a full segment
+        const uint32_t entv = inq && !lost ? (cph | (qi << 8)) : DEAD;                 // (lanes with ur == 0: chunk uj's)
+        const uint32_t ent16 = full && !lost ? (aph | (endn << 8)) : DEAD;             // ... and of the chunk behind a full segment
         s_ent4[lane] = ent4v;
         if (ur == 0u)
             s_ent[uj] = entv;
@@ -635,9 +731,8 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
 
         // ---- the record lists of the four unpacking waves, when every one of them is on the lean path (everywhere
         // but at the ends of a frame and in runs of tiny records): lane = (wave w, chunk j, quarter r) lists a quarter
-        // chunk from where the true chain crosses into it -- 18 dependent steps instead of a chunk's 70, on ONE wave
-        // (a walk costs a wave its issue slots whatever the number of walking lanes).  The walk tables are dead by now:
-        // their LDS holds the lists.
+        // chunk from where the true chain crosses into it, on ONE wave
+        // (a walk costs a wave its issue slots whatever the number of walking lanes).
         // (what this wave needs of the entries it has just stored, it takes from its registers: a wait for the LDS here would
         // also wait for the look-back words' way to memory -- stores count on the same counter)
         const uint32_t uw = lane / (4u * ROWS_CH), j = (lane >> 2) & (ROWS_CH - 1u), r = lane & 3u;
@@ -653,8 +748,8 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         if (lane == 0)
             s_coop = coop ? 1u : 0u;
         // The common case (no jumps over runs of 2-byte records in this segment, at most NOTES6 records per quarter, every
-        // record listed): the lists are the notes of the count walk put in their places -- stores that do not depend on one
-        // another, instead of a second walk along the chain (which took 5 700 of a workgroup's 34 000 cycles).  A lane stores
+        // record listed): the lists are the notes of the quarter walks put in their places -- stores that do not depend on one
+        // another, instead of a second walk along the chain.  A lane stores
         // whole groups of eight entries.  The group its records end in is filled up with the first records of the NEXT quarter
         // (every quarter starts at least seven: a record has at most 34 bytes), taken from the lane behind it: what a lane
         // stores beyond its own records is then exactly what that lane stores there itself, and it does not matter which
@@ -700,12 +795,14 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
             // ends on an even one; a lane whose records end on a group boundary has stored nothing behind them)
             if (j == ROWS_CH - 1u && r == 3u)
                 lp[qn] = static_cast<uint16_t>(ROWS_CH * CHUNK6 + 2u * (enext_reg & 255u));
-        } else if (K6_ABL != 3 && K6_ABL < 5 && coop) {
+        } else if (K6_ABL != 3 && coop) {
             const uint32_t ej = ent4v, first = rg.R0;
             const uint8_t *base = s_own + uw * (ROWS_CH * CHUNK6);
             const uint8_t *p = base + j * CHUNK6 + r * (CHUNK6 / 4u) + 2u * (ej & 255u);
             const uint8_t *const pe = base + j * CHUNK6 + (r + 1u) * (CHUNK6 / 4u);
             uint32_t idx = ej >> 8;
+            if ((ej & 255u) == DEAD)
+                p = pe; // (coop implies that the chain reaches every quarter; belt and braces)
             if (rg.pairmode) {
                 // an odd first record belongs to the previous wave's last pair: never listed
                 while (p < pe) { // the stride decode, and a store for every second record
@@ -745,14 +842,16 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                     *lp = static_cast<uint16_t>(p - base);
             }
         }
-        K6_STAMP(13, 256);
+        K6_STAMP(13, RESOLVER * 64u);
     }
     __syncthreads();
     K6_STAMP(3, 0);
     const bool coop = s_coop != 0u;
-    if ((wave >= 4u && !coop) || K6_ABL >= 5) {
+    if (K6_ABL == 2)
+        return;
+    if (FIFTH6 && wave >= 4u && !coop) {
         K6_END();
-        return; // (the fifth wave has no chunks of its own; on the lean path it takes a share of every wave's pairs)
+        return; // (a fifth wave has no chunks of its own; on the lean path it takes a share of every wave's pairs)
     }
 
     const Range6 mine = range_of(wave & 3u);
@@ -841,7 +940,9 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         // and eight for the fifth wave).
         K6_STAMP(4, 0);
         auto tail_of = [&](uint32_t ntask) { return ntask >= 3u * TAIL6 ? ntask - TAIL6 : ntask; }; // first task of the fifth wave's share
-        if (wave < 4u) {
+        if (!FIFTH6) {
+            unpack_round(wave, R0, R1, pairmode, 0u, 2u * (R1 - R0));
+        } else if (wave < 4u) {
             unpack_round(wave, R0, R1, pairmode, 0u, tail_of(2u * (R1 - R0)));
         } else {
 #pragma unroll 1
@@ -939,7 +1040,7 @@ void launch_k6_decode(const Plan6 *plans, const uint32_t *wg_tab, uint32_t stage
     const dim3 grid(nwg), block(DEC_T);
     const uint32_t nf = static_cast<uint32_t>(nframes);
     if (post.mode == 0u) {
-#ifdef MCRAW_DIAG // occupancy experiments: extra LDS per workgroup (tools/k6_occ.sh)
+#if defined(MCRAW_DIAG) || defined(K6_PADENV) // occupancy experiments: extra LDS per workgroup (tools/k6_occ.sh)
         static const uint32_t pad = getenv("MCRAW_K6_LDSPAD") ? static_cast<uint32_t>(atoi(getenv("MCRAW_K6_LDSPAD"))) : 0u;
         hipLaunchKernelGGL(k6_decode<0>, grid, block, pad, st, plans, wg_tab, stage0, look, tickets, epoch, nf, smax, post);
 #else

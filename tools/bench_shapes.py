@@ -39,6 +39,8 @@ def main():
     res = {}
     for name, img in shapes(w, h).items():
         for typ, enc, n in ((7, L.encode7, 120), (6, L.encode6, 32)):
+            if os.environ.get("SHAPES_TYPES") and str(typ) not in os.environ["SHAPES_TYPES"]:
+                continue
             buf = enc(img)
             tin = torch.from_numpy(buf).to(dev)
             tout = torch.zeros(n * w * h * 2, dtype=torch.uint8, device=dev)

@@ -36,8 +36,9 @@ torch.cuda.synchronize()
 lib.mcraw_diag_k6_prof(pp, NWG, 1)   # stamps of the last launch
 live = prof[:, 14] == 1
 P = prof[live].astype(np.float64)
-names = {0: "w0 ticket+load", 1: "w0 stage+table", 2: "w0 map walks", 3: "w0 compose + wait for wave 4", 4: "w0 (lists ready)", 5: "w0 unpack",
-         8: "w4 ticket+load", 9: "w4 stage+table", 10: "w4 maps+compose+entry", 11: "w4 crossings+counts", 12: "w4 scan+look-back", 13: "w4 entries+lists"}
+names = {0: "w0 ticket+load", 1: "w0 stage", 2: "w0 wait for wave 3 (sure entry)", 3: "w0 wait for wave 4", 4: "w0 (lists ready)", 5: "w0 unpack",
+         8: "w4 ticket+load", 9: "w4 stage", 10: "w4 warm-up walk", 11: "w4 quarter walks + lane checks + wait for wave 3", 26: "w4 check from the sure entry",
+         12: "w4 scan+look-back", 13: "w4 entries+lists", 25: "w4 walk rounds (count)"}
 for i, nm in names.items():
     print("%-30s mean %8.0f  p50 %8.0f  p90 %8.0f ticks" % (nm, P[:, i].mean(), np.median(P[:, i]), np.percentile(P[:, i], 90)))
 print("workgroups", live.sum(), "lifetime mean", P[:, 0:6].sum(axis=1).mean(), "spins/wg", P[:, 15].mean(), "max", P[:, 15].max())
