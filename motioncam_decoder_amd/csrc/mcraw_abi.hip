@@ -72,6 +72,8 @@ struct Slot {
     std::vector<int> order;
     std::vector<int32_t> host_status;
     int n7 = 0; // type-7 frames of the batch in this slot (their coded heights follow the statuses)
+    int wpf = 2; // status words per type-7 frame the batch was launched with (one per part of its side streams)
+    Buf side_sync; // type-7 frames: what the parts of a side stream tell each other (k7_side); never cleared, epoch-tagged words
     hipEvent_t done = nullptr;
     hipEvent_t fork = nullptr, join = nullptr; // a batch that holds both encodings: its legacy kernel runs on the context's second stream
     ::mcraw_ticket *owner = nullptr; // host-memory batch whose statuses still sit in this slot's arena
@@ -428,7 +430,30 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     size_t off = 0;
     // status words: two per type-7 frame (one per side stream, each written once by its workgroup), one per legacy
     // frame, one spare; then the coded height of every type-7 frame
-    const size_t nstatus = 2 * static_cast<size_t>(n7) + n6 + 1;
+    // Long side streams of small batches are resolved by two workgroups each (k7_side "parts") when the chip has room for
+    // them all at once (two workgroups of k7_side per CU).  What a part saves is the decode and the table builds of the other
+    // part's pieces; what it adds is a count over its own pieces and a hand-off: measured (tools/side_split.py), 16 x 12 MP
+    // frames 160 -> 89 us, 120 x 8K 270 -> 208 us, UHD frames (streams of two to eight pieces) lose.  More parts per
+    // stream (the kernel takes up to MAX_SPLIT7) were slower on every batch tried: MCRAW_SIDE_SPLIT=b,r pins the numbers
+    // (tests run the type-7 suites with 2,2 and 4,4).
+    int nsplit[2] = {1, 1};
+    {
+        uint32_t rmax = 0;
+        for (const Plan7 &p : B.p7)
+            rmax = std::max(rmax, p.ngroups);
+        if (rmax >= 2900u && n7 * 4 <= 512)
+            nsplit[0] = nsplit[1] = 2;
+        if (const char *e = std::getenv("MCRAW_SIDE_SPLIT")) {
+            int b = 0, r = 0;
+            const int got = std::sscanf(e, "%d,%d", &b, &r);
+            if (got == 1)
+                r = b;
+            if (got >= 1 && b >= 1 && b <= MAX_SPLIT7 && r >= 1 && r <= MAX_SPLIT7)
+                nsplit[0] = b, nsplit[1] = r;
+        }
+    }
+    const int wpf = nsplit[0] + nsplit[1]; // status words (= workgroups of k7_side) per type-7 frame
+    const size_t nstatus = static_cast<size_t>(wpf) * n7 + n6 + 1;
     L.status = carve(off, sizeof(int32_t) * (nstatus + n7));
     L.plans7 = carve(off, sizeof(Plan7) * n7);
     L.plans6 = carve(off, sizeof(Plan6) * n6);
@@ -458,15 +483,24 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         mcraw_legacy_launch_order(nseg.data(), n6, wg_tab.data());
     }
     L.total = off;
-    if (n6) {
-        const size_t need = sizeof(uint64_t) * 5 * smax * static_cast<size_t>(n6); // res, ex, hm[3] per segment
-        if (need > s.look.cap) {
-            if (int rc = ensure(s.look, need, false))
+    {
+        const size_t need6 = sizeof(uint64_t) * 5 * smax * static_cast<size_t>(n6); // res, ex, hm[3] per segment
+        if (need6 > s.look.cap) {
+            if (int rc = ensure(s.look, need6, false))
                 return rc;
             HIP_TRY(hipMemsetAsync(s.look.p, 0, s.look.cap, st)); // epoch 0 = never written
         }
+        const size_t need7 = wpf > 2 ? sizeof(uint64_t) * 2 * 2 * MAX_SPLIT7 * static_cast<size_t>(n7) : 0; // two words per part of a side stream
+        if (need7 > s.side_sync.cap) {
+            if (int rc = ensure(s.side_sync, need7, false))
+                return rc;
+            HIP_TRY(hipMemsetAsync(s.side_sync.p, 0, s.side_sync.cap, st));
+        }
         if (++s.look_epoch == 0u) { // (2^32 batches later: start over)
-            HIP_TRY(hipMemsetAsync(s.look.p, 0, s.look.cap, st));
+            if (s.look.p)
+                HIP_TRY(hipMemsetAsync(s.look.p, 0, s.look.cap, st));
+            if (s.side_sync.p)
+                HIP_TRY(hipMemsetAsync(s.side_sync.p, 0, s.side_sync.cap, st));
             s.look_epoch = 1;
         }
     }
@@ -481,13 +515,14 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     std::memset(img + L.status, 0, sizeof(int32_t) * (nstatus + n7));
     s.host_status = status;
     s.n7 = n7;
+    s.wpf = wpf;
     s.order = B.idx7;
     s.order.insert(s.order.end(), B.idx6.begin(), B.idx6.end());
     if (n7)
         std::memcpy(img + L.plans7, B.p7.data(), sizeof(Plan7) * n7);
 
     for (int k = 0; k < n6; k++)
-        B.p6[k].status = reinterpret_cast<int32_t *>(dev + L.status) + 2 * n7 + k;
+        B.p6[k].status = reinterpret_cast<int32_t *>(dev + L.status) + wpf * n7 + k;
     if (n6) {
         std::memcpy(img + L.wg_tab, wg_tab.data(), sizeof(uint32_t) * wg_tab.size());
         std::memcpy(img + L.plans6, B.p6.data(), sizeof(Plan6) * n6);
@@ -518,6 +553,10 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         W.status = reinterpret_cast<int32_t *>(dev + L.status);
         W.frames = reinterpret_cast<Frame7 *>(dev + w_frames);
         W.nstatus = static_cast<uint32_t>(nstatus);
+        W.nsplit[0] = static_cast<uint32_t>(nsplit[0]);
+        W.nsplit[1] = static_cast<uint32_t>(nsplit[1]);
+        W.sync = static_cast<uint64_t *>(s.side_sync.p);
+        W.epoch = s.look_epoch;
         W.bits = dev + w_bits;
         W.refs = reinterpret_cast<uint16_t *>(dev + w_refs);
         W.grp_off = reinterpret_cast<uint32_t *>(dev + w_grp);
@@ -660,9 +699,9 @@ int acquire_slot(mcraw_ctx *c, Slot **out, bool device_batch = false)
 // height of every type-7 frame, from its header (rows written = min(height, encH), RawData.cpp:571, :611).
 int fetch_status(mcraw_ctx *c, Slot &s, size_t status_off, int n, hipStream_t st, int32_t *status, uint32_t *encH)
 {
-    const int ndev = static_cast<int>(s.order.size()), n7 = s.n7, n6 = ndev - n7;
-    const size_t nstatus = 2 * static_cast<size_t>(n7) + n6 + 1;
-    const size_t words = nstatus + n7; // statuses (two per type-7 frame, one per legacy frame, one spare), coded heights
+    const int ndev = static_cast<int>(s.order.size()), n7 = s.n7, n6 = ndev - n7, w7 = s.wpf;
+    const size_t nstatus = static_cast<size_t>(w7) * n7 + n6 + 1;
+    const size_t words = nstatus + n7; // statuses (w7 per type-7 frame, one per legacy frame, one spare), coded heights
     if (int rc = ensure(s.status_host, sizeof(int32_t) * words, true))
         return rc;
     if (ndev)
@@ -673,8 +712,15 @@ int fetch_status(mcraw_ctx *c, Slot &s, size_t status_off, int n, hipStream_t st
     for (int i = 0; i < n && i < static_cast<int>(s.host_status.size()); i++)
         status[i] = s.host_status[i];
     for (int j = 0; j < ndev; j++)
-        if (s.order[j] < n)
-            status[s.order[j]] |= j < n7 ? (dev[2 * j] | dev[2 * j + 1]) : dev[2 * n7 + (j - n7)];
+        if (s.order[j] < n) {
+            int32_t v = 0;
+            if (j < n7)
+                for (int w = 0; w < w7; w++)
+                    v |= dev[w7 * j + w];
+            else
+                v = dev[w7 * n7 + (j - n7)];
+            status[s.order[j]] |= v;
+        }
     if (encH)
         for (int j = 0; j < n7; j++)
             if (s.order[j] < n)
@@ -1167,6 +1213,7 @@ void mcraw_ctx_destroy(mcraw_ctx *c)
         if (s.status_host.p) (void)hipHostFree(s.status_host.p);
         if (s.arena.p) (void)hipFree(s.arena.p);
         if (s.look.p) (void)hipFree(s.look.p);
+        if (s.side_sync.p) (void)hipFree(s.side_sync.p);
         if (s.dev_in.p) (void)hipFree(s.dev_in.p);
         if (s.dev_out.p) (void)hipFree(s.dev_out.p);
         if (s.done) (void)hipEventDestroy(s.done);

@@ -143,6 +143,20 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 }
 
 
+// Words that one workgroup leaves for another are 64 bits: the launch's epoch in the high half (the buffers are never
+// cleared: words of earlier launches carry older epochs and read as "not there yet"), the payload in the low half.  Every
+// word is complete in itself, so publishing one is a single relaxed store at device scope and needs no fence.
+__device__ __forceinline__ void look_put(uint64_t *w, uint32_t epoch, uint32_t v)
+{
+    __hip_atomic_store(w, (static_cast<uint64_t>(epoch) << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool look_get(const uint64_t *w, uint32_t epoch, uint32_t *v)
+{
+    const uint64_t x = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *v = static_cast<uint32_t>(x);
+    return static_cast<uint32_t>(x >> 32) == epoch;
+}
+
 // ---- fused post-decode stage (Post in mcraw_plan.h) ---------------------------------------------
 //
 // 8 consecutive samples of row y starting at an even column arrive as four dwords of (even column |

@@ -73,8 +73,14 @@ struct Frame7 {
     uint32_t nblk;       // N = 4 * tilesX * encH/4 payload blocks; 0: nothing to decode (the header was rejected)
     uint32_t fast_store;
     uint32_t encH;
+    // A side stream can be resolved by several workgroups ("parts", Work7::nsplit[]), each of which owns a range of the stream's
+    // 32 KiB pieces.  A part of the bits stream writes the payload offsets of ITS items relative to its own first item; what
+    // k7_tiles adds to an offset: part_len[q] for every q with part_item[q] <= item.
+    uint32_t part_item[3]; // first decode item of parts 1..3 of the bits stream (0xFFFFFFFF: no such part, or it had nothing to do)
+    uint32_t part_len[3];  // payload bytes of parts 0..2 (part 0: up to the end of its last item, the 16-byte header included)
     uint32_t pad;
 };
+constexpr int MAX_SPLIT7 = 4; // parts per side stream, at most
 
 // Batch-wide view of the type-7 work, passed to the kernels BY VALUE (kernarg):
 // every workspace array has the same per-frame stride (sized for the largest
@@ -83,14 +89,18 @@ struct Frame7 {
 struct Work7 {
     const Plan7 *plans;  // [n7] in pinned host memory (read by k7_side only)
     Frame7 *frames;      // [n7] in HBM (written by k7_side, read by k7_tiles)
-    int32_t *status;     // [nstatus] status words: two per type-7 frame (its bits / refs stream, each written once,
-                         // by a plain store: nothing to initialise), then one per legacy frame, then
+    int32_t *status;     // [nstatus] status words: nsplit[0] + nsplit[1] per type-7 frame (one per part of its bits / refs stream,
+                         // each written once, by a plain store: nothing to initialise), then one per legacy frame, then
                          // [n7] the coded height of every type-7 frame (read back with the statuses)
     uint8_t *bits;       // [n7][Rmax*64]  decoded `bits` stream  (:557)
     uint16_t *refs;      // [n7][Rmax*64]  decoded `refs` stream  (:560)
     uint32_t *grp_off;   // [n7][Rmax*ITEM_SPLIT+1] payload byte offset of every decode item (:562 + prefix of LEN)
     uint32_t Rmax;       // largest ngroups in the batch
-    uint32_t nstatus;    // status words in front of the coded heights (2 * n7 + legacy frames + 1)
+    uint32_t nstatus;    // status words in front of the coded heights ((nsplit[0] + nsplit[1]) * n7 + legacy frames + 1)
+    uint32_t nsplit[2];  // workgroups ("parts") per bits / refs stream, 1 .. MAX_SPLIT7: long streams of small batches are cut up
+    uint64_t *sync;      // [n7][2][MAX_SPLIT7][2] what a part tells the next one (epoch-tagged words, never cleared): records up to
+                         // the end of its pieces; where the chain enters the next part's first piece
+    uint32_t epoch;      // ... of this launch
     int32_t n7;
     Post post;           // fused post-decode stage (mode 0: none)
     uint32_t xcd_chunk;  // k7_tiles: logical items per XCD run (0: one run per XCD = the whole grid in eight parts)

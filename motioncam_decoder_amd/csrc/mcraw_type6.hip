@@ -48,17 +48,6 @@ constexpr uint32_t SPIN6 = 1u << 12;
 constexpr uint32_t SPIN6 = 1u << 20;              // polls before a workgroup gives the frame up (never seen; a hang is worse)
 #endif
 
-__device__ __forceinline__ void look_put(uint64_t *w, uint32_t epoch, uint32_t v)
-{
-    __hip_atomic_store(w, (static_cast<uint64_t>(epoch) << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ bool look_get(const uint64_t *w, uint32_t epoch, uint32_t *v)
-{
-    const uint64_t x = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *v = static_cast<uint32_t>(x);
-    return static_cast<uint32_t>(x >> 32) == epoch;
-}
-
 // Samples 4*qt..4*qt+3 of the record at byte `ro` of the staged stream, reference NOT yet added;
 // *ref receives the header's 12-bit reference (RawData_Legacy.cpp:372-375).  The payload is an
 // MSB-first bitstream of sb-bit fields (sb = header nibble for <= 10, 16 big-endian raw bits above,

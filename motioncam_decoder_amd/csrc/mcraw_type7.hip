@@ -241,8 +241,26 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     // First one side stream of every frame, then the other.  At 240 frames two workgroups share a CU, and they are the ones
     // 256 apart in the launch: with the streams of a frame side by side (2 f + s) those were two of the same kind -- two long
     // ones on half of the CUs --, now they are one of each: k7_side 71 -> 67 us (six interleaved pairs of runs, tools/ab.sh).
-    const uint32_t nfr = static_cast<uint32_t>(W.n7);
-    const uint32_t s = blockIdx.x >= nfr ? 1u : 0u, f = blockIdx.x - (s ? nfr : 0u), fs = 2u * f + s;
+    // A long stream of a small batch is cut into PARTS (round 4; W.nsplit[stream]): every part owns a range of the stream's
+    // pieces, [m_lo, m_hi), and the records that START in them.  What a part needs to know -- where in its first piece the
+    // chain enters, and the index of its first record -- only the chain itself says, so:
+    //   phase 1  every part but the last follows the chain through its pieces with the walker alone and COUNTS (no record
+    //            is decoded: a unit costs its walk and two barriers).  Part 0 starts on the stream's first record; the others
+    //            start half a piece in front of their range on a byte that is most likely no record at all: a wrong chain reads
+    //            payload bytes as headers and falls onto the true one within a few hundred bytes (k7_side's segment walkers and
+    //            the legacy kernel's rest on the same fact).  All parts do this at the same time.
+    //   hand-off part p waits for what part p - 1 says (W.sync: records up to the end of its pieces, and where the chain enters
+    //            the next piece), checks that its own chain entered its range exactly there -- nothing is taken on trust --,
+    //            and says the same for its own range.  A chain of one hop per part.
+    //   phase 2  the pipeline below (walk, decode, offsets) over the part's pieces, from the entry and the record index it now
+    //            knows.  A part whose speculation failed starts it from what its predecessor said (and says its own afterwards);
+    //            one whose predecessor never speaks (workgroups started out of order and the chip is full) follows the chain
+    //            from the stream's first record by itself.  Payload offsets are relative to the part's first item; k7_tiles adds
+    //            the totals of the parts in front (Frame7::part_item, part_len).
+    const uint32_t nfr = static_cast<uint32_t>(W.n7), nsb = W.nsplit[0], nsr = W.nsplit[1];
+    const uint32_t bq = blockIdx.x / nfr, f = blockIdx.x - bq * nfr;
+    const uint32_t s = bq < nsr ? 1u : 0u, part = s ? bq : bq - nsr, nsp = s ? nsr : nsb; // (the longer stream's parts first)
+    const uint32_t fs = (nsb + nsr) * f + (s ? nsb : 0u) + part;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef MCRAW_DIAG
@@ -315,19 +333,22 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         }
     }
     SIDE_STAMP(11); // header + count here
-    if (s == 0u && tid == 0u) {
-        Frame7 F;
-        F.in = P->in;
-        F.out = P->out;
-        F.len = len;
-        F.width = P->width;
-        F.rows = min(static_cast<uint32_t>(P->height), encH);
-        F.tilesX = tilesX;
-        F.nblk = err ? 0u : nblk; // a frame rejected here is not touched by k7_tiles
-        F.fast_store = P->fast_store;
-        F.encH = encH;
-        F.pad = 0u;
-        W.frames[f] = F;
+    Frame7 *const FR = W.frames + f;
+    if (s == 0u && part == 0u && tid == 0u) { // (field by field: part_item[q] / part_len[q] of the parts that exist belong to them)
+        FR->in = P->in;
+        FR->out = P->out;
+        FR->len = len;
+        FR->width = P->width;
+        FR->rows = min(static_cast<uint32_t>(P->height), encH);
+        FR->tilesX = tilesX;
+        FR->nblk = err ? 0u : nblk; // a frame rejected here is not touched by k7_tiles
+        FR->fast_store = P->fast_store;
+        FR->encH = encH;
+        FR->pad = 0u;
+        for (uint32_t q = err ? 0u : nsb - 1u; q < 3u; q++) {
+            FR->part_item[q] = 0xFFFFFFFFu;
+            FR->part_len[q] = 0u;
+        }
         W.status[W.nstatus + f] = static_cast<int32_t>(encH); // read back with the statuses (rows written = min(height, encH))
     }
     if (err) {
@@ -335,6 +356,20 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             *status = err;
         return;
     }
+    // The pieces of this part.  Where the stream ends is not known before its chain has been followed; the split is made
+    // on a guess -- the stream reaches to where the other one starts, or to the end of the frame, as encoders lay them
+    // out -- and any guess gives a partition: the ranges are disjoint, the last part's is open-ended.
+    uint32_t m_lo = 0u, m_hi = 0xFFFFFFFFu;
+    if (nsp > 1u) {
+        const uint32_t other = s ? bitsOff : refsOff;
+        const uint64_t end_guess = other > so ? other : len;
+        const uint64_t npieces = (end_guess - A0 + SIDE_PIECE - 1u) / SIDE_PIECE; // (A0 <= so + 4 <= len, end_guess > so)
+        m_lo = static_cast<uint32_t>(part * npieces / nsp);
+        if (part + 1u < nsp)
+            m_hi = static_cast<uint32_t>((part + 1u) * npieces / nsp);
+    }
+    uint64_t *const sync = W.sync + (static_cast<size_t>(2u * f + s) * MAX_SPLIT7 + part) * 2u; // mine; sync[-2], sync[-1]: the part in front
+    constexpr uint32_t ENDX = 0xFFFFFFFFu; // hand-off: the stream is over (its last record lies in front, or the chain has ended)
 
     uint8_t *bits = W.bits + static_cast<size_t>(f) * W.Rmax * 64u;
     uint16_t *refs = W.refs + static_cast<size_t>(f) * W.Rmax * 64u;
@@ -343,10 +378,17 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     uint32_t upc = 0;                      // piece of the unit just walked (the decoders' next work)
     uint32_t bb = 0;                       // piece whose bytes are in s_b
     uint32_t tb = 0;                       // piece whose strides are in s_T
-    uint32_t n = 0;                        // records decoded
-    uint64_t carry = 16u;                  // payload offset of the next item (RawData.cpp:562)
+    uint32_t n = 0;                        // records in front of the unit just walked (their index, when `known_n`)
+    uint64_t carry = 0u;                   // payload offset of the next item (RawData.cpp:562), relative to the part's first item
+    uint32_t n_first = 0xFFFFFFFFu;        // first record this part decodes (none yet)
     int32_t lane_err = 0;                  // per lane (a bits entry above 16)
     bool dead = false;                     // uniform: the chain ended before R records
+    uint32_t decode_from = 0u;             // units of pieces in front of this one are walked, not decoded
+    constexpr uint32_t NOENTRY = 0xFFFFFFFEu;
+#ifndef MCRAW_SPEC_WARM
+#define MCRAW_SPEC_WARM 1024
+#endif
+    constexpr uint32_t SPEC_WARM = MCRAW_SPEC_WARM; // candidates (2 bytes each) in front of its pieces at which a speculative count starts
 
     // registers -> bytes of a piece (what the decoders read)
     auto store_bytes = [&](const Lines &r) {
@@ -556,17 +598,7 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     };
 
     const uint32_t k = lane & 7u, sub = lane >> 3;
-    // prologue: piece 0 in LDS, pieces 1 and 2 on their way, first unit walked
-    store_bytes(nx);
-    SIDE_STAMP(12); // piece 0 arrived
-    build_strides(nx, 0u);
-    load_piece(nx, 1u);
-    load_piece(ny, 2u);
-    lds_barrier();
-    SIDE_STAMP(13);
-    if (wave == 0u)
-        walk(0u, static_cast<uint32_t>((so + 4u) & 15u) >> 1, 0u, min(R, SIDE_LCAP / 4u), true); // a short first unit: the decoders start early
-    SIDE_STAMP(14);
+    const uint32_t first_cand = static_cast<uint32_t>((so + 4u) & 15u) >> 1; // the stream's first record, behind the 4-byte count
     // S (wave 0, bits stream): item lengths of one unit -> payload offsets: exclusive scan, eight items per lane and pass
     static_assert((2u * SIDE_LCAP) % 512u == 0u, "whole passes of 512 items");
     auto scan_unit = [&](uint32_t par, uint32_t n0, uint32_t cnt) {
@@ -598,8 +630,182 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         }
     };
 
+    // ---- hand-off between the parts of a stream
+#ifdef MCRAW_INJECT_MUTE7 // test builds (tests/test_gpu_split.py): the first part of every stream never tells, the others give up soon
+    constexpr uint32_t SPIN7 = 1u << 6;
+#else
+    constexpr uint32_t SPIN7 = 1u << 19; // polls before a part stops waiting and follows the chain from the stream's start by itself
+#endif
+    __shared__ uint32_t s_ask[4];
+    bool told = part + 1u >= nsp; // what the next part needs has been said (the last part has nobody to tell)
+    auto tell = [&](uint32_t count, uint32_t where) { // records in front of the next part's pieces; candidate at which the chain enters them
+        if (!told && tid == 0u) {
+#ifdef MCRAW_INJECT_MUTE7
+            if (part != 0u)
+#endif
+            {
+                look_put(sync, W.epoch, count);
+                look_put(sync + 1, W.epoch, where);
+            }
+        }
+        told = true;
+    };
+    // what the part in front says (all threads; false: it never spoke)
+    auto ask = [&](uint32_t &count, uint32_t &where) {
+        lds_barrier();
+        if (tid == 0u) {
+            uint32_t c = 0u, w = first_cand, ok = 1u;
+            if (part) {
+                ok = 0u;
+                for (uint32_t spin = 0; spin < SPIN7; spin++) {
+                    if (look_get(sync - 2, W.epoch, &c) && look_get(sync - 1, W.epoch, &w)) {
+                        ok = 1u;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            s_ask[0] = c;
+            s_ask[1] = w;
+            s_ask[2] = ok;
+        }
+        lds_barrier();
+        count = s_ask[0];
+        where = s_ask[1];
+        return s_ask[2] != 0u;
+    };
+    auto nothing_to_decode = [&]() { // (bits stream: this part adds nothing to the payload offsets)
+        if (tid == 0u && s == 0u && nsp > 1u) {
+            if (part + 1u < nsp)
+                FR->part_len[part] = 0u;
+            if (part)
+                FR->part_item[part - 1u] = 0xFFFFFFFFu;
+        }
+    };
+
+    // ---- phase 1 (count) and the hand-off: where phase 2 starts
+    uint32_t run_piece = 0u, run_cand = first_cand, run_n = 0u; // piece, candidate in it, records in front of it
+    uint32_t nx_piece = 0u;                                       // the piece that is on its way into nx
+    uint32_t exitc = ENDX;                                        // where the chain enters piece m_hi (phase 2, when it still has to be said)
+    bool go = true;
+    if (nsp > 1u) {
+        const bool empty = m_lo >= m_hi, lastp = part + 1u >= nsp;
+        const bool owns0 = !empty && m_lo == 0u; // the part that owns piece 0 (part 0, or the parts in front of this one own nothing)
+        const bool spec = !empty && !lastp && !owns0;
+        uint32_t entry = NOENTRY, cnt1 = 0u, exit1 = ENDX; // where the chain enters piece m_lo; records of the part's pieces; where it enters piece m_hi
+        bool dead1 = false;                                // ... it ended inside the part's pieces
+        if (!empty && !lastp) {
+            // The count: the walker alone, over the part's pieces -- from the stream's first record, or (spec) from SPEC_WARM
+            // candidates in front of them, on a byte that is most likely no record at all.
+            uint32_t cpiece = spec ? m_lo - 1u : 0u, lst = 0u;
+            if (spec)
+                load_piece(nx, cpiece);
+            build_strides(nx, cpiece);
+            load_piece(nx, cpiece + 1u);
+            nx_piece = cpiece + 1u;
+            lds_barrier();
+            if (wave == 0u)
+                walk(0u, spec ? SIDE_HALF - SPEC_WARM : first_cand, 0u, spec ? SIDE_LCAP : min(R, SIDE_LCAP), true);
+            for (;;) {
+                lds_barrier();
+                const uint4 st4 = *reinterpret_cast<const uint4 *>(s_st[lst]);
+                const uint32_t pu = __builtin_amdgcn_readfirstlane(st4.x);
+                const uint32_t total = __builtin_amdgcn_readfirstlane(st4.y);
+                const uint32_t why = __builtin_amdgcn_readfirstlane(st4.z);
+                const uint32_t SU = __builtin_amdgcn_readfirstlane(st4.w);
+                const uint32_t npc = why == 2u ? cpiece + 1u : cpiece;
+                if (cpiece >= m_lo) {
+                    cnt1 += total;
+                    dead1 = dead1 || why == 3u;
+                }
+                if (npc > cpiece && npc == m_lo) {
+                    entry = pu - SIDE_HALF;
+#ifndef MCRAW_FORCE_SEGW // (what the chain looked like while it ran over payload bytes says nothing about the stream)
+                    segw = false;
+#endif
+                    seg_valid = false;
+                }
+                if (npc > cpiece && npc == m_hi)
+                    exit1 = pu - SIDE_HALF;
+                if ((!spec && cnt1 >= R) || why == 3u || npc >= m_hi)
+                    break;
+                if (npc > cpiece) { // (the walker has left the piece whose strides are in s_T)
+                    build_strides(nx, npc);
+                    load_piece(nx, npc + 1u);
+                    nx_piece = npc + 1u;
+                    lds_barrier();
+                }
+                if (wave == 0u)
+                    walk(lst ^ 1u, npc > cpiece ? pu - SIDE_HALF : pu, SU, spec ? SIDE_LCAP : min(R - cnt1, SIDE_LCAP), npc > cpiece);
+                cpiece = npc;
+                lst ^= 1u;
+            }
+            SIDE_STAMP(20); // count over
+        }
+        // The hand-off: what the part in front says, what this part says, where its decode starts.
+        uint32_t pn = 0u, pw = first_cand;
+        const bool ok = owns0 ? true : ask(pn, pw);
+        SIDE_STAMP(21); // the part in front has spoken
+        decode_from = m_lo;
+        if (!ok) { // it never spoke: from the stream's first record on, by itself (and this part says its own at the end)
+            if (empty) { // (a part that owns nothing only has to find out what to pass on)
+                decode_from = 0xFFFFFFFFu;
+                if (m_hi == 0u) {
+                    tell(0u, first_cand);
+                    nothing_to_decode();
+                    go = false;
+                }
+            }
+        } else if (!owns0 && (pw == ENDX || pn >= R)) { // the stream is over in front of this part
+            tell(pn, ENDX);
+            nothing_to_decode();
+            go = false;
+        } else if (empty) { // nothing of the stream falls to this part: pass it on
+            tell(pn, pw);
+            nothing_to_decode();
+            go = false;
+        } else if (lastp) {
+            run_piece = m_lo, run_cand = owns0 ? first_cand : pw, run_n = pn;
+        } else if (owns0 || pw == entry) { // the count stands: say it, then decode
+            const uint32_t upto = pn + cnt1;
+            tell(min(upto, R), upto >= R || dead1 || exit1 == ENDX ? ENDX : exit1);
+            run_piece = m_lo, run_cand = owns0 ? first_cand : entry, run_n = pn;
+        } else { // the chain enters this part's pieces elsewhere: decode from there, and say afterwards what comes out of it
+            run_piece = m_lo, run_cand = pw, run_n = pn;
+        }
+        if (go && run_n >= R) { // (nothing left of the stream)
+            tell(run_n, ENDX);
+            nothing_to_decode();
+            go = false;
+        }
+    }
+
     uint32_t cur = 0;                 // list (and item-length buffer) of the unit the decoders work on
     uint32_t prev_n = 0, prev_total = 0; // the unit before it, not yet scanned
+    if (go) {
+    // ---- phase 2.  Prologue: the first piece in LDS, the next two on their way, first unit walked
+    lds_barrier(); // (every wave is done with the count)
+    upc = bb = tb = run_piece;
+    n = run_n;
+#ifdef MCRAW_FORCE_SEGW
+    segw = true;
+#else
+    segw = false;
+#endif
+    seg_valid = false;
+    carry = run_piece == 0u && decode_from == 0u ? 16u : 0u; // (the part that decodes the stream's first record starts behind the 16-byte header)
+    if (nx_piece != run_piece)
+        load_piece(nx, run_piece);
+    store_bytes(nx);
+    SIDE_STAMP(12); // first piece arrived
+    build_strides(nx, run_piece);
+    load_piece(nx, run_piece + 1u);
+    load_piece(ny, run_piece + 2u);
+    lds_barrier();
+    SIDE_STAMP(13);
+    if (wave == 0u) // a short first unit: the decoders start early
+        walk(0u, run_cand, 0u, min(R - run_n, SIDE_LCAP / 4u), true);
+    SIDE_STAMP(14);
     while (true) {
         lds_barrier();
         SIDE_STAMP(0);
@@ -609,8 +815,13 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         const uint32_t total = __builtin_amdgcn_readfirstlane(st4.y);
         const uint32_t why = __builtin_amdgcn_readfirstlane(st4.z);
         const uint32_t SU = __builtin_amdgcn_readfirstlane(st4.w);
-        const bool last = n + total >= R || why == 3u;
         const uint32_t npc = why == 2u ? upc + 1u : upc; // piece of the next unit
+        const bool last = n + total >= R || why == 3u || npc >= m_hi; // (... or the next unit is the next part's)
+        const bool skip = upc < decode_from;             // a unit in front of this part's pieces: walked, not decoded
+        if (!skip && n_first == 0xFFFFFFFFu)
+            n_first = n;
+        if (npc > upc && npc == m_hi)
+            exitc = pu - SIDE_HALF;
         const bool moved = upc > bb, build = !last && npc > tb;
         if (moved) { // the decoders move on to piece bb + 1: every unit of piece bb has been decoded
             store_bytes(nx);
@@ -632,7 +843,7 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             if (s == 0u && prev_total) // the unit the decoders finished before the last barrier
                 scan_unit(cur ^ 1u, prev_n, prev_total);
             SIDE_STAMP(5);
-        } else {
+        } else if (!skip) {
             // D: record decode, lane = (record, k) owns samples 8k..8k+7; the list entry and header of the
             // next pass are fetched while this pass is unpacked
             const uint8_t *B = s_b;
@@ -704,15 +915,16 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             SIDE_STAMP(3);
         }
         prev_n = n;
-        prev_total = total;
+        prev_total = skip ? 0u : total;
         n += total;
         if (last) {
-            dead = n < R;
+            dead = why == 3u && n < R && !skip; // (a chain that ends in front of this part's pieces is the owner's to report)
             break;
         }
         upc = npc;
         cur ^= 1u;
     }
+    tell(min(n, R), n >= R || dead || exitc == ENDX ? ENDX : exitc); // (a part that could not say it behind its count)
     if (s == 0u && prev_total) { // the last unit's offsets
         lds_barrier();
         if (wave == 0u)
@@ -721,11 +933,21 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     if (tid == 0u) {
         if (dead) // a record crosses `len` before the stream has its R records (RawData.cpp:419-420)
             lane_err |= MCRAW_E_TRUNCATED;
-        if (s == 0u && !dead) {
-            goff[ITEM_SPLIT * R] = static_cast<uint32_t>(min(carry, static_cast<uint64_t>(0xffffffffu)));
-            if (carry > len) // some block crosses `len` (RawData.cpp:419-420)
-                lane_err |= MCRAW_E_TRUNCATED;
+        if (s == 0u) {
+            const uint32_t c32 = static_cast<uint32_t>(min(carry, static_cast<uint64_t>(0xffffffffu)));
+            if (n >= R && !dead && n_first != 0xFFFFFFFFu) { // the part that decodes the stream's last record: where the payload ends
+                goff[ITEM_SPLIT * R] = c32;
+                if (nsp == 1u && carry > len) // some block crosses `len` (RawData.cpp:419-420); with several parts k7_tiles
+                    lane_err |= MCRAW_E_TRUNCATED; // makes this check, behind the sum over the parts
+            }
+            if (nsp > 1u) {
+                if (part + 1u < nsp)
+                    FR->part_len[part] = n_first != 0xFFFFFFFFu ? c32 : 0u;
+                if (part)
+                    FR->part_item[part - 1u] = n_first != 0xFFFFFFFFu ? ITEM_SPLIT * n_first : 0xFFFFFFFFu;
+            }
         }
+    }
     }
     // one status word per stream, written once (no initialisation needed in front of the kernel)
     if (lane_err)
@@ -784,6 +1006,30 @@ __device__ __forceinline__ ItemS item_scalars(const Work7 &W, uint32_t item, uin
     if (I.valid) {
         start = grp[0];
         end = grp[1];
+        if (W.nsplit[0] > 1u) { // offsets are relative to the first item of the part of k7_side that wrote them
+            // the part an item belongs to: the last one whose first item is not behind it; the payload of all parts in front of
+            // that one lies in front of the item (parts that had nothing to decode say no first item and a length of 0)
+            uint32_t ps = 0u, pe = 0u, sum_s = 0u;
+            uint64_t e64 = end;
+#pragma unroll
+            for (uint32_t q = 0; q < 3u; q++) {
+                const uint32_t pi = F->part_item[q];
+                ps = g >= pi ? q + 1u : ps;
+                pe = g + 1u >= pi && pi != 0xFFFFFFFFu ? q + 1u : pe;
+            }
+#pragma unroll
+            for (uint32_t q = 0; q < 3u; q++) {
+                const uint32_t pl = F->part_len[q];
+                sum_s += q < ps ? pl : 0u;
+                e64 += q < pe ? pl : 0u;
+            }
+            start += sum_s;
+            end = static_cast<uint32_t>(e64);
+            // the payload's end against `len` (RawData.cpp:419-420: some block would cross it), checked here because no part of
+            // k7_side knows the sum; by the wave of the frame's last item
+            if ((g + 1u) * ITEM_BLOCKS >= nblk && e64 > F->len)
+                atomicOr(W.status + (W.nsplit[0] + W.nsplit[1]) * f, MCRAW_E_TRUNCATED);
+        }
     }
     I.g = g;
     I.nblk = nblk;
@@ -991,7 +1237,7 @@ void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st)
     const uint32_t n7 = static_cast<uint32_t>(W.n7);
     switch (stage) {
     case MCRAW_K7_SIDE:
-        hipLaunchKernelGGL(k7_side, dim3(2 * n7), dim3(SIDE_T), 0, st, W);
+        hipLaunchKernelGGL(k7_side, dim3(n7 * (W.nsplit[0] + W.nsplit[1])), dim3(SIDE_T), 0, st, W);
         break;
     case MCRAW_K7_TILES: {
 #ifdef MCRAW_DIAG // timing experiments of the same kernel (see item_decode); not in the product library

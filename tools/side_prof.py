@@ -37,7 +37,7 @@ for _ in range(reps):
 torch.cuda.synchronize()
 lib.mcraw_diag_side_prof(prof, 1)
 names = {0: "top(after barrier)", 1: "moved/build done", 2: "walk done", 5: "scan done", 3: "decode done", 10: "plan read", 11: "header+count",
-         12: "piece0 stored", 13: "strides0+barrier", 14: "first walk", 15: "end"}
+         20: "count run over", 21: "part in front has spoken", 12: "piece0 stored", 13: "strides0+barrier", 14: "first walk", 15: "end"}
 for wv in (0, 1):
     row = prof[256 * wv: 256 * wv + 256]
     cnt = int(row[0])
