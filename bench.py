@@ -313,7 +313,10 @@ def cpu_baseline(L, wl, seconds):
     n = len(bufs)
     ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
     lens = (C.c_size_t * n)(*[b.size for b in bufs])
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0)) # (the CPUs this process may run on)
+    except AttributeError:
+        cores = os.cpu_count() or 1
     res = {}
     for label, th in (("all", cores), ("one", 1)):
         t = fn(7, wl.w, wl.h, ptrs, lens, n, th, 1)  # one calibration pass
@@ -581,7 +584,7 @@ def legacy_leg(torch, ctx, M, L, dev, n=32, w=4000, h=3000, nbits=12, sigma=12.0
     out["algorithmic_bytes_per_batch"] = byts
     if kms["k6_decode"] > 0:
         out["frac"] = round(byts / (kms["k6_decode"] * 1e-3) / 1e9 / 8000.0, 4)
-    for tag in ("r03", "r02"):
+    for tag in ("r04", "r03", "r02"):
         try:
             with open(os.path.join(ROOT, "profiles", tag + "_legacy_traffic.json")) as f:
                 tj = json.load(f)
@@ -590,6 +593,53 @@ def legacy_leg(torch, ctx, M, L, dev, n=32, w=4000, h=3000, nbits=12, sigma=12.0
             break
         except Exception:
             continue
+    return out
+
+
+def config5_leg(torch, ctx, M, L, dev, n=120, w=7680, h=4320, nbits=12, sigma=12.0, reps=8, distinct=4):
+    """One rank's share of BASELINE config 5 (120 frames of 7680x4320, 12-bit, type 7, resident in HBM): the step against the HBM
+    peak, and its two kernels -- an 8K frame's side streams are four times as long as a UHD frame's, and k7_side follows a chain.
+    Not the bench line; `python bench.py --config 5` times the same workload with rounds and spread."""
+    def one(seed):
+        img = L.synth_image(w, h, nbits, 1, sigma, seed)
+        return img, L.encode7(img)
+    with ThreadPoolExecutor(max_workers=distinct) as ex:
+        pairs = list(ex.map(one, [5000 + i for i in range(distinct)]))
+    lens = [p[1].size for p in pairs]
+    tin = [torch.from_numpy(pairs[i % distinct][1]).to(dev) for i in range(n)]  # (distinct addresses: every frame's bytes come from HBM)
+    tout = torch.zeros(n * w * h * 2, dtype=torch.uint8, device=dev)
+    frames = M.Context.make_frames([(tin[i].data_ptr(), lens[i % distinct], w, h, M.TYPE_BLOCK, tout.data_ptr() + i * w * h * 2, w * h)
+                                    for i in range(n)])
+    written, status = ctx.decode_batch(frames)
+    ok = all(s == 0 for s in status) and all(wr == w * h for wr in written)
+    for i in (0, n - 1):
+        got = tout[i * w * h * 2:(i + 1) * w * h * 2].cpu().numpy().view(np.uint16).reshape(h, w)
+        ok = ok and np.array_equal(got, pairs[i % distinct][0])
+    orc = L.oracle()
+    used = [orc.mcraw_oracle_len_used7(L._ptr(p[1]), p[1].size) for p in pairs]
+    byts = sum(used[i % distinct] for i in range(n)) + n * w * h * 2
+    ctx.profile(False)
+    for _ in range(8):  # (the library times its XCD mapping of k7_tiles on the first launches on a new set of buffers)
+        ctx.decode_batch(frames, want_status=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.decode_batch(frames, want_status=False)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / reps
+    ctx.profile(True)
+    for k in M.KERNELS:
+        ctx.kernel_ms(k, reset=True)
+    for _ in range(3):
+        ctx.decode_batch(frames, want_status=False)
+    torch.cuda.synchronize()
+    kms = {k: round(ctx.kernel_ms(k, reset=True)[0] / 3.0, 4) for k in ("k7_side", "k7_tiles")}
+    out = {"workload": "config 5, one rank's share: %d x %dx%d %d-bit type-7 frames, Nat" % (n, w, h, nbits), "ms_per_step": round(t * 1e3, 4),
+           "steps_timed": reps, "mpix_s": round(n * w * h / t / 1e6, 1), "algorithmic_bytes_per_step": byts,
+           "step_frac": round(byts / t / 1e9 / HBM_PEAK_GBS, 4), "kernels_ms_per_step": kms, "xcd_runs": ctx.xcd_runs(), "bit_exact": bool(ok)}
+    if kms["k7_tiles"] > 0:
+        out["frac"] = round(byts / (kms["k7_tiles"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    del tin, tout
     return out
 
 
@@ -676,7 +726,7 @@ def main():
     ctx = M.Context(local)
     ctx.profile(True)
 
-    dists = [args.dist] + ([] if (args.no_also or world > 1) else [("u" if args.dist == "nat" else "nat")])
+    dists = [args.dist] + ([] if args.no_also else [("u" if args.dist == "nat" else "nat")])  # (at every N: a SCALE line is as complete as the N = 1 line)
     results = {}
     calib = box_calibration(torch, dev) if rank == 0 else None
     for d in dists:
@@ -796,11 +846,17 @@ def main():
                                 "xcd_runs": s2["kernels_ms_per_step"].get("xcd_runs"),
                                 "bit_exact": results[d]["ok"]}
         out.update(extra)
-        if world == 1 and not args.no_cpu:
+        if not args.no_cpu: # (rank 0 alone, at every N: the other ranks wait at the barrier below)
             try:
                 out["legacy"] = legacy_leg(torch, ctx, M, L, dev)
             except Exception as e:
                 out["legacy"] = {"error": repr(e)}
+            if args.config != 5:
+                try:
+                    out["config5"] = config5_leg(torch, ctx, M, L, dev)
+                except Exception as e:
+                    out["config5"] = {"error": repr(e)}
+                torch.cuda.empty_cache()
             try:
                 out["mixed64"] = mixed64_leg(torch, ctx, M, L, dev)
             except Exception as e:
@@ -810,6 +866,11 @@ def main():
             except Exception as e:
                 out["post_stage"] = {"error": repr(e)}
             try:
+                if world > 1: # this rank was bound to its GPU's NUMA node: the baseline is the NODE's cores
+                    try:
+                        os.sched_setaffinity(0, range(os.cpu_count() or 1))
+                    except OSError:
+                        pass
                 out["cpu_baseline"] = cpu_baseline(L, wl, args.cpu_seconds)
             except Exception as e:  # the baseline is a report, never a reason to lose the GPU line
                 out["cpu_baseline"] = {"error": repr(e)}

@@ -103,6 +103,14 @@ int mcraw_ticket_wait(mcraw_ticket *ticket, size_t *written, int32_t *status);
 /* Wait for everything submitted on the context; fetch the statuses of the
  * last batch (status may be NULL).  Returns 0 or negative. */
 int mcraw_ctx_synchronize(mcraw_ctx *ctx, int32_t *status, int nframes);
+/* Device-memory batches submitted WITHOUT a status request, several in a row (the reference's loop, example.cpp:187-195, run as
+ * batches that follow each other on the GPU): every device-memory batch of a context has a serial number (the last one
+ * submitted: mcraw_ctx_last_serial); mcraw_ctx_batch_status waits for that batch and returns its statuses (0; 1 when the
+ * serial is not one of the last 64 such batches); mcraw_ctx_errors returns the OR of the statuses of all frames of such
+ * batches whose statuses became known since the last call with `reset` (mcraw_ctx_synchronize makes all of them known). */
+uint64_t mcraw_ctx_last_serial(mcraw_ctx *ctx);
+int mcraw_ctx_batch_status(mcraw_ctx *ctx, uint64_t serial, int32_t *status, int nframes);
+int32_t mcraw_ctx_errors(mcraw_ctx *ctx, int reset);
 
 /* ---- several GPUs of one node (device pool) --------------------------------------------------
  *
@@ -140,11 +148,16 @@ int mcraw_pool_decode_batch(mcraw_pool *pool, const mcraw_frame *frames, int nfr
 /* The same for buffers that are already resident: frames[i].in / .out are device pointers in the HBM of the GPU that
  * decodes frame i, mcraw_pool_device(pool, i % mcraw_pool_size(pool)) -- BASELINE config 5's form (a clip sharded over
  * the node's GPUs by frame index; lib/Decoder.cpp:184-235 run as one batch).  With `written` or `status` it returns when
- * every member's share is decoded. */
+ * every member's share is decoded.  Where a frame's buffers live is CHECKED (hipPointerGetAttributes): a frame whose `in`
+ * or `out` is not device memory of the GPU that decodes it gets MCRAW_E_ARGS and is not decoded -- it would be decoded
+ * over xGMI at a fraction of the rate, or fault. */
 int mcraw_pool_decode_batch_device(mcraw_pool *pool, const mcraw_frame *frames, int nframes, size_t *written, int32_t *status);
 /* With `written` and `status` both NULL the call above only queues every member's share (each on its context's own stream)
- * and returns; mcraw_pool_synchronize waits for everything the members have queued and fetches the statuses of the last
- * resident batch (status may be NULL) -- several batches in a row then run back to back on every GPU. */
+ * and returns; several batches in a row then run back to back on every GPU.  mcraw_pool_synchronize waits for everything
+ * the members have queued and fetches the statuses of the CALLING THREAD's last such batch (status may be NULL) -- the pool
+ * may be used from several host threads at once, each sees its own.  It returns a negative value for a runtime failure, else
+ * the OR of the statuses of all frames of all queued batches (of any thread) whose outcome became known since the last
+ * call: 0 = every frame of every queued batch decoded. */
 int mcraw_pool_synchronize(mcraw_pool *pool, int32_t *status, int nframes);
 int mcraw_pool_decode_batch_async(mcraw_pool *pool, const mcraw_frame *frames, int nframes, mcraw_pool_ticket **ticket);
 int mcraw_pool_ticket_wait(mcraw_pool_ticket *ticket, size_t *written, int32_t *status);

@@ -104,6 +104,12 @@ def load():
                                        C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
     lib.mcraw_ctx_synchronize.restype = C.c_int
     lib.mcraw_ctx_synchronize.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
+    lib.mcraw_ctx_last_serial.restype = C.c_uint64
+    lib.mcraw_ctx_last_serial.argtypes = [C.c_void_p]
+    lib.mcraw_ctx_batch_status.restype = C.c_int
+    lib.mcraw_ctx_batch_status.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_int32), C.c_int]
+    lib.mcraw_ctx_errors.restype = C.c_int32
+    lib.mcraw_ctx_errors.argtypes = [C.c_void_p, C.c_int]
     lib.mcraw_ctx_profile.restype = C.c_int
     lib.mcraw_ctx_profile.argtypes = [C.c_void_p, C.c_int]
     lib.mcraw_ctx_profile_every.restype = C.c_int
@@ -225,10 +231,13 @@ class Pool:
         return (list(written)[:n], list(status)[:n]) if want_status else None
 
     def synchronize(self, n):
+        """Waits for everything queued; returns the statuses of the calling thread's last queued resident batch.
+        ``self.errors``: OR of the statuses of all frames of all queued batches whose outcome became known with this call."""
         status = (C.c_int32 * max(n, 1))()
         rc = self._lib.mcraw_pool_synchronize(self._h, status, n)
-        if rc != 0:
+        if rc < 0:
             raise McrawError("mcraw_pool_synchronize failed (%d): %s" % (rc, self._lib.mcraw_pool_last_error().decode()))
+        self.errors = rc
         return list(status)[:n]
 
     def decode_batch(self, frames):
@@ -333,6 +342,20 @@ class Context:
         if rc != 0:
             raise McrawError("mcraw_ctx_synchronize failed (%d): %s" % (rc, self._lib.mcraw_last_error().decode()))
         return list(status)[:nframes]
+
+    def last_serial(self):
+        return int(self._lib.mcraw_ctx_last_serial(self._h))
+
+    def batch_status(self, serial, nframes):
+        """Statuses of the device-memory batch `serial` that was submitted without a status request (None: not one of the last 64)."""
+        status = (C.c_int32 * max(nframes, 1))()
+        rc = self._lib.mcraw_ctx_batch_status(self._h, serial, status, nframes)
+        if rc < 0:
+            raise McrawError("mcraw_ctx_batch_status failed (%d): %s" % (rc, self._lib.mcraw_last_error().decode()))
+        return None if rc else list(status)[:nframes]
+
+    def errors(self, reset=True):
+        return int(self._lib.mcraw_ctx_errors(self._h, 1 if reset else 0))
 
     def set_post(self, black=None, pack12=False, bits=None):
         """Fused post-decode stage of the batches to come: black levels (4 values, CFA order

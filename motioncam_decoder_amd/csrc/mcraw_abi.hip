@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -89,6 +90,7 @@ struct Slot {
     size_t status_off = 0;
     Post post{0, 0, 0};
     bool unresolved = false;
+    uint64_t serial = 0; // of the device-memory batch in this slot
 };
 
 // One sub-batch of a host-memory batch, riding in a slot.
@@ -157,6 +159,12 @@ struct mcraw_ctx {
     int last_slot = -1;
     int last_n = 0;
     std::vector<int32_t> last_status; // its statuses once resolved
+    // every device-memory batch has a serial number; the statuses of the last few that were submitted WITHOUT a status
+    // request are kept once they are known (mcraw_ctx_batch_status), and their OR since the last look (mcraw_ctx_errors):
+    // a caller that queues batches back to back -- the device pool, from several host threads -- can still tell which failed
+    uint64_t serial = 0;
+    std::deque<std::pair<uint64_t, std::vector<int32_t>>> settled;
+    int32_t sticky = 0;
     std::mutex mu;
 };
 
@@ -660,8 +668,15 @@ int settle_slot(mcraw_ctx *c, Slot &s, std::vector<int32_t> *keep)
         c->post = s.post; // a frame planned again gets the post stage its batch was submitted with
         rc = resolve_device(c, s, s.frames.data(), n, c->aux, status.data(), encH.data());
         c->post = now;
+        if (rc == 0) {
+            for (int32_t v : status)
+                c->sticky |= v;
+            c->settled.emplace_back(s.serial, status);
+            if (c->settled.size() > 64)
+                c->settled.pop_front();
+        }
         if (keep)
-            keep->swap(status);
+            *keep = status;
         s.unresolved = false;
         s.frames.clear();
     }
@@ -800,6 +815,7 @@ int decode_device(mcraw_ctx *c, const mcraw_frame *frames, int n, hipStream_t st
     c->last_slot = static_cast<int>(sp - c->dslots);
     c->last_n = n;
     c->last_status.clear();
+    s.serial = ++c->serial;
     if (!written && !status_out) {
         s.frames.assign(frames, frames + n);
         s.post = c->post;
@@ -1345,6 +1361,50 @@ int mcraw_ctx_synchronize(mcraw_ctx *c, int32_t *status, int nframes)
             status[i] = i < static_cast<int>(c->last_status.size()) ? c->last_status[i] : 0;
     }
     return 0;
+}
+
+uint64_t mcraw_ctx_last_serial(mcraw_ctx *c)
+{
+    if (!c)
+        return 0;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return c->serial;
+}
+
+int mcraw_ctx_batch_status(mcraw_ctx *c, uint64_t serial, int32_t *status, int nframes)
+{
+    if (!c || nframes < 0 || (nframes > 0 && !status))
+        return -1;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(hipSetDevice(c->device));
+    for (int k = 0; k < NDSLOT; k++) { // still in its slot: wait for it and plan again what needs it
+        Slot &s = c->dslots[k];
+        if (s.busy && s.unresolved && s.serial == serial) {
+            const bool last = k == c->last_slot;
+            if (int rc = settle_slot(c, s, last ? &c->last_status : nullptr))
+                return rc;
+            if (last)
+                c->last_slot = -1;
+        }
+    }
+    for (const auto &e : c->settled)
+        if (e.first == serial) {
+            for (int i = 0; i < nframes; i++)
+                status[i] = i < static_cast<int>(e.second.size()) ? e.second[i] : 0;
+            return 0;
+        }
+    return 1; // not a batch submitted without a status request, or more than 64 such batches ago
+}
+
+int32_t mcraw_ctx_errors(mcraw_ctx *c, int reset)
+{
+    if (!c)
+        return 0;
+    std::lock_guard<std::mutex> lk(c->mu);
+    const int32_t v = c->sticky;
+    if (reset)
+        c->sticky = 0;
+    return v;
 }
 
 size_t mcraw_decode7(uint16_t *output, int width, int height, const uint8_t *input, size_t len)

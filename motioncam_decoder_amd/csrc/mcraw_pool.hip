@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <sched.h>
 
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <cstdio>
@@ -19,6 +21,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/mcraw_hip.h"
@@ -71,6 +74,9 @@ struct Member {
     std::condition_variable cv;
     std::deque<std::function<void()>> tasks;
     uint64_t submitted = 0, completed = 0;
+    // the same two counters for waiters that spin a little before they block: a hand-off through the condition variable
+    // alone costs a wake-up of 30 - 60 us each way, a quarter of a 240-frame batch's decode time
+    std::atomic<uint64_t> submitted_a{0}, completed_a{0};
     bool created = false, quit = false;
     int create_rc = 0;
     std::string create_err;
@@ -80,13 +86,22 @@ struct Member {
         std::unique_lock<std::mutex> lk(mu);
         tasks.push_back(std::move(fn));
         const uint64_t seq = ++submitted;
+        submitted_a.store(seq, std::memory_order_release);
         cv.notify_all();
         return seq;
     }
+    static constexpr int SPIN_US = 200; // how long a waiter polls before it blocks
     void wait(uint64_t seq)
     {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return completed >= seq; });
+        const auto t0 = std::chrono::steady_clock::now();
+        while (completed_a.load(std::memory_order_acquire) < seq) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(20000)) { // (a long task: block)
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return completed >= seq; });
+                return;
+            }
+            std::this_thread::yield();
+        }
     }
     void wait_created()
     {
@@ -125,8 +140,15 @@ struct Member {
             created = true;
             cv.notify_all();
         }
+        uint64_t taken = 0;
         for (;;) {
             std::function<void()> fn;
+            { // (a member that has just finished a task polls for the next one for a moment before it goes to sleep)
+                const auto t0 = std::chrono::steady_clock::now();
+                while (submitted_a.load(std::memory_order_acquire) == taken &&
+                       std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(SPIN_US))
+                    std::this_thread::yield();
+            }
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return !tasks.empty() || quit; });
@@ -134,11 +156,13 @@ struct Member {
                     break; // (quit, and nothing left to run)
                 fn = std::move(tasks.front());
                 tasks.pop_front();
+                taken++;
             }
             fn();
             {
                 std::unique_lock<std::mutex> lk(mu);
                 completed++;
+                completed_a.store(completed, std::memory_order_release);
                 cv.notify_all();
             }
         }
@@ -155,9 +179,23 @@ thread_local std::string g_pool_err;
 struct mcraw_pool {
     std::vector<Member *> members;
     std::mutex mu; // one batch at a time
-    std::vector<std::vector<int>> last_device_index; // per member: caller's indices of its frames in the last resident batch
-    int last_device_n = 0;
+    uint64_t id = 0; // (a later pool at the same address is another pool)
 };
+
+namespace {
+std::atomic<uint64_t> g_pool_ids{0};
+// The calling thread's last resident batch that was only queued (mcraw_pool_decode_batch_device without `written` / `status`):
+// which of its frames went to which member, under which serial number of that member's context, and what the host decided
+// about a frame by itself (MCRAW_E_ARGS).  One record per pool and host thread: mcraw_pool_synchronize reports a thread its OWN batch.
+struct Queued {
+    uint64_t pool_id = 0;
+    int n = 0;
+    std::vector<std::vector<int>> index; // per member: caller's indices of its frames
+    std::vector<uint64_t> serial;        // per member: its context's batch serial (0: nothing was submitted)
+    std::vector<int32_t> host_status;    // per frame
+};
+thread_local std::unordered_map<const mcraw_pool *, Queued> g_queued;
+} // namespace
 
 // A sharded batch in flight.
 struct mcraw_pool_ticket {
@@ -237,6 +275,7 @@ int mcraw_pool_create(const int *devices, int ndevices, mcraw_pool **out)
             return -static_cast<int>(hipErrorInvalidDevice);
         }
     mcraw_pool *p = new mcraw_pool();
+    p->id = ++g_pool_ids;
     for (int d : devs) {
         Member *m = new Member();
         m->device = d;
@@ -418,6 +457,63 @@ int mcraw_pool_ticket_wait(mcraw_pool_ticket *t, size_t *written, int32_t *statu
     return rc;
 }
 
+// Is `ptr` device memory of `device`?  hipPointerGetAttributes answers that (a look-up in the runtime's tables: ~0.3 us, 0.15 ms for
+// the 480 pointers of a 240-frame batch -- a seventh of the batch's decode time), so what it said about an ALLOCATION is
+// remembered per calling thread: a pointer inside a range that was seen before costs a binary search.  A range is asked about
+// again every 256th time it is hit (memory that was freed and allocated again on another GPU does not stay "known" for long).
+namespace {
+struct KnownRange {
+    uintptr_t base, end;
+    int device; // -1: not device memory
+    unsigned hits;
+};
+thread_local std::vector<KnownRange> g_ranges; // sorted by base
+} // namespace
+
+static bool resident_on(const void *ptr, int device)
+{
+    if (!ptr)
+        return false;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(ptr);
+    size_t lo = 0, hi = g_ranges.size();
+    while (lo < hi) { // last range with base <= a
+        const size_t mid = (lo + hi) / 2;
+        if (g_ranges[mid].base <= a)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    if (lo > 0 && a < g_ranges[lo - 1].end && (++g_ranges[lo - 1].hits & 255u) != 0u)
+        return g_ranges[lo - 1].device == device;
+    hipPointerAttribute_t at;
+    int dev = -1;
+    if (hipPointerGetAttributes(&at, ptr) != hipSuccess)
+        (void)hipGetLastError(); // (an unregistered host pointer is an error to HIP, not to us)
+    else if (at.type == hipMemoryTypeDevice)
+        dev = at.device;
+    void *base = nullptr;
+    size_t size = 0;
+    if (dev >= 0 && hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t *>(&base), &size, const_cast<void *>(ptr)) == hipSuccess && size) {
+        const uintptr_t b = reinterpret_cast<uintptr_t>(base);
+        if (lo > 0 && g_ranges[lo - 1].base == b) {
+            g_ranges[lo - 1] = {b, b + size, dev, 1u};
+        } else {
+            if (g_ranges.size() >= 4096) // (a caller with very many allocations: start over)
+                g_ranges.clear(), lo = 0;
+            g_ranges.insert(g_ranges.begin() + static_cast<long>(lo), KnownRange{b, b + size, dev, 1u});
+            // a new allocation may overlap stale neighbours (their memory was freed): drop them
+            for (size_t k = g_ranges.size(); k-- > 0;)
+                if (k != lo && g_ranges[k].base < b + size && g_ranges[k].end > b)
+                    g_ranges.erase(g_ranges.begin() + static_cast<long>(k)), lo -= k < lo ? 1 : 0;
+        }
+    } else {
+        (void)hipGetLastError();
+        if (lo > 0 && a < g_ranges[lo - 1].end) // (what was known about this address is no longer true)
+            g_ranges.erase(g_ranges.begin() + static_cast<long>(lo - 1));
+    }
+    return dev == device;
+}
+
 int mcraw_pool_decode_batch_device(mcraw_pool *p, const mcraw_frame *frames, int nframes, size_t *written, int32_t *status)
 {
     if (!p || nframes < 0 || (nframes > 0 && !frames)) {
@@ -427,8 +523,15 @@ int mcraw_pool_decode_batch_device(mcraw_pool *p, const mcraw_frame *frames, int
     const int G = static_cast<int>(p->members.size());
     std::vector<std::vector<mcraw_frame>> sub(G);
     std::vector<std::vector<int>> index(G);
+    std::vector<int32_t> host_status(nframes, 0);
     for (int i = 0; i < nframes; i++) { // frame i -> member i mod G: its buffers live in THAT member's HBM
         const int m = mcraw_shard_of(i, G);
+        // (checked, not assumed: a frame on another GPU would be decoded over xGMI at a fraction of the rate or fault, a
+        // host pointer would fault; neither shows on a one-GPU box)
+        if (!resident_on(frames[i].in, p->members[m]->device) || !resident_on(frames[i].out, p->members[m]->device)) {
+            host_status[i] = MCRAW_E_ARGS;
+            continue;
+        }
         sub[m].push_back(frames[i]);
         index[m].push_back(i);
     }
@@ -436,12 +539,10 @@ int mcraw_pool_decode_batch_device(mcraw_pool *p, const mcraw_frame *frames, int
     std::vector<std::vector<int32_t>> st(G);
     std::vector<int> rcs(G, 0);
     std::vector<std::string> errs(G);
-    std::vector<uint64_t> seq(G, 0);
+    std::vector<uint64_t> seq(G, 0), serial(G, 0);
     const bool async = !written && !status; // nobody asks: the members only queue their shares (mcraw_pool_synchronize waits)
     {
         std::lock_guard<std::mutex> lk(p->mu);
-        p->last_device_index = index;
-        p->last_device_n = nframes;
         for (int m = 0; m < G; m++) {
             wr[m].assign(sub[m].size(), 0);
             st[m].assign(sub[m].size(), 0);
@@ -453,6 +554,8 @@ int mcraw_pool_decode_batch_device(mcraw_pool *p, const mcraw_frame *frames, int
                                             async ? nullptr : wr[m].data(), async ? nullptr : st[m].data());
                 if (rcs[m] != 0)
                     errs[m] = mcraw_last_error();
+                else
+                    serial[m] = mcraw_ctx_last_serial(mem->ctx); // (this member's context is driven by this thread alone)
             });
         }
     }
@@ -470,6 +573,21 @@ int mcraw_pool_decode_batch_device(mcraw_pool *p, const mcraw_frame *frames, int
                 status[index[m][k]] = st[m][k];
         }
     }
+    for (int i = 0; i < nframes; i++)
+        if (host_status[i]) {
+            if (written)
+                written[i] = 0;
+            if (status)
+                status[i] = host_status[i];
+        }
+    if (async) { // what mcraw_pool_synchronize needs to report THIS thread its own batch
+        Queued &q = g_queued[p];
+        q.pool_id = p->id;
+        q.n = nframes;
+        q.index.swap(index);
+        q.serial.swap(serial);
+        q.host_status.swap(host_status);
+    }
     return rc;
 }
 
@@ -478,38 +596,57 @@ int mcraw_pool_synchronize(mcraw_pool *p, int32_t *status, int nframes)
     if (!p)
         return -1;
     const int G = static_cast<int>(p->members.size());
-    std::vector<std::vector<int>> index;
+    Queued mine;
     {
-        std::lock_guard<std::mutex> lk(p->mu);
-        index = p->last_device_index;
+        auto it = g_queued.find(p);
+        if (it != g_queued.end() && it->second.pool_id == p->id)
+            mine = it->second; // (kept: a second synchronize reports the same batch)
     }
-    index.resize(G);
+    mine.index.resize(G);
+    mine.serial.resize(G, 0);
     std::vector<std::vector<int32_t>> st(G);
     std::vector<int> rcs(G, 0);
+    std::vector<int32_t> sticky(G, 0);
     std::vector<std::string> errs(G);
     std::vector<uint64_t> seq(G, 0);
     for (int m = 0; m < G; m++) {
-        st[m].assign(index[m].size(), 0);
+        st[m].assign(mine.index[m].size(), 0);
         Member *mem = p->members[m];
         seq[m] = mem->run([&, m, mem] {
-            rcs[m] = mcraw_ctx_synchronize(mem->ctx, st[m].empty() ? nullptr : st[m].data(), static_cast<int>(st[m].size()));
+            rcs[m] = mcraw_ctx_synchronize(mem->ctx, nullptr, 0);
+            if (rcs[m] == 0 && mine.serial[m] && !st[m].empty()) {
+                const int r = mcraw_ctx_batch_status(mem->ctx, mine.serial[m], st[m].data(), static_cast<int>(st[m].size()));
+                if (r < 0)
+                    rcs[m] = r;
+            }
             if (rcs[m] != 0)
                 errs[m] = mcraw_last_error();
+            sticky[m] = mcraw_ctx_errors(mem->ctx, 1);
         });
     }
     int rc = 0;
+    int32_t any = 0;
     for (int m = 0; m < G; m++) {
         p->members[m]->wait(seq[m]);
         if (rcs[m] != 0 && rc == 0) {
             rc = rcs[m];
             g_pool_err = errs[m];
         }
+        any |= sticky[m];
         if (status)
-            for (size_t k = 0; k < index[m].size(); k++)
-                if (index[m][k] < nframes)
-                    status[index[m][k]] = st[m][k];
+            for (size_t k = 0; k < mine.index[m].size(); k++)
+                if (mine.index[m][k] < nframes)
+                    status[mine.index[m][k]] = st[m][k];
     }
-    return rc;
+    for (int i = 0; i < mine.n && i < static_cast<int>(mine.host_status.size()); i++)
+        if (mine.host_status[i]) {
+            any |= mine.host_status[i];
+            if (status && i < nframes)
+                status[i] = mine.host_status[i];
+        }
+    if (rc != 0)
+        return rc < 0 ? rc : -rc;
+    return any;
 }
 
 int mcraw_pool_decode_batch(mcraw_pool *p, const mcraw_frame *frames, int nframes, size_t *written, int32_t *status)

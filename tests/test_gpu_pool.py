@@ -218,3 +218,128 @@ def test_pool_rejects_an_unknown_post_stage():
         pass  # (the wrapper itself refuses a strip width the ABI does not know)
     finally:
         pool.close()
+
+
+def test_resident_batches_whose_buffers_are_not_where_the_rule_says():
+    """mcraw_pool_decode_batch_device CHECKS where a frame's buffers live: a host pointer (pinned or pageable) is no
+    device memory of the member that decodes the frame -> MCRAW_E_ARGS for that frame, nothing written, the other frames
+    decode; the same through the queued form, where the verdict comes from mcraw_pool_synchronize."""
+    import torch
+    pool = M.Pool([0, 0])
+    lib = M.load()
+    try:
+        items = _batch(8)
+        dev = torch.device("cuda", 0)
+        ins = [torch.from_numpy(it[2]).to(dev) for it in items]
+        outs = [torch.full((it[1].size * 2,), 0xA5, dtype=torch.uint8, device=dev) for it in items]
+        host_in = lib.mcraw_host_alloc(items[2][2].size)            # pinned host memory: GPU-visible, but no HBM
+        C.memmove(host_in, items[2][2].ctypes.data, items[2][2].size)
+        pageable_out = np.zeros(items[5][1].size, np.uint16)         # not known to HIP at all
+        descs = []
+        for i, it in enumerate(items):
+            pin = host_in if i == 2 else ins[i].data_ptr()
+            pout = pageable_out.ctypes.data if i == 5 else outs[i].data_ptr()
+            descs.append((pin, it[2].size, it[1].shape[1], it[1].shape[0], it[0], pout, it[1].size))
+        torch.cuda.synchronize()
+        frames = M.Context.make_frames(descs)
+        written, status = pool.decode_batch_device(frames)
+        want = [M.E_ARGS if i in (2, 5) else 0 for i in range(8)]
+        assert status == want, status
+        assert [w for i, w in enumerate(written) if i in (2, 5)] == [0, 0]
+        for i, it in enumerate(items):
+            a = outs[i].cpu().numpy()
+            if i == 2:
+                assert (a == 0xA5).all()
+            elif i != 5:
+                assert np.array_equal(a.view(np.uint16).reshape(it[1].shape), it[1])
+        assert not pageable_out.any()
+        # queued
+        assert pool.decode_batch_device(frames, want_status=False) is None
+        assert pool.synchronize(8) == want and pool.errors == M.E_ARGS
+        assert pool.synchronize(8) == want and pool.errors == M.E_ARGS  # (asked again: the same batch, the host's verdicts with it)
+        lib.mcraw_host_free(host_in)
+    finally:
+        pool.close()
+
+
+def test_queued_resident_batches_of_two_host_threads_are_reported_to_their_own_thread():
+    """Two host threads queue status-less resident batches on one pool at the same time -- one of them with a frame that
+    fails (a stream cut short) --: mcraw_pool_synchronize gives every thread the statuses of ITS last batch (round 3 kept one
+    index map per pool: the threads got each other's), and a failure in an EARLIER queued batch is not lost: it is in the OR
+    that synchronize returns."""
+    import threading
+    import torch
+    pool = M.Pool([0, 0, 0])
+    dev = torch.device("cuda", 0)
+    items = _batch(12)
+    results, errors = {}, []
+    barrier = threading.Barrier(2)
+
+    def worker(name, nframes, break_at, rounds_bad, rounds_good):
+        try:
+            its = items[:nframes]
+            ins = []
+            for i, it in enumerate(its):
+                buf = it[2]
+                if i == break_at:
+                    buf = buf[: max(8, buf.size // 3)].copy()
+                ins.append(torch.from_numpy(np.ascontiguousarray(buf)).to(dev))
+            outs = [torch.zeros(it[1].size * 2, dtype=torch.uint8, device=dev) for it in its]
+            good_ins = [torch.from_numpy(it[2]).to(dev) for it in its]
+            torch.cuda.synchronize()
+            bad = M.Context.make_frames([(ins[i].data_ptr(), ins[i].numel(), it[1].shape[1], it[1].shape[0], it[0], outs[i].data_ptr(), it[1].size)
+                                         for i, it in enumerate(its)])
+            good = M.Context.make_frames([(good_ins[i].data_ptr(), good_ins[i].numel(), it[1].shape[1], it[1].shape[0], it[0], outs[i].data_ptr(), it[1].size)
+                                          for i, it in enumerate(its)])
+            barrier.wait(timeout=60)
+            for _ in range(rounds_bad):
+                pool.decode_batch_device(bad, want_status=False)
+            for _ in range(rounds_good):
+                pool.decode_batch_device(good, want_status=False)
+            barrier.wait(timeout=60)
+            st = pool.synchronize(nframes)
+            results[name] = (st, pool.errors)
+        except Exception as e:  # pragma: no cover
+            errors.append((name, repr(e)))
+            try:
+                barrier.abort()
+            except Exception:
+                pass
+
+    ta = threading.Thread(target=worker, args=("a", 12, 4, 3, 0))   # its LAST batch holds the broken frame 4
+    tb = threading.Thread(target=worker, args=("b", 7, 2, 1, 2))    # an EARLIER batch held a broken frame, the last one is clean
+    ta.start(); tb.start(); ta.join(120); tb.join(120)
+    pool.close()
+    assert not errors and not ta.is_alive() and not tb.is_alive(), errors
+    sa, ea = results["a"]
+    sb, eb = results["b"]
+    assert len(sa) == 12 and sa[4] != 0 and all(s == 0 for i, s in enumerate(sa) if i != 4), sa
+    assert len(sb) == 7 and all(s == 0 for s in sb), sb
+    assert (ea | eb) != 0  # the earlier failure of thread b (and thread a's) are in the OR of whoever synchronised first
+
+
+def test_context_reports_batches_that_were_queued_without_a_status_request():
+    """mcraw_ctx_last_serial / mcraw_ctx_batch_status / mcraw_ctx_errors: three status-less device batches in a row, the
+    middle one with a broken frame; every batch's own statuses can still be had, and the OR says that something failed."""
+    import torch
+    dev = torch.device("cuda", 0)
+    ctx = M.Context(0)
+    items = _batch(6)
+    outs = [torch.zeros(it[1].size * 2, dtype=torch.uint8, device=dev) for it in items]
+    ins = [torch.from_numpy(it[2]).to(dev) for it in items]
+    cut = torch.from_numpy(items[3][2][: items[3][2].size // 2].copy()).to(dev)
+    torch.cuda.synchronize()
+
+    def frames(broken):
+        return M.Context.make_frames([((cut if broken and i == 3 else ins[i]).data_ptr(), (cut if broken and i == 3 else ins[i]).numel(),
+                                       it[1].shape[1], it[1].shape[0], it[0], outs[i].data_ptr(), it[1].size) for i, it in enumerate(items)])
+    serials = []
+    for broken in (False, True, False):
+        ctx.decode_batch(frames(broken), want_status=False)
+        serials.append(ctx.last_serial())
+    assert serials[0] < serials[1] < serials[2]
+    st = [ctx.batch_status(s, 6) for s in serials]
+    assert st[0] == [0] * 6 and st[2] == [0] * 6 and st[1][3] != 0 and all(v == 0 for i, v in enumerate(st[1]) if i != 3), st
+    assert ctx.errors() == st[1][3] and ctx.errors() == 0
+    assert ctx.batch_status(serials[2] + 1000, 6) is None
+    ctx.close()
