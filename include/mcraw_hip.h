@@ -199,10 +199,12 @@ int mcraw_ctx_profile(mcraw_ctx *ctx, int enable);
 int mcraw_ctx_profile_every(mcraw_ctx *ctx, int n);
 int mcraw_ctx_kernel_ms(mcraw_ctx *ctx, int id, double *ms, int *launches, int reset);
 /* How the tile kernel's workgroups are dealt to the GPU's eight XCDs for large resident batches: the library measures two
- * mappings on the first launches on a new set of buffers (which one is faster depends on where those buffers lie in
- * physical memory) and keeps the faster.  Returns the choice made for the current buffers: the length of the runs in
- * workgroups (0: the grid in eight parts), -1 while it is still measuring or nothing was measured (small or host-memory
- * batches use runs of 128).  Environment MCRAW_XCD_CHUNK pins the mapping (then always -1 here). */
+ * mappings on the first launches of a geometry (frames per batch, groups per frame) -- which one is faster depends on where
+ * the caller's buffers lie in physical memory --, keeps the faster, and times one launch in 64 afterwards (the chosen mapping
+ * and the other one in turn) so that the choice follows the caller's buffers; a caller that never reuses a buffer is not kept
+ * measuring.  Returns the choice for the geometry of the last such batch: the length of the runs in workgroups (0: the grid
+ * in eight parts), -1 while the first measurements are under way or nothing was measured (small or host-memory batches use
+ * runs of 128).  Environment MCRAW_XCD_CHUNK pins the mapping (then always -1 here). */
 int mcraw_ctx_xcd_runs(mcraw_ctx *ctx);
 
 /* Optional stage fused behind the decode, for consumers that take the mosaic further on the

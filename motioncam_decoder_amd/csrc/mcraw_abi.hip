@@ -136,23 +136,26 @@ struct mcraw_ctx {
     KStat kstat[MCRAW_K_COUNT];
     std::vector<hipEvent_t> event_pool;
     // How k7_tiles' workgroups are dealt to the XCDs (Work7::xcd_chunk), chosen by measurement for large resident batches:
-    // which of the candidates is faster depends on where the caller's buffers lie in physical memory (see submit()), so
-    // the first launches on a new set of buffers try each candidate twice between events and the faster one stays.
+    // which of the candidates is faster depends on where the caller's buffers lie in physical memory (see submit()).  The
+    // choice is made PER GEOMETRY (frames, groups), not per buffer: the first launches of a geometry try each candidate twice
+    // between events and the faster one stays; afterwards one launch in 64 is timed -- the chosen candidate and the other one
+    // in turn --, and the choice moves when the other one has become the faster (a caller whose buffers change is never
+    // left measuring, and one whose buffers moved to a place where the other mapping wins gets there).
     struct Tune {
         static constexpr int NC = 2;
-        const void *key_out = nullptr; // what the choice was made for: first output pointer, frames, groups
-        int key_n = 0;
+        int key_n = 0;       // what the choice was made for: frames, groups
         uint32_t key_R = 0;
         int issued[NC] = {0, 0}, done[NC] = {0, 0};
-        float best[NC] = {0.f, 0.f};
+        float best[NC] = {0.f, 0.f}; // first samples: the minimum; afterwards a moving average
         int decided = -1;
+        unsigned long long launches = 0; // tunable launches since the decision
         struct Pending {
             hipEvent_t a, b;
             int cand;
         };
         std::vector<Pending> pending;
         unsigned long long used = 0; // (least recently used entry is replaced)
-    } tunes[4]; // a few buffer sets at a time: a caller that alternates between two sets of frame buffers keeps both choices
+    } tunes[4]; // a few geometries at a time
     unsigned long long tune_clock = 0;
     int tune_last = -1; // entry of the last tunable batch (mcraw_ctx_xcd_runs)
     // last device-memory batch, for mcraw_ctx_synchronize
@@ -254,31 +257,32 @@ struct Layout { // byte offsets inside the slot arena / upload image
 
 constexpr uint32_t TUNE_CHUNKS[mcraw_ctx::Tune::NC] = {128u, 0u};
 
-// Which candidate the next k7_tiles launch of a large resident batch runs with: -1 = the choice is made
-// (the entry's `decided`), else the candidate to time.  Never blocks: finished event pairs are collected as they come.
-int tune_pick(mcraw_ctx *c, const void *out0, int n7, uint32_t R)
+// Which candidate the next k7_tiles launch of a large resident batch runs with: -1 = the entry's `decided` (not timed),
+// else the candidate to run AND time.  Never blocks: finished event pairs are collected as they come.
+int tune_pick(mcraw_ctx *c, int n7, uint32_t R)
 {
     constexpr int NC = mcraw_ctx::Tune::NC, SAMPLES = 2, NT = static_cast<int>(sizeof(c->tunes) / sizeof(c->tunes[0]));
+    constexpr unsigned long long RECHECK = 64; // one launch in this many is timed once the choice is made
     int e = -1, lru = 0;
     for (int i = 0; i < NT; i++) {
-        if (c->tunes[i].key_out == out0 && c->tunes[i].key_n == n7 && c->tunes[i].key_R == R)
+        if (c->tunes[i].key_n == n7 && c->tunes[i].key_R == R)
             e = i;
         if (c->tunes[i].used < c->tunes[lru].used)
             lru = i;
     }
-    if (e < 0) { // another set of buffers: measure again, in the entry that was not used for the longest time
+    if (e < 0) { // another geometry: measure, in the entry that was not used for the longest time
         e = lru;
         mcraw_ctx::Tune &t = c->tunes[e];
-        for (auto &p : t.pending) { // (their results belong to the old buffers)
+        for (auto &p : t.pending) { // (their results belong to the old geometry)
             (void)hipEventSynchronize(p.b);
             c->event_pool.push_back(p.a);
             c->event_pool.push_back(p.b);
         }
         t.pending.clear();
-        t.key_out = out0;
         t.key_n = n7;
         t.key_R = R;
         t.decided = -1;
+        t.launches = 0;
         for (int k = 0; k < NC; k++)
             t.issued[k] = t.done[k] = 0, t.best[k] = 0.f;
     }
@@ -294,15 +298,25 @@ int tune_pick(mcraw_ctx *c, const void *out0, int n7, uint32_t R)
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, t.pending[i].a, t.pending[i].b) == hipSuccess && ms > 0.f) {
             const int k = t.pending[i].cand;
-            t.best[k] = t.done[k] ? std::min(t.best[k], ms) : ms;
+            if (t.decided < 0)
+                t.best[k] = t.done[k] ? std::min(t.best[k], ms) : ms;
+            else
+                t.best[k] = 0.75f * t.best[k] + 0.25f * ms;
             t.done[k]++;
         }
         c->event_pool.push_back(t.pending[i].a);
         c->event_pool.push_back(t.pending[i].b);
         t.pending.erase(t.pending.begin() + static_cast<long>(i));
     }
-    if (t.decided >= 0)
-        return -1;
+    if (t.decided >= 0) {
+        const int other = 1 - t.decided;
+        if (t.best[other] < 0.99f * t.best[t.decided]) // (the re-checks say the other mapping has become the faster one)
+            t.decided = other;
+        t.launches++;
+        if (t.launches % RECHECK != 0 || !t.pending.empty())
+            return -1;
+        return (t.launches / RECHECK) % 2 ? 1 - t.decided : t.decided;
+    }
     bool all = true;
     for (int k = 0; k < NC; k++)
         all = all && t.done[k] >= SAMPLES;
@@ -576,9 +590,9 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         // Neither is the faster one everywhere: the same launch takes 0.96 - 1.04 ms with the one and 0.97 - 1.01 ms with
         // the other, from box to box and -- for the eight parts -- from one process to the next on one box: the streams
         // meet on memory channels or not, as the physical pages of the caller's buffers fall (runs of 8 MiB are the slow
-        // case every time).  So large resident batches measure: the first launches on a new set of buffers take turns
-        // between events, then the faster candidate stays (tune_pick).  MCRAW_XCD_CHUNK pins the choice (0: eight parts,
-        // 1: blockIdx order, n: runs of n).
+        // case every time).  So large resident batches measure: the first launches of a geometry take turns between
+        // events, the faster candidate stays, and one launch in 64 re-checks it (tune_pick).  MCRAW_XCD_CHUNK pins the
+        // choice (0: eight parts, 1: blockIdx order, n: runs of n).
         static const int xcd_env = []() {
             const char *e = std::getenv("MCRAW_XCD_CHUNK");
             return e ? std::atoi(e) : -1;
@@ -587,7 +601,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         int tune_cand = -1;
         uint32_t xcd_chunk = xcd_env >= 0 ? static_cast<uint32_t>(xcd_env) : 128u;
         if (tunable) {
-            tune_cand = tune_pick(c, B.p7[0].out, n7, static_cast<uint32_t>(Rmax));
+            tune_cand = tune_pick(c, n7, static_cast<uint32_t>(Rmax));
             xcd_chunk = TUNE_CHUNKS[tune_cand >= 0 ? tune_cand : std::max(c->tunes[c->tune_last].decided, 0)];
         }
         W.xcd_chunk = xcd_chunk;

@@ -151,3 +151,32 @@ def test_async_ticket_survives_context_synchronize(gpu_ctx):
     written, status = gpu_ctx.wait(t)
     assert status[0] == 0 and written[0] == 1920 * 1080 and np.array_equal(outs[0], img)
     assert status[1] != 0 and written[1] == 0
+
+
+def test_xcd_mapping_is_decided_for_a_caller_that_never_reuses_an_output_buffer():
+    """A streaming caller rotates its output buffers: 8 sets, 64 resident batches of 32 frames.  Round 3 keyed the choice of
+    k7_tiles' XCD mapping on the first output pointer (4 entries): such a caller measured for ever.  The choice is per geometry
+    now: decided after the first few launches, re-checked by one timed launch in 64; every batch decodes right."""
+    import torch
+    dev = torch.device("cuda:0")
+    ctx = M.Context(0)
+    w, h, n = 1920, 1080, 32
+    imgs = [L.synth_image(w, h, 12, 1, 12.0, 8100 + i) for i in range(4)]
+    bufs = [L.encode7(im) for im in imgs]
+    tin = [torch.from_numpy(bufs[i % 4]).to(dev) for i in range(n)]
+    sets = [torch.zeros(n * w * h * 2, dtype=torch.uint8, device=dev) for _ in range(8)]
+    frames = [M.Context.make_frames([(tin[i].data_ptr(), tin[i].numel(), w, h, 7, t.data_ptr() + i * w * h * 2, w * h) for i in range(n)])
+              for t in sets]
+    seen = []
+    for b in range(64):
+        ctx.decode_batch(frames[b % 8], want_status=False)
+        if b in (3, 15, 63):
+            ctx.synchronize()
+            seen.append(ctx.xcd_runs())
+    st = ctx.synchronize(n)
+    assert st == [0] * n
+    assert seen[-1] in (0, 128) and seen[1] in (0, 128), seen  # decided early, and still decided at the end
+    for t in sets:
+        for i in (0, n - 1):
+            assert np.array_equal(t[i * w * h * 2:(i + 1) * w * h * 2].cpu().numpy().view(np.uint16).reshape(h, w), imgs[i % 4])
+    ctx.close()
