@@ -180,12 +180,24 @@ __device__ __forceinline__ void post_pack12(const uint32_t p[4], uint32_t o[3])
     for (int i = 0; i < 4; i++) {
         const uint32_t c = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(mcraw_u16x2, p[i]),
                                                                                   __builtin_bit_cast(mcraw_u16x2, 0x0FFF0FFFu)));
-        // a << 12 | b in two instructions: the low half of c times 4096 plus its high half (v_mad_u32_u16 reads halves)
-        uint32_t ti;
-        asm("v_mad_u32_u16 %0, %1, %2, %3" : "=v"(ti) : "v"(c), "s"(4096u), "v"(c >> 16));
-        t[i] = ti;
+        // a << 12 | b in ONE instruction: the dot product of (a, b) with (4096, 1) (v_dot2_u32_u16; round 3 shifted the high
+        // half down and used v_mad_u32_u16: two)
+        t[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(mcraw_u16x2, c), __builtin_bit_cast(mcraw_u16x2, 0x00011000u), 0u, false);
     }
     // memory order: t0.b2 t0.b1 t0.b0 | t1.b2 t1.b1 t1.b0 | ...
+    o[0] = __builtin_amdgcn_perm(t[1], t[0], 0x06000102u);
+    o[1] = __builtin_amdgcn_perm(t[2], t[1], 0x05060001u);
+    o[2] = __builtin_amdgcn_perm(t[3], t[2], 0x04050600u);
+}
+
+// The same without the clamp: for samples that are known to be below 4096 (k7_tiles proves it per decode item from the blocks'
+// references and storage widths, with the black levels already taken off the references).
+__device__ __forceinline__ void post_pack12_lean(const uint32_t p[4], uint32_t o[3])
+{
+    uint32_t t[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        t[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(mcraw_u16x2, p[i]), __builtin_bit_cast(mcraw_u16x2, 0x00011000u), 0u, false);
     o[0] = __builtin_amdgcn_perm(t[1], t[0], 0x06000102u);
     o[1] = __builtin_amdgcn_perm(t[2], t[1], 0x05060001u);
     o[2] = __builtin_amdgcn_perm(t[3], t[2], 0x04050600u);
@@ -271,11 +283,13 @@ __device__ __forceinline__ void post_store_bytes(uint8_t *dst, const uint32_t *o
 // form) / 16-byte friendly (16-bit form).
 // PB: bits per output sample, a compile-time property of the kernel instance (16, 12, 10 or 14) so that every
 // instance carries one packing only.
+// `lean` (12-bit strips only, wave-uniform): the samples need neither the black levels (they are off the references already)
+// nor the clamp.
 template <bool NT, int PB>
 __device__ __forceinline__ void post_store8(uint16_t *out, const Post &post, uint32_t width, uint32_t y, uint32_t x,
-                                            uint32_t p[4], uint32_t n, bool quick)
+                                            uint32_t p[4], uint32_t n, bool quick, bool lean = false)
 {
-    if (post.mode & POST_BLACK)
+    if (!(PB == 12 && lean) && (post.mode & POST_BLACK))
         post_black(p, post, y);
     if (PB == 10 || PB == 14) { // 10 / 14 bytes per 8 samples; rows start on even bytes when width % 8 == 0
         constexpr uint32_t B = PB == 10 ? 10u : 14u;
@@ -302,7 +316,10 @@ __device__ __forceinline__ void post_store8(uint16_t *out, const Post &post, uin
     }
     if (PB == 12) {
         uint32_t o[3];
-        post_pack12(p, o);
+        if (lean)
+            post_pack12_lean(p, o);
+        else
+            post_pack12(p, o);
         uint8_t *dst = reinterpret_cast<uint8_t *>(out) + static_cast<size_t>(y) * post_row_bytes(width, post.mode) + (x >> 3) * 12u;
         if (quick && n == 8u) {
             typedef uint32_t u32x3 __attribute__((ext_vector_type(3), aligned(4)));

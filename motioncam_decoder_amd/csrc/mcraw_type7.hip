@@ -986,6 +986,7 @@ struct ItemS {
     uint32_t len;
     uint16_t *out;
     size_t meta;         // index of the group's first entry in W.bits / W.refs
+    uint32_t lean;       // (12-bit strip rows) no sample of the item can reach 4096, black levels are off its references
 };
 
 __device__ __forceinline__ ItemS item_scalars(const Work7 &W, uint32_t item, uint32_t first_frame, uint32_t class_groups)
@@ -1044,6 +1045,7 @@ __device__ __forceinline__ ItemS item_scalars(const Work7 &W, uint32_t item, uin
     I.len = F->len;
     I.out = F->out;
     I.meta = static_cast<size_t>(f) * W.Rmax * 64u + static_cast<size_t>(g) * ITEM_BLOCKS;
+    I.lean = 0u;
     return I;
 }
 
@@ -1056,7 +1058,7 @@ __device__ __forceinline__ void store_px8(const ItemS &I, const Post &post, uint
     if (y >= static_cast<uint32_t>(I.rows) || x >= width)
         return;
     if (POST) { // black levels / 12-bit strip rows (mcraw_dev.h)
-        post_store8<NT, POST>(I.out, post, width, y, x, p, min(8u, width - x), I.fast != 0u);
+        post_store8<NT, POST>(I.out, post, width, y, x, p, min(8u, width - x), I.fast != 0u, POST == 12 && I.lean != 0u);
         return;
     }
     uint16_t *dst = I.out + static_cast<size_t>(y) * static_cast<size_t>(width) + x;
@@ -1190,6 +1192,22 @@ __global__ __launch_bounds__(256) void k7_tiles(const Work7 W, uint32_t total, u
     if (I.valid && lane < ITEM_BLOCKS && I.g * ITEM_BLOCKS + lane < I.nblk) {
         b = W.bits[I.meta + lane];
         r = W.refs[I.meta + lane];
+    }
+    if (POST == 12) {
+        // 12-bit strips (round 4): a block is one colour plane of its tile (block k of a tile: row parity k >> 1, column parity
+        // k & 1, RawData.cpp:581-593), so its black level is ONE value and can come off its reference -- if the reference is not
+        // below it --, and no sample of the block can reach 4096 when reference - black + (2^storage width - 1) does not: then
+        // neither the saturating subtraction nor the clamp of the strip stage can change a sample, and the item's stores skip
+        // both (16 of the stage's ~ 54 vector instructions per lane and call).  One ballot per item decides.
+        const uint32_t bl2 = (W.post.mode & POST_BLACK) ? ((lane & 2u) ? W.post.black23 : W.post.black01) : 0u;
+        const uint32_t bl = (lane & 1u) ? bl2 >> 16 : bl2 & 0xffffu;
+        const uint32_t sw = b <= 6u ? b : b <= 8u ? 8u : 10u; // storage width of the block's residuals (RawData.cpp:424-458)
+        const bool real = I.valid && lane < ITEM_BLOCKS && I.g * ITEM_BLOCKS + lane < I.nblk;
+        // (r + 2^sw - 1 <= 65535: the reference add of the decode does not wrap either, RawData.cpp:581-593)
+        const bool fits = !real || (b <= 10u && r >= bl && r - bl + ((1u << sw) - 1u) <= 4095u && r + ((1u << sw) - 1u) <= 65535u);
+        I.lean = __ballot(!fits) == 0ull ? 1u : 0u;
+        if (I.lean)
+            r -= bl;
     }
 
     uint32_t tot;

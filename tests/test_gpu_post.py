@@ -144,22 +144,30 @@ def test_at_most_one_strip_width(gpu_ctx):
     gpu_ctx.set_post()
 
 
-@pytest.mark.parametrize("bits", [12, None])
-def test_post_stage_large_batch_under_load(gpu_ctx, bits):
-    """120 UHD frames per batch, every frame checked (on the GPU, against an upload of the oracle's rows): what goes wrong only
-    when the memory pipeline is backed up -- a store whose data registers are overwritten before it has read them wrote wrong
-    12-bit strips for the bench's 240-frame batch while every small-frame test passed."""
+@pytest.mark.parametrize("typ,bits,bright", [(7, 12, False), (7, None, False), (7, 10, False), (7, 14, False), (7, 12, True),
+                                             (6, 12, False), (6, 10, False), (6, None, False)])
+def test_post_stage_large_batch_under_load(gpu_ctx, typ, bits, bright):
+    """120 UHD frames per batch (32 for the legacy kernel), every frame checked (on the GPU, against an upload of the oracle's
+    rows), every store form of both kernels: what goes wrong only when the memory pipeline is backed up -- a store whose data
+    registers are overwritten before it has read them wrote wrong 12-bit strips for the bench's 240-frame batch while every
+    small-frame test passed.  `bright`: frames whose samples reach 4095 and whose references lie below the black levels in
+    places, so that the items of one batch take both paths of the 12-bit stage (the lean one: no clamp, black levels off the
+    references; and the general one)."""
     dev = torch.device("cuda:0")
-    w, h, n, distinct = 3840, 2160, 120, 4
-    black = [64, 60, 68, 72]
-    imgs = [L.synth_image(w, h, 12, 1, 12.0, 900 + i) for i in range(distinct)]
-    bufs = [L.encode7(im) for im in imgs]
-    want = [torch.from_numpy(np.ascontiguousarray(L.oracle_post(im, black, bits == 12))).to(dev) for im in imgs]
-    rb = L.post_row_bytes(w, bits == 12)
+    w, h, n, distinct = 3840, 2160, (120 if typ == 7 else 32), 4
+    black = [64, 60, 68, 72] if not bright else [300, 2, 1200, 40]
+    imgs = [L.synth_image(w, h, 12, 1, 12.0, 900 + i).copy() for i in range(distinct)]
+    if bright:
+        for k, im in enumerate(imgs):
+            im[200 * k: 200 * k + 300, :] = np.minimum(4095, im[200 * k: 200 * k + 300, :].astype(np.uint32) * 3).astype(np.uint16)  # clipped highlights
+            im[1000:1100, 64 * k: 64 * k + 1024] //= 16                                                                         # shadows below the black levels
+    bufs = [(L.encode7 if typ == 7 else L.encode6)(im) for im in imgs]
+    want = [torch.from_numpy(np.ascontiguousarray(L.oracle_post(im, black, bits=bits))).to(dev) for im in imgs]
+    rb = L.post_row_bytes(w, bits=bits)
     cap16 = (h * rb + 1) // 2
     t_in = [torch.from_numpy(b).to(dev) for b in bufs]
     t_out = torch.zeros(n * cap16 * 2, dtype=torch.uint8, device=dev)
-    descs = [(t_in[i % distinct].data_ptr(), t_in[i % distinct].numel(), w, h, 7, t_out.data_ptr() + i * cap16 * 2, cap16) for i in range(n)]
+    descs = [(t_in[i % distinct].data_ptr(), t_in[i % distinct].numel(), w, h, typ, t_out.data_ptr() + i * cap16 * 2, cap16) for i in range(n)]
     frames = M.Context.make_frames(descs)
     gpu_ctx.set_post(black=black, bits=bits)
     try:
@@ -173,7 +181,7 @@ def test_post_stage_large_batch_under_load(gpu_ctx, bits):
                 got = t_out[i * cap16 * 2: i * cap16 * 2 + h * rb].view(h, rb)
                 if not torch.equal(got, want[i % distinct]):
                     bad = (got != want[i % distinct]).nonzero()
-                    raise AssertionError("bits %s round %d frame %d: %d bytes differ, first at (row, byte) %s" %
-                                         (bits, rnd, i, bad.shape[0], bad[:4].tolist()))
+                    raise AssertionError("type %d bits %s round %d frame %d: %d bytes differ, first at (row, byte) %s" %
+                                         (typ, bits, rnd, i, bad.shape[0], bad[:4].tolist()))
     finally:
         gpu_ctx.set_post()
