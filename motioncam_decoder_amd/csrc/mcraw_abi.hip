@@ -1055,13 +1055,17 @@ int host_submit(mcraw_ticket *t)
         }
         int rc = host_submit_part(t, first, count);
         // out of device memory: halve the sub-batch; a single frame that cannot get its workspace fails alone
+        // (the failed attempt may have queued uploads from the caller's buffers into a slot that no part of the ticket owns:
+        // they are waited for here, so that no copy can still be reading a buffer when the ticket is reported done)
         while (rc == -static_cast<int>(hipErrorOutOfMemory) && count > 1) {
             (void)hipGetLastError();
+            (void)hipStreamSynchronize(c->h2d);
             count = (count + 1) / 2;
             rc = host_submit_part(t, first, count);
         }
         if (rc == -static_cast<int>(hipErrorOutOfMemory)) {
             (void)hipGetLastError();
+            (void)hipStreamSynchronize(c->h2d);
             t->status[first] |= MCRAW_E_DEVICE;
             t->skipped.push_back(first);
             rc = 0;

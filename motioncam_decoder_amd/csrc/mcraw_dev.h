@@ -255,6 +255,9 @@ __device__ __forceinline__ MCRAW_GLOBAL V *gptr(T *p)
 #endif
 typedef uint32_t mcraw_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t mcraw_u32x3 __attribute__((ext_vector_type(3)));
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "store_stream16/12: the `sc1 nt` mnemonics and the two wait states behind a store of more than 8 bytes are gfx940+ facts"
+#endif
 __device__ __forceinline__ void store_stream16(void *dst, mcraw_u32x4 v)
 {
     // (the string ends with s_nop 1: nothing inside an asm statement is padded, and the compiler's next instruction may

@@ -17,13 +17,19 @@ Writer::Writer(const std::string &path, const nlohmann::json &cameraMetadata, co
 {
     if (!mFile)
         throw IOException("Failed to open " + path);
-    FileMagic magic{};
-    std::memcpy(magic.magic, kMagic, sizeof(kMagic));
-    magic.version = kVersion;
-    put(&magic, sizeof(magic));
-    const std::string text = cameraMetadata.dump();
-    putChunk(static_cast<uint32_t>(Kind::JSON), static_cast<uint32_t>(text.size()));
-    put(text.data(), text.size());
+    try {
+        FileMagic magic{};
+        std::memcpy(magic.magic, kMagic, sizeof(kMagic));
+        magic.version = kVersion;
+        put(&magic, sizeof(magic));
+        const std::string text = cameraMetadata.dump();
+        putChunk(static_cast<uint32_t>(Kind::JSON), static_cast<uint32_t>(text.size()));
+        put(text.data(), text.size());
+    } catch (...) { // (no destructor runs for an object whose constructor throws)
+        std::fclose(mFile);
+        mFile = nullptr;
+        throw;
+    }
 }
 
 Writer::~Writer()
@@ -38,8 +44,10 @@ Writer::~Writer()
 
 void Writer::put(const void *data, size_t size)
 {
-    if (size && std::fwrite(data, 1, size, mFile) != size)
+    if (size && std::fwrite(data, 1, size, mFile) != size) {
+        mFinished = true; // a file with a hole gets no index: it must not read as a valid container
         throw IOException("Failed to write data");
+    }
     mPos += static_cast<int64_t>(size);
 }
 
@@ -57,12 +65,13 @@ void Writer::addFrame(int64_t timestamp, const uint8_t *payload, size_t size, co
         throw IOException("Writer is finished");
     if (size > std::numeric_limits<uint32_t>::max())
         throw IOException("Frame too large");
-    mFrames.push_back({mPos, timestamp});
+    const int64_t at = mPos;
     putChunk(static_cast<uint32_t>(Kind::FRAME), static_cast<uint32_t>(size));
     put(payload, size);
     const std::string text = frameMetadata.dump();
     putChunk(static_cast<uint32_t>(Kind::JSON), static_cast<uint32_t>(text.size()));
     put(text.data(), text.size());
+    mFrames.push_back({at, timestamp}); // (the index only lists frames that are in the file whole)
 }
 
 void Writer::putAudio(int64_t timestampNs, const int16_t *samples, size_t count)
@@ -122,13 +131,17 @@ void Writer::finish()
         l.time = r.time;
         put(&l, sizeof(l));
     }
+    if (rows.size() > static_cast<size_t>(std::numeric_limits<int32_t>::max()))
+        throw IOException("Too many frames");
     FrameTable table{};
     table.magic = static_cast<int32_t>(kFrameTableMagic);
     table.rows = static_cast<int32_t>(rows.size());
     table.rowsPosition = rowsPosition;
     putChunk(static_cast<uint32_t>(Kind::FRAME_TABLE), sizeof(table));
     put(&table, sizeof(table));
-    if (std::fflush(mFile) != 0)
+    FILE *f = mFile;
+    mFile = nullptr;
+    if (std::fclose(f) != 0) // (what the C library still held goes to the file here: a full disk shows now)
         throw IOException("Failed to write data");
 }
 

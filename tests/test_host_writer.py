@@ -73,7 +73,9 @@ def test_written_container_reads_like_its_source(tools, variant, tmp_path):
     out2 = str(tmp_path / "out2.mcraw")
     subprocess.run([EXPORT, out, "--remux", out2] + variant, check=True, capture_output=True, timeout=120)
     assert open(out2, "rb").read() == open(out, "rb").read()
-    if os.path.exists(REFEX):
+    if not os.path.exists(REFEX): # (the reference's own example, built from /root/reference by `make -C oracle dropin`: absent on the GPU box)
+        pytest.skip("oracle/_ref/example_ref is not built: the written file was only read back by this repository's reader")
+    if True:
         so, sf = _reference_outputs(src, str(tmp_path / "ref_src"))
         oo, of = _reference_outputs(out, str(tmp_path / "ref_out"))
         assert so == oo and sorted(sf) == sorted(of) and len(sf) == 5  # four DNGs + audio.wav
@@ -92,13 +94,20 @@ def test_trimmed_and_audio_less_containers(tools, tmp_path):
     subprocess.run([EXPORT, src, "--remux", mute, "--no-audio-index"], check=True, capture_output=True, timeout=120)
     got = _probe(probe, mute)
     assert "frames 1000 2000 3000 4000" in got and "audio " not in got and "loader 0" in got
-    if os.path.exists(REFEX):
-        so, sf = _reference_outputs(src, str(tmp_path / "ref_src"), n=2)
-        oo, of = _reference_outputs(out, str(tmp_path / "ref_out"), n=2)
-        for name in sf:
-            assert sf[name] == of[name], name
-        _, mf = _reference_outputs(mute, str(tmp_path / "ref_mute"))
-        assert [n for n in mf if n.endswith(".dng")] == [n for n in sf if n.endswith(".dng")] or len(mf) >= 4
+    if not os.path.exists(REFEX):
+        pytest.skip("oracle/_ref/example_ref is not built: the written files were only read back by this repository's reader")
+    so, sf = _reference_outputs(src, str(tmp_path / "ref_src"), n=2)
+    oo, of = _reference_outputs(out, str(tmp_path / "ref_out"), n=2)
+    assert sorted(sf) == sorted(of)
+    for name in sf:
+        assert sf[name] == of[name], name
+    # the file without an audio index: the reference writes the same four DNGs as from the source clip, byte for byte
+    _, full = _reference_outputs(src, str(tmp_path / "ref_full"))
+    _, mf = _reference_outputs(mute, str(tmp_path / "ref_mute"))
+    dngs = sorted(n for n in full if n.endswith(".dng"))
+    assert len(dngs) == 4 and sorted(n for n in mf if n.endswith(".dng")) == dngs
+    for name in dngs:
+        assert mf[name] == full[name], name
 
 
 def test_writer_refuses_use_after_finish_and_oversized_chunks(tools, tmp_path):
