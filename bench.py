@@ -511,7 +511,7 @@ def post_stage(torch, ctx, M, L, wl, steps):
         for t in wl.t_outs[:1]:
             t.zero_()
         ctx.profile(only=("k7_tiles",))
-        for _ in range(2):
+        for _ in range(8):  # (the XCD mapping is chosen per row format: measured on the first launches with this one)
             ctx.decode_batch(wl.descs, mem=M.MEM_DEVICE, stream=stream, want_status=False)
         torch.cuda.synchronize()
         ctx.kernel_ms("k7_tiles", reset=True)
@@ -533,7 +533,10 @@ def post_stage(torch, ctx, M, L, wl, steps):
         return {"stage": "black levels %s subtracted, rows as 12-bit strips" % black, "ms_per_step": round(1e3 * el / steps, 4),
                 "mpix_s": round(wl.pixels * steps / el / 1e6, 1), "tiles_ms_per_launch": round(tile_ms / max(tile_n, 1), 4),
                 "algorithmic_bytes_per_launch": wl.in_bytes + out_b, "achieved_gbs": round(ach, 1),
-                "frac": round(ach / HBM_PEAK_GBS, 4), "bit_exact": bool(ok)}
+                "frac": round(ach / HBM_PEAK_GBS, 4), "xcd_runs": ctx.xcd_runs(), "bit_exact": bool(ok),
+                "bound": "the memory pipeline's instruction rate: two stores per lane and call like the plain kernel, 12 instead of 16 bytes each "
+                         "(768 B per wave instruction); the stage's arithmetic is 14 vector instructions per lane and call for items "
+                         "that take the lean path (DESIGN 3)"}
     finally:
         ctx.set_post()
         ctx.profile(True)

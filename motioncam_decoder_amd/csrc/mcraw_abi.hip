@@ -143,8 +143,8 @@ struct mcraw_ctx {
     // left measuring, and one whose buffers moved to a place where the other mapping wins gets there).
     struct Tune {
         static constexpr int NC = 2;
-        int key_n = 0;       // what the choice was made for: frames, groups
-        uint32_t key_R = 0;
+        int key_n = 0;       // what the choice was made for: frames, groups, row format (another kernel instance, other rows)
+        uint32_t key_R = 0, key_mode = 0;
         int issued[NC] = {0, 0}, done[NC] = {0, 0};
         float best[NC] = {0.f, 0.f}; // first samples: the minimum; afterwards a moving average
         int decided = -1;
@@ -259,13 +259,13 @@ constexpr uint32_t TUNE_CHUNKS[mcraw_ctx::Tune::NC] = {128u, 0u};
 
 // Which candidate the next k7_tiles launch of a large resident batch runs with: -1 = the entry's `decided` (not timed),
 // else the candidate to run AND time.  Never blocks: finished event pairs are collected as they come.
-int tune_pick(mcraw_ctx *c, int n7, uint32_t R)
+int tune_pick(mcraw_ctx *c, int n7, uint32_t R, uint32_t mode)
 {
     constexpr int NC = mcraw_ctx::Tune::NC, SAMPLES = 2, NT = static_cast<int>(sizeof(c->tunes) / sizeof(c->tunes[0]));
     constexpr unsigned long long RECHECK = 64; // one launch in this many is timed once the choice is made
     int e = -1, lru = 0;
     for (int i = 0; i < NT; i++) {
-        if (c->tunes[i].key_n == n7 && c->tunes[i].key_R == R)
+        if (c->tunes[i].key_n == n7 && c->tunes[i].key_R == R && c->tunes[i].key_mode == mode)
             e = i;
         if (c->tunes[i].used < c->tunes[lru].used)
             lru = i;
@@ -281,6 +281,7 @@ int tune_pick(mcraw_ctx *c, int n7, uint32_t R)
         t.pending.clear();
         t.key_n = n7;
         t.key_R = R;
+        t.key_mode = mode;
         t.decided = -1;
         t.launches = 0;
         for (int k = 0; k < NC; k++)
@@ -452,18 +453,20 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     size_t off = 0;
     // status words: two per type-7 frame (one per side stream, each written once by its workgroup), one per legacy
     // frame, one spare; then the coded height of every type-7 frame
-    // Long side streams of small batches are resolved by two workgroups each (k7_side "parts") when the chip has room for
-    // them all at once (two workgroups of k7_side per CU).  What a part saves is the decode and the table builds of the other
-    // part's pieces; what it adds is a count over its own pieces and a hand-off: measured (tools/side_split.py), 16 x 12 MP
-    // frames 160 -> 89 us, 120 x 8K 270 -> 208 us, UHD frames (streams of two to eight pieces) lose.  More parts per
-    // stream (the kernel takes up to MAX_SPLIT7) were slower on every batch tried: MCRAW_SIDE_SPLIT=b,r pins the numbers
-    // (tests run the type-7 suites with 2,2 and 4,4).
+    // Long side streams of small batches are resolved by several workgroups each (k7_side "parts") when the chip has room for
+    // them all at once (two workgroups of k7_side per CU).  What a part saves is the other parts' pieces; what it adds is a
+    // count over its own pieces and a hand-off: measured (tools/side_split.py, tools/side_warm2.sh), 16 x 12 MP frames
+    // 160 -> 85 us with four parts per stream (14-bit noise 205 -> 162), 120 x 8K 270 -> 208 us with two (four would be 960
+    // workgroups), UHD frames (streams of two to eight pieces) lose.  MCRAW_SIDE_SPLIT=b,r pins the numbers (tests run the
+    // type-7 suites with 2,2 and 4,4).
     int nsplit[2] = {1, 1};
     {
         uint32_t rmax = 0;
         for (const Plan7 &p : B.p7)
             rmax = std::max(rmax, p.ngroups);
-        if (rmax >= 2900u && n7 * 4 <= 512)
+        if (rmax >= 2900u && n7 * 8 <= 512)
+            nsplit[0] = nsplit[1] = 4;
+        else if (rmax >= 2900u && n7 * 4 <= 512)
             nsplit[0] = nsplit[1] = 2;
         if (const char *e = std::getenv("MCRAW_SIDE_SPLIT")) {
             int b = 0, r = 0;
@@ -601,7 +604,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         int tune_cand = -1;
         uint32_t xcd_chunk = xcd_env >= 0 ? static_cast<uint32_t>(xcd_env) : 128u;
         if (tunable) {
-            tune_cand = tune_pick(c, n7, static_cast<uint32_t>(Rmax));
+            tune_cand = tune_pick(c, n7, static_cast<uint32_t>(Rmax), c->post.mode);
             xcd_chunk = TUNE_CHUNKS[tune_cand >= 0 ? tune_cand : std::max(c->tunes[c->tune_last].decided, 0)];
         }
         W.xcd_chunk = xcd_chunk;

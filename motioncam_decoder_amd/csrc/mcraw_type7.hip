@@ -386,9 +386,14 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     uint32_t decode_from = 0u;             // units of pieces in front of this one are walked, not decoded
     constexpr uint32_t NOENTRY = 0xFFFFFFFEu;
 #ifndef MCRAW_SPEC_WARM
-#define MCRAW_SPEC_WARM 1024
+#define MCRAW_SPEC_WARM 8192
 #endif
-    constexpr uint32_t SPEC_WARM = MCRAW_SPEC_WARM; // candidates (2 bytes each) in front of its pieces at which a speculative count starts
+    // candidates (2 bytes each) in front of its pieces at which a speculative count starts.  Half a piece: with 2 KiB (what the
+    // segment walkers start with) enough counts of four-part streams arrived on a wrong chain -- and then decode from what the
+    // part in front says, one part after the other -- that four parts were slower than two (tools/side_warm2.sh: 16 x 12 MP
+    // natural frames 110 -> 85 us, 14-bit noise 205 -> 162 us with 16 KiB)
+    constexpr uint32_t SPEC_WARM = MCRAW_SPEC_WARM;
+    static_assert(SPEC_WARM <= SIDE_HALF, "a speculative count starts inside the piece in front of the part's first");
 
     // registers -> bytes of a piece (what the decoders read)
     auto store_bytes = [&](const Lines &r) {
