@@ -274,7 +274,7 @@ def mixed64_leg(torch, ctx, M, L, dev, reps=40):
     for i, it in enumerate(items):
         ok = ok and np.array_equal(tout[i].cpu().numpy().view(np.uint16).reshape(it[1].shape), it[1])
     ctx.profile(False) # (no events between the batches: they follow each other on the stream, as the bench line's steps do)
-    for _ in range(3):
+    for _ in range(24): # (the split of the side streams is measured on the first launches of a geometry)
         ctx.decode_batch(frames, want_status=False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -287,7 +287,7 @@ def mixed64_leg(torch, ctx, M, L, dev, reps=40):
     byts = sum(it[2].size for it in items) + 2 * px
     return {"workload": "config 4: 64 frames, type 7 (14-bit U/Nat) and type 6 (10/12/14-bit) interleaved, 1920x1080 / 4032x3024 / 4000x3000",
             "ms_per_batch": round(t * 1e3, 4), "batches_timed": reps, "mpix_s": round(px / t / 1e6, 1),
-            "in_plus_out_GBs": round(byts / t / 1e9, 1), "bit_exact": bool(ok)}
+            "in_plus_out_GBs": round(byts / t / 1e9, 1), "side_parts": ctx.side_parts(), "bit_exact": bool(ok)}
 
 
 def cpu_baseline(L, wl, seconds):
@@ -622,7 +622,7 @@ def config5_leg(torch, ctx, M, L, dev, n=120, w=7680, h=4320, nbits=12, sigma=12
     used = [orc.mcraw_oracle_len_used7(L._ptr(p[1]), p[1].size) for p in pairs]
     byts = sum(used[i % distinct] for i in range(n)) + n * w * h * 2
     ctx.profile(False)
-    for _ in range(8):  # (the library times its XCD mapping of k7_tiles on the first launches on a new set of buffers)
+    for _ in range(28):  # (the library times the XCD mapping of k7_tiles and the split of the side streams on the first launches of a geometry)
         ctx.decode_batch(frames, want_status=False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -639,7 +639,8 @@ def config5_leg(torch, ctx, M, L, dev, n=120, w=7680, h=4320, nbits=12, sigma=12
     kms = {k: round(ctx.kernel_ms(k, reset=True)[0] / 3.0, 4) for k in ("k7_side", "k7_tiles")}
     out = {"workload": "config 5, one rank's share: %d x %dx%d %d-bit type-7 frames, Nat" % (n, w, h, nbits), "ms_per_step": round(t * 1e3, 4),
            "steps_timed": reps, "mpix_s": round(n * w * h / t / 1e6, 1), "algorithmic_bytes_per_step": byts,
-           "step_frac": round(byts / t / 1e9 / HBM_PEAK_GBS, 4), "kernels_ms_per_step": kms, "xcd_runs": ctx.xcd_runs(), "bit_exact": bool(ok)}
+           "step_frac": round(byts / t / 1e9 / HBM_PEAK_GBS, 4), "kernels_ms_per_step": kms, "xcd_runs": ctx.xcd_runs(),
+           "side_parts": ctx.side_parts(), "bit_exact": bool(ok)}
     if kms["k7_tiles"] > 0:
         out["frac"] = round(byts / (kms["k7_tiles"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     del tin, tout

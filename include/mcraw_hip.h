@@ -206,6 +206,11 @@ int mcraw_ctx_kernel_ms(mcraw_ctx *ctx, int id, double *ms, int *launches, int r
  * in eight parts), -1 while the first measurements are under way or nothing was measured (small or host-memory batches use
  * runs of 128).  Environment MCRAW_XCD_CHUNK pins the mapping (then always -1 here). */
 int mcraw_ctx_xcd_runs(mcraw_ctx *ctx);
+/* How many workgroups resolve each side stream of the frames of large-frame resident batches (lib/RawData.cpp:463-498 is one chain
+ * per stream; which of a frame's two streams is the slow one depends on its content): chosen by measurement on the first launches
+ * of a geometry, re-checked by one timed launch in 64.  Returns 16 * (parts of the bits stream) + (parts of the refs stream) for
+ * the geometry of the last such batch, -1 while measuring or when nothing was measured. */
+int mcraw_ctx_side_parts(mcraw_ctx *ctx);
 
 /* Optional stage fused behind the decode, for consumers that take the mosaic further on the
  * device or ship it as a DNG strip (what example.cpp:80-92 hands to the DNG writer: the raw strip,

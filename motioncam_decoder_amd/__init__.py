@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "mcraw_pool_size", "mcraw_pool_device", "mcraw_pool_numa_cpus", "mcraw_pool_ctx", "mcraw_pool_set_post",
     "mcraw_pool_host_alloc", "mcraw_pool_decode_batch", "mcraw_pool_decode_batch_async", "mcraw_pool_ticket_wait",
     "mcraw_pool_decode_batch_device", "mcraw_ctx_xcd_runs", "mcraw_pool_synchronize", "mcraw_tile_order",
-    "mcraw_ctx_last_serial", "mcraw_ctx_batch_status", "mcraw_ctx_errors",
+    "mcraw_ctx_last_serial", "mcraw_ctx_batch_status", "mcraw_ctx_errors", "mcraw_ctx_side_parts",
 ]
 
 POST_BLACK, POST_PACK12, POST_PACK10, POST_PACK14 = 1, 2, 4, 8
@@ -343,6 +343,11 @@ class Context:
         if rc != 0:
             raise McrawError("mcraw_ctx_synchronize failed (%d): %s" % (rc, self._lib.mcraw_last_error().decode()))
         return list(status)[:nframes]
+
+    def side_parts(self):
+        """(parts of the bits stream, parts of the refs stream) k7_side was measured to run fastest with, or None."""
+        v = int(self._lib.mcraw_ctx_side_parts(self._h))
+        return None if v < 0 else (v >> 4, v & 15)
 
     def last_serial(self):
         return int(self._lib.mcraw_ctx_last_serial(self._h))

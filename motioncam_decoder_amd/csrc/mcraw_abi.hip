@@ -156,6 +156,26 @@ struct mcraw_ctx {
         std::vector<Pending> pending;
         unsigned long long used = 0; // (least recently used entry is replaced)
     } tunes[4]; // a few geometries at a time
+    // How many workgroups ("parts") resolve a long side stream of a small resident batch (Work7::nsplit[bits, refs]): which of
+    // the two streams is the slow one is a matter of content -- the bits stream of coded frames (short runs of equally long
+    // records), the refs stream of noise --, and the chip holds 512 workgroups of k7_side at a time.  Chosen like the XCD mapping:
+    // the first launches of a geometry try each candidate twice between events, the fastest stays, one launch in 64 re-checks.
+    struct SideTune {
+        static constexpr int MAXC = 6;
+        int key_n = 0;
+        uint32_t key_R = 0;
+        int nc = 0, cand[MAXC][2] = {{1, 1}};
+        int issued[MAXC] = {0}, done[MAXC] = {0};
+        float best[MAXC] = {0.f};
+        int decided = -1;
+        unsigned long long launches = 0, used = 0;
+        struct Pending {
+            hipEvent_t a, b;
+            int cand;
+        };
+        std::vector<Pending> pending;
+    } side_tunes[4];
+    int side_last = -1;
     unsigned long long tune_clock = 0;
     int tune_last = -1; // entry of the last tunable batch (mcraw_ctx_xcd_runs)
     // last device-memory batch, for mcraw_ctx_synchronize
@@ -338,6 +358,101 @@ int tune_pick(mcraw_ctx *c, int n7, uint32_t R, uint32_t mode)
     return pick;
 }
 
+// The split of the side streams the next k7_side launch of a resident batch runs with: the index of a candidate to run AND
+// time, or -1 = the entry's `decided` (the first candidate while nothing is decided).  c->side_last is the entry.
+int side_pick(mcraw_ctx *c, int n7, uint32_t R)
+{
+    typedef mcraw_ctx::SideTune ST;
+    constexpr int SAMPLES = 2, NT = static_cast<int>(sizeof(c->side_tunes) / sizeof(c->side_tunes[0]));
+    constexpr unsigned long long RECHECK = 64;
+    int e = -1, lru = 0;
+    for (int i = 0; i < NT; i++) {
+        if (c->side_tunes[i].key_n == n7 && c->side_tunes[i].key_R == R && c->side_tunes[i].nc)
+            e = i;
+        if (c->side_tunes[i].used < c->side_tunes[lru].used)
+            lru = i;
+    }
+    if (e < 0) {
+        e = lru;
+        ST &t = c->side_tunes[e];
+        for (auto &p : t.pending) {
+            (void)hipEventSynchronize(p.b);
+            c->event_pool.push_back(p.a);
+            c->event_pool.push_back(p.b);
+        }
+        t.pending.clear();
+        t.key_n = n7;
+        t.key_R = R;
+        t.decided = -1;
+        t.launches = 0;
+        // (512 workgroups of k7_side are resident at once; parts that own little leave early, so somewhat more can pay:
+        // 120 x 8K frames ran fastest with 4 + 1 parts = 600 workgroups, tools/side_split.py)
+        const int budget = 1024 / std::max(n7, 1);
+        static const int all[][2] = {{4, 4}, {4, 2}, {4, 1}, {2, 2}, {2, 4}, {3, 1}, {1, 3}};
+        t.nc = 0;
+        for (const auto &cd : all)
+            if (cd[0] + cd[1] <= budget && t.nc < ST::MAXC)
+                t.cand[t.nc][0] = cd[0], t.cand[t.nc][1] = cd[1], t.nc++;
+        if (t.nc == 0)
+            t.cand[0][0] = t.cand[0][1] = 1, t.nc = 1;
+        for (int k = 0; k < ST::MAXC; k++)
+            t.issued[k] = t.done[k] = 0, t.best[k] = 0.f;
+    }
+    ST &t = c->side_tunes[e];
+    t.used = ++c->tune_clock;
+    c->side_last = e;
+    for (size_t i = 0; i < t.pending.size();) {
+        if (hipEventQuery(t.pending[i].b) != hipSuccess) {
+            (void)hipGetLastError();
+            i++;
+            continue;
+        }
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.pending[i].a, t.pending[i].b) == hipSuccess && ms > 0.f) {
+            const int k = t.pending[i].cand;
+            if (t.decided < 0)
+                t.best[k] = t.done[k] ? std::min(t.best[k], ms) : ms;
+            else
+                t.best[k] = 0.75f * t.best[k] + 0.25f * ms;
+            t.done[k]++;
+        }
+        c->event_pool.push_back(t.pending[i].a);
+        c->event_pool.push_back(t.pending[i].b);
+        t.pending.erase(t.pending.begin() + static_cast<long>(i));
+    }
+    if (t.nc == 1) {
+        t.decided = 0;
+        return -1;
+    }
+    if (t.decided >= 0) {
+        for (int k = 0; k < t.nc; k++)
+            if (t.best[k] < 0.97f * t.best[t.decided])
+                t.decided = k;
+        t.launches++;
+        if (t.launches % RECHECK != 0 || !t.pending.empty())
+            return -1;
+        return static_cast<int>((t.launches / RECHECK) % static_cast<unsigned long long>(t.nc));
+    }
+    bool all_done = true;
+    for (int k = 0; k < t.nc; k++)
+        all_done = all_done && t.done[k] >= SAMPLES;
+    if (all_done) {
+        t.decided = 0;
+        for (int k = 1; k < t.nc; k++)
+            if (t.best[k] < t.best[t.decided])
+                t.decided = k;
+        return -1;
+    }
+    int pick = -1;
+    for (int k = 0; k < t.nc; k++)
+        if (t.issued[k] < SAMPLES + 1 && (pick < 0 || t.issued[k] < t.issued[pick]))
+            pick = k;
+    if (pick < 0)
+        return -1;
+    t.issued[pick]++;
+    return pick;
+}
+
 int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::vector<Geom7> *geom_override,
            const uint8_t *const *dev_in, uint16_t *const *dev_out, hipStream_t st, size_t *status_off)
 {
@@ -456,17 +571,26 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     // Long side streams of small batches are resolved by several workgroups each (k7_side "parts") when the chip has room for
     // them all at once (two workgroups of k7_side per CU).  What a part saves is the other parts' pieces; what it adds is a
     // count over its own pieces and a hand-off: measured (tools/side_split.py, tools/side_warm2.sh), 16 x 12 MP frames
-    // 160 -> 85 us with four parts per stream (14-bit noise 205 -> 162), 120 x 8K 270 -> 208 us with two (four would be 960
-    // workgroups), UHD frames (streams of two to eight pieces) lose.  MCRAW_SIDE_SPLIT=b,r pins the numbers (tests run the
-    // type-7 suites with 2,2 and 4,4).
+    // 160 -> 85 us with four parts per stream (14-bit noise 205 -> 162), 120 x 8K 270 -> 208 us with two, UHD frames (streams
+    // of two to eight pieces) lose.  Which stream needs the parts is a matter of content, so resident batches measure
+    // (side_pick); host-memory batches and re-planned frames take two or four per stream.  MCRAW_SIDE_SPLIT=b,r pins the
+    // numbers (tests run the type-7 suites with 2,2 and 4,4).
     int nsplit[2] = {1, 1};
+    int side_cand = -1;
     {
         uint32_t rmax = 0;
         for (const Plan7 &p : B.p7)
             rmax = std::max(rmax, p.ngroups);
-        if (rmax >= 2900u && n7 * 8 <= 512)
+        const bool longstreams = rmax >= 2900u && n7 * 4 <= 1024;
+        if (longstreams && !dev_in && !geom_override && !std::getenv("MCRAW_SIDE_SPLIT")) {
+            side_cand = side_pick(c, n7, rmax);
+            const mcraw_ctx::SideTune &t = c->side_tunes[c->side_last];
+            const int k = side_cand >= 0 ? side_cand : std::max(t.decided, 0);
+            nsplit[0] = t.cand[k][0];
+            nsplit[1] = t.cand[k][1];
+        } else if (longstreams && n7 * 8 <= 512)
             nsplit[0] = nsplit[1] = 4;
-        else if (rmax >= 2900u && n7 * 4 <= 512)
+        else if (longstreams && n7 * 4 <= 512)
             nsplit[0] = nsplit[1] = 2;
         if (const char *e = std::getenv("MCRAW_SIDE_SPLIT")) {
             int b = 0, r = 0;
@@ -615,7 +739,8 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
             W.class_groups[k] = class_groups[k];
         for (uint32_t stage : {MCRAW_K7_SIDE, MCRAW_K7_TILES}) {
             hipEvent_t ta = nullptr, tb = nullptr;
-            if (stage == MCRAW_K7_TILES && tune_cand >= 0) {
+            const bool time_side = stage == MCRAW_K7_SIDE && side_cand >= 0;
+            if ((stage == MCRAW_K7_TILES && tune_cand >= 0) || time_side) {
                 ta = get_event(c);
                 tb = get_event(c);
                 if (ta && tb)
@@ -627,7 +752,10 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
             }
             if (ta && tb) {
                 (void)hipEventRecord(tb, st);
-                c->tunes[c->tune_last].pending.push_back({ta, tb, tune_cand});
+                if (time_side)
+                    c->side_tunes[c->side_last].pending.push_back({ta, tb, side_cand});
+                else
+                    c->tunes[c->tune_last].pending.push_back({ta, tb, tune_cand});
             }
         }
     }
@@ -1504,6 +1632,17 @@ int mcraw_ctx_xcd_runs(mcraw_ctx *c)
         return -2;
     std::lock_guard<std::mutex> lk(c->mu);
     return c->tune_last >= 0 && c->tunes[c->tune_last].decided >= 0 ? static_cast<int>(TUNE_CHUNKS[c->tunes[c->tune_last].decided]) : -1;
+}
+
+int mcraw_ctx_side_parts(mcraw_ctx *c)
+{
+    if (!c)
+        return -2;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->side_last < 0 || c->side_tunes[c->side_last].decided < 0)
+        return -1;
+    const mcraw_ctx::SideTune &t = c->side_tunes[c->side_last];
+    return t.cand[t.decided][0] * 16 + t.cand[t.decided][1];
 }
 
 int mcraw_ctx_profile_every(mcraw_ctx *c, int n)

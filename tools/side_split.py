@@ -29,7 +29,7 @@ for name, w, h, nb, dist, sig, n in shapes:
     tout = torch.zeros(n * w * h * 2, dtype=torch.uint8, device=dev)
     fr = M.Context.make_frames([(tin[i % 2].data_ptr(), tin[i % 2].numel(), w, h, 7, tout.data_ptr() + i * w * h * 2, w * h) for i in range(n)])
     line = {}
-    for sp in os.environ.get("SPLITS", "auto,1,2,4").split(","):
+    for sp in os.environ.get("SPLITS", "auto;1;2;4").split(";"):
         if sp == "auto":
             os.environ.pop("MCRAW_SIDE_SPLIT", None)
         else:
