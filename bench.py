@@ -582,7 +582,7 @@ def legacy_leg(torch, ctx, M, L, dev, n=32, w=4000, h=3000, nbits=12, sigma=12.0
            "mpix_s": round(n * w * h / t / 1e6, 1), "in_plus_out_GBs": round(byts / t / 1e9, 1),
            "input_bpp": round(8.0 * bufs[0].size / (w * h), 2), "kernels_ms": kms, "bit_exact": bool(ok)}
     # the same roofline figures as for the bench line: the batch (wall) and its one kernel against the HBM peak, and the
-    # HBM traffic of that kernel from the committed counter passes (tools/profile_r03.sh; not measured in this run)
+    # HBM traffic of that kernel from the committed counter passes (tools/profile_round.sh; not measured in this run)
     out["step_frac"] = round(byts / t / 1e9 / 8000.0, 4)
     out["algorithmic_bytes_per_batch"] = byts
     if kms["k6_decode"] > 0:

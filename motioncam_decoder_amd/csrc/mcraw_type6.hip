@@ -297,15 +297,16 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
 #pragma unroll
         for (uint32_t r = 0; r < NROUND; r++) {
             const uint32_t i = tid + r * DEC_T;
-            // (streamed, but for the segment's last chunk: the next segment of this frame -- on this XCD when frames and XCDs
-            // go round in step -- reads it again as its front and then finds it in the L2)
+            // Plain loads (round 4; round 3's were non-temporal): the KiB in front of the segment is the last KiB of the segment
+            // before, and the pieces a thread of the last round fetches BEHIND the stage (3 KiB: the round is not full) are the
+            // next segment's first -- both are found in the XCD's L2 by the workgroup that needs them when a frame's segments run on
+            // one XCD.  Counters: 1.015 x the stream's bytes fetched from memory (non-temporal: 1.23 - 1.47 x, the lines were
+            // fetched again), and the fetch behind the stage is worth 2 - 4 % (tools/ab6n.sh).
             const uint32_t off = seg * OWN - FRONT6 + i * 16u;
             if (!(seg || i >= FRONT6 / 16u))
                 v[r] = make_uint4(0u, 0u, 0u, 0u);
-            else if (i >= (FRONT6 + OWN - CHUNK6) / 16u)
-                v[r] = ld_b128(rs, off);
             else
-                v[r] = ld_b128_nt(rs, off);
+                v[r] = ld_b128(rs, off);
         }
     };
     fetch();
@@ -665,14 +666,21 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
             if (lane == 0)
 #endif
                 look_put(res, epoch, (RES_AGG << 30) | (total << 5) | (lost ? DEAD : lastp));
+            // (a window of LBW segments per poll: the nearest segment that already holds a prefix is mostly less than ten back --
+            // what lies between a segment's own count and its prefix is one look-back --, and a poll is LBW small requests to the
+            // fabric: with 64 lanes polling, the polls were a quarter of the kernel's fetched bytes)
+#ifndef K6_LBW
+#define K6_LBW 16
+#endif
+            constexpr uint32_t LBW = K6_LBW;
             int32_t jn = static_cast<int32_t>(seg) - 1; // nearest segment of the window (lane 0)
             while (!lost) {
                 const int32_t k = jn - static_cast<int32_t>(lane);
                 w = RES_AGG << 30; // segments "before the frame": nothing, and never reached (segment 0 has a prefix)
-                const bool ok = k < 0 || (look_get(res - seg + k, epoch, &w) && (w >> 30) != 0u);
+                const bool ok = lane < LBW && (k < 0 || (look_get(res - seg + k, epoch, &w) && (w >> 30) != 0u));
                 const uint64_t okm = __ballot(ok), pm = __ballot(ok && (w >> 30) == RES_PREFIX);
-                const uint32_t np = pm ? static_cast<uint32_t>(__builtin_ctzll(pm)) : 64u; // lanes in front of the first prefix
-                const uint64_t need = np >= 64u ? ~0ull : ((1ull << np) | ((1ull << np) - 1ull));
+                const uint32_t np = pm ? static_cast<uint32_t>(__builtin_ctzll(pm)) : LBW; // lanes in front of the first prefix
+                const uint64_t need = np >= LBW ? (1ull << LBW) - 1ull : ((1ull << np) | ((1ull << np) - 1ull));
                 if ((okm & need) != need) { // not all published yet
                     if (++spins > SPIN6)
                         lost = true;
@@ -680,11 +688,11 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                     continue;
                 }
                 uint32_t add;
-                (void)wave_excl_scan(lane <= np ? (w >> 5) & 0xFFFFFFu : 0u, lane, &add);
+                (void)wave_excl_scan(lane <= np && lane < LBW ? (w >> 5) & 0xFFFFFFu : 0u, lane, &add);
                 base = min(base + add, 0xFFFFFFu);
-                if (np < 64u)
+                if (np < LBW)
                     break;
-                jn -= 64;
+                jn -= static_cast<int32_t>(LBW);
             }
         }
         K6_STAMP(12, RESOLVER * 64u);

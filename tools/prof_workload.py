@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One workload of the bench line, alone, for rocprofv3 (tools/profile_r03.sh): the program goes directly behind `--`.
+"""One workload of the bench line, alone, for rocprofv3 (tools/profile_round.sh): the program goes directly behind `--`.
 
     python3 tools/prof_workload.py nat|u|legacy|mixed64|post12|config5 [launches]
 
@@ -40,7 +40,7 @@ def main():
         stream = torch.cuda.current_stream().cuda_stream
         written, status = ctx.decode_batch(wl.descs, mem=M.MEM_DEVICE, stream=stream, want_status=True)
         assert all(s == 0 for s in status)
-        for _ in range(8):  # (the XCD mapping of k7_tiles is measured on the first launches)
+        for _ in range(24):  # (the XCD mapping of k7_tiles and the split of the side streams are measured on the first launches)
             ctx.decode_batch(wl.descs, mem=M.MEM_DEVICE, stream=stream, want_status=False)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -17,5 +17,5 @@ for W in nat u legacy; do
   rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d "$OUT/$W/write" -- python3 "$R/tools/prof_workload.py" $W 4 > "$OUT/$W.write.log" 2>&1
   rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU -d "$OUT/$W/sq" -- python3 "$R/tools/prof_workload.py" $W 4 > "$OUT/$W.sq.log" 2>&1
 done
-cd "$R" && python3 tools/summarize_r03.py "$TAG" > "$OUT/summary.log" 2>&1
+cd "$R" && python3 tools/summarize_round.py "$TAG" > "$OUT/summary.log" 2>&1
 tail -20 "$OUT/summary.log"

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/prof_<tag>/<workload>/ (rocprofv3 CSVs of tools/profile_r03.sh) -> profiles/<tag>_<workload>_kernel_stats.csv
+"""gpurun_out/prof_<tag>/<workload>/ (rocprofv3 CSVs of tools/profile_round.sh) -> profiles/<tag>_<workload>_kernel_stats.csv
 (the mcraw kernels' rows, with the run's JSON line -- box yardstick included -- as a comment header), profiles/<tag>_counters.json
 and the HBM traffic of the dominant kernels (profiles/traffic.json for k7_tiles, profiles/<tag>_legacy_traffic.json).
 
@@ -44,7 +44,7 @@ def main():
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
-    summary = {"tag": tag, "made_by": "tools/profile_r03.sh (rocprofv3 ... -- python3 tools/prof_workload.py <workload> <launches>)", "workloads": {}}
+    summary = {"tag": tag, "made_by": "tools/profile_round.sh (rocprofv3 ... -- python3 tools/prof_workload.py <workload> <launches>)", "workloads": {}}
     for w in ("nat", "u", "legacy", "mixed64", "post12", "config5"):
         info = last_json(os.path.join(src, w + ".stats.log"))
         stats = sorted(glob.glob(os.path.join(src, w, "stats", "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
