@@ -21,6 +21,8 @@
 
 #include "../../include/mcraw_hip.h"
 
+#include <type_traits>
+
 namespace mcraw {
 
 constexpr uint32_t DEAD = 31; // phase value: the chain ended (a record crossed `len`)
@@ -48,34 +50,46 @@ constexpr uint32_t SPIN6 = 1u << 12;
 constexpr uint32_t SPIN6 = 1u << 20;              // polls before a workgroup gives the frame up (never seen; a hang is worse)
 #endif
 
-// Samples 4*qt..4*qt+3 of the record at byte `ro` of the staged stream, reference NOT yet added;
-// *ref receives the header's 12-bit reference (RawData_Legacy.cpp:372-375).  The payload is an
-// MSB-first bitstream of sb-bit fields (sb = header nibble for <= 10, 16 big-endian raw bits above,
-// RawData_Legacy.cpp:38-370), so the lane's four fields are the top 4*sb bits of a 64-bit
-// big-endian window that starts 4*qt*sb bits into the payload.  The window is cut out of three
-// aligned dwords with two byte permutes (alignment and byte swap in one selector).
-__device__ __forceinline__ void quad6(const uint8_t *__restrict__ bytes, uint32_t ro, uint32_t qt, uint32_t v[4],
-                                      uint32_t *ref)
+// A lane's record PAIR (round 4): what is computed once per record is computed for both records at once.
+//   ha, hb : the two headers (records start on even bytes: 16-bit reads), even-column record first
+//   refs   : both 12-bit references, packed like the samples (RawData_Legacy.cpp:372-375: big-endian, low nibble of byte 0 first)
+struct Pair6 {
+    uint32_t sa, sb;   // field widths
+    uint32_t refs;
+};
+__device__ __forceinline__ Pair6 pair6_head(uint32_t ha, uint32_t hb)
 {
-    const uint32_t h = *reinterpret_cast<const uint16_t *>(bytes + ro); // records start on even bytes
-    const uint32_t hb = (h >> 4) & 15u;
-    *ref = ((h & 15u) << 8) | (h >> 8);
-    const uint32_t sb = hb <= 10u ? hb : 16u;
-    const uint32_t ob = 4u * qt * sb;       // bit offset of my fields in the payload
-    const uint32_t B = ro + 2u + (ob >> 3); // first byte of the window
+    Pair6 r;
+    const uint32_t na = __builtin_amdgcn_ubfe(ha, 4u, 4u), nb = __builtin_amdgcn_ubfe(hb, 4u, 4u);
+    r.sa = na <= 10u ? na : 16u;
+    r.sb = nb <= 10u ? nb : 16u;
+    const uint32_t hh = ha | (hb << 16);
+    r.refs = __builtin_amdgcn_perm(hh, hh, 0x02030001u) & 0x0FFF0FFFu; // bytes swapped inside each half
+    return r;
+}
+// Samples 4*qt..4*qt+3 (qt4 = 4 * qt) of the record at byte `ro` of the staged stream, field width `s`, reference NOT yet
+// added.  The payload is an MSB-first bitstream of s-bit fields (s = header nibble for <= 10, 16 big-endian raw bits above,
+// RawData_Legacy.cpp:38-370), so the lane's four fields are the top 4*s bits of a 64-bit big-endian window that starts
+// 4*qt*s bits into the payload.
+__device__ __forceinline__ void quad6u(const uint8_t *__restrict__ bytes, uint32_t ro, uint32_t qt4, uint32_t s, uint32_t v[4])
+{
+    const uint32_t ob = mul_u24(qt4, s);                                               // bit offset of my fields in the payload
+    // the window: three aligned dwords, cut to the byte it starts on and byte-swapped by two permutes (one selector does both).
+    // (gfx950 reads LDS at any alignment, and ONE 8-byte read at the window's first byte holds all four fields -- but such reads
+    // stall the LDS pipeline: the kernel 0.383 instead of 0.362 ms, docs/lab_notes.md)
+    const uint32_t B = ro + 2u + (ob >> 3);
     const uint32_t *w = reinterpret_cast<const uint32_t *>(bytes + (B & ~3u));
-    const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
     const uint32_t k = B & 3u;
+    const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
     const uint32_t sel = 0x00010203u + __builtin_amdgcn_perm(k, k, 0u); // k in every byte lane
-    const uint32_t hi0 = __builtin_amdgcn_perm(d1, d0, sel), lo0 = __builtin_amdgcn_perm(d2, d1, sel);
-    // odd field width and odd quarter: the fields start on a nibble
-    const uint64_t W = ((static_cast<uint64_t>(hi0) << 32) | lo0) << (ob & 4u);
-    const uint32_t hi = static_cast<uint32_t>(W >> 32);
-    // fields 0 and 1 end within the high dword for every width; 2 and 3 can reach into the low one
-    v[0] = __builtin_amdgcn_ubfe(hi, (32u - sb) & 31u, sb);
-    v[1] = __builtin_amdgcn_ubfe(hi, (32u - 2u * sb) & 31u, sb);
-    v[2] = __builtin_amdgcn_ubfe(static_cast<uint32_t>(W >> ((64u - 3u * sb) & 63u)), 0u, sb);
-    v[3] = __builtin_amdgcn_ubfe(static_cast<uint32_t>(W >> ((64u - 4u * sb) & 63u)), 0u, sb);
+    const uint32_t hi = __builtin_amdgcn_perm(d1, d0, sel), lo = __builtin_amdgcn_perm(d2, d1, sel);
+    const uint64_t W = (static_cast<uint64_t>(hi) << 32) | lo; // big-endian window; my fields start (ob & 4) bits below its top
+    // field i ends p_i = 64 - (ob & 4) - (i + 1) * s bits above the window's bottom: p_0, p_1 >= 32 for every width
+    const uint32_t p0 = (64u - s) - (ob & 4u), p1 = p0 - s, p2 = p1 - s, p3 = p2 - s;
+    v[0] = __builtin_amdgcn_ubfe(hi, p0 & 31u, s);
+    v[1] = __builtin_amdgcn_ubfe(hi, p1 & 31u, s);
+    v[2] = __builtin_amdgcn_ubfe(static_cast<uint32_t>(W >> (p2 & 63u)), 0u, s);
+    v[3] = __builtin_amdgcn_ubfe(static_cast<uint32_t>(W >> (p3 & 63u)), 0u, s);
 }
 
 // Unpacking: one wave per ROWS_CH consecutive chunks (4 KiB of stream), four such waves per workgroup.  Lanes
@@ -870,36 +884,45 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     const uint32_t m20 = widerow ? 0u : ((1u << 20) + ppr - 1u) / ppr;
 
     // Unpack the pairs of records [wlo, whi) (both even) of unpacking wave uw, listed in s_pos[uw]: four lanes per pair; of
-    // its 2 * (whi - wlo) tasks, those in [tb, te)
-    auto unpack_round = [&](uint32_t uw, uint32_t wlo, uint32_t whi, bool by_pair, uint32_t tb, uint32_t te) {
+    // its 2 * (whi - wlo) tasks, those in [tb, te).  What is the same for every task of a round -- the list's layout, whether a
+    // round can span more than two rows -- is decided once, outside the loop (a workgroup has one ready wave per SIMD most of
+    // the time: every scalar branch inside the loop is paid in full).
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+    auto unpack_loop = [&](auto by_pair_t, auto wide_t, auto fast_t, uint32_t uw, uint32_t wlo, uint32_t tb, uint32_t te) {
+        constexpr bool BY_PAIR = decltype(by_pair_t)::value, WIDE = decltype(wide_t)::value, FAST = decltype(fast_t)::value;
         const uint8_t *bytes = s_own + uw * (ROWS_CH * CHUNK6);
         const uint32_t pair0 = wlo >> 1;
         const uint16_t *pairs = s_pos[uw];
         const uint32_t *both = reinterpret_cast<const uint32_t *>(s_pos[uw]);
         const uint32_t y0 = pair0 / ppr, r0 = pair0 - y0 * ppr; // wave-uniform
         const uint32_t row0 = y0 * width;
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+        const uint32_t qt = (tb + lane) & 3u, qt4 = 4u * qt; // (t advances by 64)
         for (uint32_t t = tb + lane; t < te; t += 64u) {
             // one task: 8 pixels (even columns from record A, odd columns from record B, uint16 wrap
             // on the reference add) and where they go
-            const uint32_t q = t >> 2, qt = t & 3u;
-            uint32_t roa, rob;
-            if (by_pair) { // the odd-column record starts where the even-column one ends (RawData_Legacy.cpp:377-442)
+            const uint32_t q = t >> 2;
+            uint32_t roa, rob, ha, hb;
+            if (BY_PAIR) { // the odd-column record starts where the even-column one ends (RawData_Legacy.cpp:377-442)
                 roa = pairs[q];
-                rob = roa + 2u + len6_of(static_cast<uint32_t>(bytes[roa]) >> 4);
+                ha = *reinterpret_cast<const uint16_t *>(bytes + roa);
+                rob = roa + 2u + len6_of(__builtin_amdgcn_ubfe(ha, 4u, 4u));
+                hb = *reinterpret_cast<const uint16_t *>(bytes + rob);
             } else {
                 const uint32_t ro2 = both[q];
                 roa = ro2 & 0xffffu;
                 rob = ro2 >> 16;
+                ha = *reinterpret_cast<const uint16_t *>(bytes + roa);
+                hb = *reinterpret_cast<const uint16_t *>(bytes + rob);
             }
-            uint32_t va[4], vb[4], refa, refb;
-            quad6(bytes, roa, qt, va, &refa);
-            quad6(bytes, rob, qt, vb, &refb);
+            const Pair6 hd = pair6_head(ha, hb);
+            uint32_t va[4], vb[4];
+            quad6u(bytes, roa, qt4, hd.sa, va);
+            quad6u(bytes, rob, qt4, hd.sb, vb);
             const uint32_t n = r0 + q;
-            const uint32_t dy = widerow ? (n >= ppr ? 1u : 0u) : mul_u24(n, m20) >> 20;
+            const uint32_t dy = WIDE ? (n >= ppr ? 1u : 0u) : mul_u24(n, m20) >> 20;
             const uint32_t x = (n - __umul24(dy, ppr)) * 32u + 8u * qt; // RawData_Legacy.cpp:479-486
-            const u16x2 refs = __builtin_bit_cast(u16x2, refa | (refb << 16));
+            const u16x2 refs = __builtin_bit_cast(u16x2, hd.refs);
             uint32_t o[4];
 #pragma unroll
             for (int j = 0; j < 4; j++)
@@ -911,14 +934,21 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
             }
             // (y0 + dy) * width without a per-lane 32-bit multiply: a wide row (width can exceed 24
             // bits) advances by at most one row per round, a narrow one has width < 2^14
-            uint16_t *px = out + (row0 + (widerow ? (dy ? width : 0u) : __umul24(dy, width)) + x);
+            uint16_t *px = out + (row0 + (WIDE ? (dy ? width : 0u) : __umul24(dy, width)) + x);
+            const bool whole = x + 8u <= width;
             if (K6_ABL == 1) {
                 if ((o[0] ^ o[1] ^ o[2] ^ o[3]) == 0x12345678u)
                     px[0] = 1;
-            } else if (fast && x + 8u <= width) {
-                const u32x4 v = {o[0], o[1], o[2], o[3]};
-                __builtin_nontemporal_store(v, gptr<u32x4>(px));
-            } else if (x + 8u <= width) { // rows off the 16-byte grid: still one (unaligned) 16-byte store
+            } else if (__builtin_expect(__ballot(!whole) == 0ull, 1)) { // (no lane of this pass at a cropped row end: the rule)
+                if (FAST) {
+                    const u32x4 v = {o[0], o[1], o[2], o[3]};
+                    store_stream16(px, __builtin_bit_cast(mcraw_u32x4, v)); // (write-through, streaming: as k7_tiles' stores)
+                } else { // rows off the 16-byte grid: still one (unaligned) 16-byte store
+                    typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(2)));
+                    const u32x4_u v = {o[0], o[1], o[2], o[3]};
+                    *gptr<u32x4_u>(px) = v;
+                }
+            } else if (whole) {
                 typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(2)));
                 const u32x4_u v = {o[0], o[1], o[2], o[3]};
                 *gptr<u32x4_u>(px) = v;
@@ -928,6 +958,29 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                     if (x + j < width)
                         gptr<uint16_t>(px)[j] = static_cast<uint16_t>(o[j >> 1] >> (16u * (j & 1u)));
             }
+        }
+    };
+    auto unpack_round = [&](uint32_t uw, uint32_t wlo, uint32_t whi, bool by_pair, uint32_t tb, uint32_t te) {
+        (void)whi;
+        typedef std::integral_constant<bool, true> yes;
+        typedef std::integral_constant<bool, false> no;
+        const bool bp = __builtin_amdgcn_readfirstlane(by_pair ? 1 : 0) != 0; // (the same for all lanes: made known to the compiler)
+        auto with_layout = [&](auto wide_t, auto fast_t) {
+            if (bp)
+                unpack_loop(yes{}, wide_t, fast_t, uw, wlo, tb, te);
+            else
+                unpack_loop(no{}, wide_t, fast_t, uw, wlo, tb, te);
+        };
+        if (fast) {
+            if (widerow)
+                with_layout(yes{}, yes{});
+            else
+                with_layout(no{}, yes{});
+        } else { // rows off the 16-byte grid
+            if (widerow)
+                with_layout(yes{}, no{});
+            else
+                with_layout(no{}, no{});
         }
     };
 
