@@ -626,7 +626,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     {
         std::vector<uint32_t> nseg(n6);
         for (int k = 0; k < n6; k++) {
-            nseg[k] = (B.p6[k].nchunks + 4 * ROWS_CH - 1) / (4 * ROWS_CH);
+            nseg[k] = (B.p6[k].nchunks + SEG_CHUNKS6 - 1) / SEG_CHUNKS6;
             smax = std::max(smax, nseg[k]);
         }
         mcraw_legacy_launch_order(nseg.data(), n6, wg_tab.data());

@@ -116,16 +116,14 @@ static_assert(ROWS_CAP <= 1024u && ROWS_CAP % 2u == 0u, "the division-free row a
 
 // ------------------------------------------------------------------ k6_decode
 constexpr uint32_t TAIL6 = 128;           // (five-wave form) tasks (8 pixels each) of every unpacking wave's list that the fifth wave takes over
-constexpr uint32_t DEC_CH = 4 * ROWS_CH;  // chunks per workgroup: four unpacking waves
-#ifndef MCRAW_K6_WAVES
-#define MCRAW_K6_WAVES 4
-#endif
+constexpr uint32_t UNPACK_W = SEG_WAVES6;         // unpacking waves per workgroup
+constexpr uint32_t DEC_CH = UNPACK_W * ROWS_CH;   // chunks per workgroup
 // Waves per workgroup.  Four: the last wave resolves the chain, then unpacks its chunks like the others (seven workgroups fit a CU:
 // the kernel is a chain of latencies -- load, walk, look-back, lists, unpack --, and what hides them is the number of
 // segments in flight).  Five (rounds 2 and 3): a wave of its own resolves and then takes a share of every list.
 constexpr uint32_t DEC_T = 64 * MCRAW_K6_WAVES;
 constexpr bool FIFTH6 = DEC_T == 320;
-static_assert(DEC_T == 256 || DEC_T == 320, "four unpacking waves; the resolving wave is the last one");
+static_assert(DEC_T == 128 || DEC_T == 256 || DEC_T == 320, "two or four unpacking waves; the resolving wave is the last one");
 constexpr uint32_t FRONT6 = CHUNK6;       // bytes staged in front of the segment: the chains that cross into them have become one by the segment's start
 #ifndef MCRAW_WARM6
 #define MCRAW_WARM6 512
@@ -134,7 +132,7 @@ constexpr uint32_t WARM6 = MCRAW_WARM6;   // bytes in front of its quarter chunk
 constexpr uint32_t QUART6 = CHUNK6 / 4;   // bytes of stream per walker
 constexpr uint32_t NQ6 = 4 * DEC_CH;      // walkers = quarter chunks per segment
 constexpr uint32_t NOFRONT = 255;         // s_front's boundary: the chains never became one inside this segment
-static_assert(NQ6 == 64, "one walker per lane of the resolving wave");
+static_assert(NQ6 == 64 || NQ6 == 32, "one walker per lane of the resolving wave (the lanes behind them take no part)");
 static_assert(WARM6 <= FRONT6 && WARM6 % 2u == 0u && WARM6 >= 64u, "the walkers of the first quarter start inside the staged front");
 
 // Bytes from a record's header to the next record's (RawData_Legacy.cpp:13-32,377-442); `b` = the header's first byte.
@@ -263,7 +261,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     // holding the even record only (up to ROWS_CAP records; the unpacking lane finds the odd one behind it)
     typedef uint16_t PosList[ROWS_CAP / 2 + 2];
     static_assert(sizeof(PosList) % 4u == 0u, "the lists are read as dwords");
-    __shared__ __attribute__((aligned(4))) PosList s_pos[4];
+    __shared__ __attribute__((aligned(4))) PosList s_pos[UNPACK_W];
     // entry of my chunks and of the one behind them (phase | first record << 8), and of every quarter of my chunks
     __shared__ uint32_t s_ent[DEC_CH + 1], s_ent4[NQ6];
     __shared__ uint8_t s_fmap[32]; // (only for streams whose chains never meet) my entry phase -> my exit phase
@@ -334,7 +332,8 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
 
     // ---- what the resolving wave finds out (lane = quarter chunk: chunk uj, quarter ur)
     const uint32_t uj = lane >> 2, ur = lane & 3u;
-    const uint32_t qb = FRONT6 + lane * QUART6, qe = qb + QUART6;
+    const bool walker6 = lane < NQ6; // (two-wave workgroups: 32 quarters, the resolving wave's upper lanes stand behind every bound)
+    const uint32_t qb = walker6 ? FRONT6 + lane * QUART6 : 0u, qe = walker6 ? qb + QUART6 : 0u;
     constexpr uint32_t NOTES6 = 32;
     uint32_t nb[NOTES6 / 4u] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}; // where my quarter's records start (half positions, a byte each)
     uint32_t a = DEAD, x = DEAD, qn = 0u; // phases at which the chain enters and leaves my quarter; records it starts there
@@ -730,7 +729,8 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         const uint32_t ent4v = qp | (qi << 8);
         const uint32_t entv = inq && !lost ? (cph | (qi << 8)) : DEAD;                 // (lanes with ur == 0: chunk uj's)
         const uint32_t ent16 = full && !lost ? (aph | (endn << 8)) : DEAD;             // ... and of the chunk behind a full segment
-        s_ent4[lane] = ent4v;
+        if (walker6)
+            s_ent4[lane] = ent4v;
         if (ur == 0u)
             s_ent[uj] = entv;
         if (lane == 0)
@@ -748,14 +748,14 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         // also wait for the look-back words' way to memory -- stores count on the same counter)
         const uint32_t uw = lane / (4u * ROWS_CH), j = (lane >> 2) & (ROWS_CH - 1u), r = lane & 3u;
         static_assert(ROWS_CH == 4, "an unpacking wave's chunks are sixteen lanes of this wave");
-        const uint32_t ew0 = wave_lane(entv, 0u), ew1 = wave_lane(entv, 16u), ew2 = wave_lane(entv, 32u), ew3 = wave_lane(entv, 48u);
+        const uint32_t ew0 = wave_lane(entv, 0u), ew1 = wave_lane(entv, 16u), ew2 = wave_lane(entv, 32u % NQ6), ew3 = wave_lane(entv, 48u % NQ6);
         auto ent_reg = [&](uint32_t w) { // entry of chunk w * ROWS_CH, as ent_of() will read it
-            const uint32_t v = w == 0u ? ew0 : w == 1u ? ew1 : w == 2u ? ew2 : w == 3u ? ew3 : ent16;
+            const uint32_t v = w >= UNPACK_W ? ent16 : w == 0u ? ew0 : w == 1u ? ew1 : w == 2u ? ew2 : ew3;
             return cfirst + w * ROWS_CH < nchunks ? v : DEAD;
         };
         const uint32_t enext_reg = ent_reg(uw + 1u);
         const Range6 rg = range_from(uw, ent_reg(uw), enext_reg);
-        const bool coop = __ballot(!rg.lean) == 0ull;
+        const bool coop = __ballot(walker6 && !rg.lean) == 0ull;
         if (lane == 0)
             s_coop = coop ? 1u : 0u;
         // The common case (no jumps over runs of 2-byte records in this segment, at most NOTES6 records per quarter, every
@@ -765,8 +765,10 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         // (every quarter starts at least seven: a record has at most 34 bytes), taken from the lane behind it: what a lane
         // stores beyond its own records is then exactly what that lane stores there itself, and it does not matter which
         // of the two stores comes last.
-        const bool noted = coop && notes_ok && __ballot(rg.pairmode || rg.N + NOTES6 > ROWS_CAP / 2u) == 0ull;
-        if (K6_ABL != 3 && noted) {
+        const bool noted = coop && notes_ok && __ballot(walker6 && (rg.pairmode || rg.N + NOTES6 > ROWS_CAP / 2u)) == 0ull;
+        if (!walker6) {
+            // (the upper lanes of a two-wave workgroup's resolving wave list nothing)
+        } else if (K6_ABL != 3 && noted) {
             const int32_t slot0 = static_cast<int32_t>(qi - rg.R0); // -1: an odd first record belongs to the previous wave's
             uint16_t *lp = s_pos[uw] + slot0;                        // last pair, never listed
             const uint32_t boff = j * CHUNK6 + r * (CHUNK6 / 4u);
@@ -775,7 +777,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                 // the next quarter's first eight notes, 128 half positions further on (lane 63: the chunk behind the segment
                 // is entered at phase `aph`)
                 uint32_t x0 = wave_next(nb[0], 0u), x1 = wave_next(nb[1], 0u);
-                x0 = (lane == 63u ? aph & 31u : x0) | 0x80808080u;
+                x0 = (lane == NQ6 - 1u ? aph & 31u : x0) | 0x80808080u;
                 x1 |= 0x80808080u;
                 const uint64_t nx = (static_cast<uint64_t>(x1) << 32) | x0;
                 const uint32_t o0 = gp == 0u ? nb[0] : gp == 1u ? nb[2] : gp == 2u ? nb[4] : nb[6];
