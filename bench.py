@@ -474,11 +474,12 @@ def pool_leg(torch, M, L, wl, devices, link=None, nframes=240, reps=2):
         for dv in sorted(set(devs)):
             torch.cuda.synchronize(dv)
         frames = M.Context.make_frames(descs)
-        pool.decode_batch_device(frames)
+        for _ in range(12): # (a member's context first measures its XCD mapping on these buffers: not what a call costs)
+            pool.decode_batch_device(frames)
         t0 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(10):
             written, status = pool.decode_batch_device(frames)
-        t = (time.perf_counter() - t0) / 5
+        t = (time.perf_counter() - t0) / 10
         ok = all(s == 0 for s in status)
         got = tout[n - 1].cpu().numpy().view(np.uint16).reshape(wl.h, wl.w)
         ok = ok and np.array_equal(got, wl.pairs[(n - 1) % d][0])
