@@ -67,7 +67,7 @@ def parse():
                          "each get 4-5 %% longer, so the default stays 1)")
     ap.add_argument("--no-also", action="store_true", help="skip the second (other distribution) measurement")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-seconds", type=float, default=6.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work per cpu_baseline pass (all threads, then one thread)")
     a = ap.parse_args()
     cw, ch, cf = {3: (3840, 2160, 240), 5: (7680, 4320, 120)}[a.config]
     a.width = a.width or cw
