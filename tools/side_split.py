@@ -19,6 +19,9 @@ ctx.profile(True)
 shapes = [("8K nat x120", 7680, 4320, 12, 1, 12.0, 120), ("12MP u14 x16", 4032, 3024, 14, 0, 0.0, 16), ("12MP nat x16", 4032, 3024, 12, 1, 12.0, 16),
           ("UHD nat x1", 3840, 2160, 12, 1, 12.0, 1), ("UHD nat x32", 3840, 2160, 12, 1, 12.0, 32), ("UHD nat x120", 3840, 2160, 12, 1, 12.0, 120),
           ("UHD u12 x120", 3840, 2160, 12, 0, 0.0, 120)]
+if os.environ.get("SHAPE_EXTRA"):  # "name,w,h,bits,dist,sigma,frames"
+    e = os.environ["SHAPE_EXTRA"].split(",")
+    shapes.append((e[0], int(e[1]), int(e[2]), int(e[3]), int(e[4]), float(e[5]), int(e[6])))
 only = os.environ.get("SHAPES")
 for name, w, h, nb, dist, sig, n in shapes:
     if only and not any(o in name for o in only.split(",")):
