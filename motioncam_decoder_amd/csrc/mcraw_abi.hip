@@ -20,7 +20,7 @@
 #include "mcraw_plan.h"
 
 namespace mcraw {
-void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st);
+void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st, bool thin = false);
 void launch_k6_decode(const Plan6 *plans, const uint32_t *wg_tab, uint32_t stage0, uint32_t nwg, const Look6 &look,
                       uint32_t *tickets, uint32_t epoch, int nframes, uint32_t smax, const Post &post, hipStream_t st);
 } // namespace mcraw
@@ -77,6 +77,7 @@ struct Slot {
     Buf side_sync; // type-7 frames: what the parts of a side stream tell each other (k7_side); never cleared, epoch-tagged words
     hipEvent_t done = nullptr;
     hipEvent_t fork = nullptr, join = nullptr; // a batch that holds both encodings: its legacy kernel runs on the context's second stream
+    hipEvent_t side_done = nullptr; // k7_side of the batch, when it ran on the context's side stream
     ::mcraw_ticket *owner = nullptr; // host-memory batch whose statuses still sit in this slot's arena
     int owner_part = -1;
     hipEvent_t uploaded = nullptr; // host-memory pipeline: inputs of the sub-batch are in HBM
@@ -130,6 +131,15 @@ struct mcraw_ctx {
     Slot rslot;          // frames planned a second time (always drained before the call returns)
     hipStream_t aux = nullptr; // deferred second plans of batches whose caller stream is not known any more
     hipStream_t legacy = nullptr; // the legacy kernel of a batch that holds both encodings (beside the type-7 kernels)
+    // Batches that follow each other on the context's OWN stream (caller's stream NULL): k7_side is a chain per side stream
+    // (lib/RawData.cpp:463-498) that has to be done before the tile loop (:556-562 -> :571-608), a handful of latency-bound
+    // workgroups.  k7_side of batch n + 1 runs on `side` -- a stream of the lowest priority, a hardware queue of its own --
+    // while k7_tiles of batch n streams: as THIN workgroups (one wave per SIMD, 23 KB of LDS), which find room on a CU whenever
+    // one of the tile kernel's leaves (the fat ones, 57 KB and two waves per SIMD, starve until the tile kernel is through).
+    // `tmain`: only with a CU partition (MCRAW_SIDE_CUS > 0, an experiment).
+    hipStream_t side = nullptr, tmain = nullptr;
+    hipStream_t last_own = nullptr;  // which of the context's own streams the last own-stream batch went to
+    hipEvent_t chain = nullptr;      // orders two own-stream batches that went to different streams
     uint32_t profile = 0; // bit id: bracket launches of kernel id with events
     uint32_t profile_every = 1, profile_tick[MCRAW_K_COUNT] = {0}; // ... every n-th launch of it only
     Post post{0, 0, 0};   // fused post-decode stage of the batches to come (mcraw_ctx_set_post)
@@ -161,7 +171,7 @@ struct mcraw_ctx {
     // records), the refs stream of noise --, and the chip holds 512 workgroups of k7_side at a time.  Chosen like the XCD mapping:
     // the first launches of a geometry try each candidate twice between events, the fastest stays, one launch in 64 re-checks.
     struct SideTune {
-        static constexpr int MAXC = 6;
+        static constexpr int MAXC = 8;
         int key_n = 0;
         uint32_t key_R = 0;
         int nc = 0, cand[MAXC][2] = {{1, 1}};
@@ -388,7 +398,7 @@ int side_pick(mcraw_ctx *c, int n7, uint32_t R)
         // (512 workgroups of k7_side are resident at once; parts that own little leave early, so somewhat more can pay:
         // 120 x 8K frames ran fastest with 4 + 1 parts = 600 workgroups, tools/side_split.py)
         const int budget = 1024 / std::max(n7, 1);
-        static const int all[][2] = {{4, 4}, {4, 2}, {4, 1}, {2, 2}, {2, 4}, {3, 1}, {1, 3}};
+        static const int all[][2] = {{4, 4}, {4, 2}, {4, 1}, {2, 2}, {2, 4}, {3, 1}, {1, 3}, {1, 1}}; // (unsplit can win too)
         t.nc = 0;
         for (const auto &cd : all)
             if (cd[0] + cd[1] <= budget && t.nc < ST::MAXC)
@@ -426,7 +436,7 @@ int side_pick(mcraw_ctx *c, int n7, uint32_t R)
     }
     if (t.decided >= 0) {
         for (int k = 0; k < t.nc; k++)
-            if (t.best[k] < 0.97f * t.best[t.decided])
+            if (t.done[k] > 0 && t.best[k] < 0.97f * t.best[t.decided])
                 t.decided = k;
         t.launches++;
         if (t.launches % RECHECK != 0 || !t.pending.empty())
@@ -447,14 +457,21 @@ int side_pick(mcraw_ctx *c, int n7, uint32_t R)
     for (int k = 0; k < t.nc; k++)
         if (t.issued[k] < SAMPLES + 1 && (pick < 0 || t.issued[k] < t.issued[pick]))
             pick = k;
-    if (pick < 0)
+    if (pick < 0) {
+        if (t.pending.empty()) { // every sample is in or was lost (an event that could not be read): decide on what there is
+            t.decided = 0;
+            for (int k = 1; k < t.nc; k++)
+                if (t.done[k] && (!t.done[t.decided] || t.best[k] < t.best[t.decided]))
+                    t.decided = k;
+        }
         return -1;
+    }
     t.issued[pick]++;
     return pick;
 }
 
 int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::vector<Geom7> *geom_override,
-           const uint8_t *const *dev_in, uint16_t *const *dev_out, hipStream_t st, size_t *status_off)
+           const uint8_t *const *dev_in, uint16_t *const *dev_out, hipStream_t st, size_t *status_off, hipStream_t side_st = nullptr)
 {
     // ---- plan on the host -------------------------------------------------
     std::vector<int32_t> status(n, 0);
@@ -528,6 +545,10 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         }
     }
     const int n7 = static_cast<int>(B.p7.size()), n6 = static_cast<int>(B.p6.size());
+    // k7_side on the context's side stream (as thin workgroups that find room beside the tile kernel's), the rest of the batch on
+    // `st` behind an event
+    hipStream_t sst = side_st && n7 > 0 && s.side_done && !geom_override && !dev_in ? side_st : nullptr;
+    static const bool no_thin = std::getenv("MCRAW_SIDE_FAT") != nullptr; // timing experiment: the fat workgroups there too
 
     // Type-7 plans in order of decreasing size, cut into size classes: the unpack kernel is launched
     // once per class with that class's group count, so a batch that mixes small and large frames does
@@ -643,13 +664,13 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         if (need7 > s.side_sync.cap) {
             if (int rc = ensure(s.side_sync, need7, false))
                 return rc;
-            HIP_TRY(hipMemsetAsync(s.side_sync.p, 0, s.side_sync.cap, st));
+            HIP_TRY(hipMemsetAsync(s.side_sync.p, 0, s.side_sync.cap, sst ? sst : st));
         }
         if (++s.look_epoch == 0u) { // (2^32 batches later: start over)
             if (s.look.p)
                 HIP_TRY(hipMemsetAsync(s.look.p, 0, s.look.cap, st));
             if (s.side_sync.p)
-                HIP_TRY(hipMemsetAsync(s.side_sync.p, 0, s.side_sync.cap, st));
+                HIP_TRY(hipMemsetAsync(s.side_sync.p, 0, s.side_sync.cap, sst ? sst : st));
             s.look_epoch = 1;
         }
     }
@@ -740,22 +761,27 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         for (uint32_t stage : {MCRAW_K7_SIDE, MCRAW_K7_TILES}) {
             hipEvent_t ta = nullptr, tb = nullptr;
             const bool time_side = stage == MCRAW_K7_SIDE && side_cand >= 0;
+            hipStream_t kst = stage == MCRAW_K7_SIDE && sst ? sst : st; // (the side stream's kernels follow each other on it)
             if ((stage == MCRAW_K7_TILES && tune_cand >= 0) || time_side) {
                 ta = get_event(c);
                 tb = get_event(c);
                 if (ta && tb)
-                    (void)hipEventRecord(ta, st);
+                    (void)hipEventRecord(ta, kst);
             }
             {
-                KTimer t(c, static_cast<int>(stage), st);
-                launch_k7(W, stage, st);
+                KTimer t(c, static_cast<int>(stage), kst);
+                launch_k7(W, stage, kst, stage == MCRAW_K7_SIDE && sst != nullptr && !no_thin);
             }
             if (ta && tb) {
-                (void)hipEventRecord(tb, st);
+                (void)hipEventRecord(tb, kst);
                 if (time_side)
                     c->side_tunes[c->side_last].pending.push_back({ta, tb, side_cand});
                 else
                     c->tunes[c->tune_last].pending.push_back({ta, tb, tune_cand});
+            }
+            if (stage == MCRAW_K7_SIDE && sst) { // the tile kernel needs what k7_side leaves in the slot's workspace
+                HIP_TRY(hipEventRecord(s.side_done, sst));
+                HIP_TRY(hipStreamWaitEvent(st, s.side_done, 0));
             }
         }
     }
@@ -947,13 +973,41 @@ int resolve_device(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, hipS
 // Decode a batch whose buffers are in HBM.  With `written` / `status_out` the call synchronises and
 // resolves everything; without, frames that need a second plan get it in mcraw_ctx_synchronize (or when
 // the slot comes round again).
-int decode_device(mcraw_ctx *c, const mcraw_frame *frames, int n, hipStream_t st, size_t *written, int32_t *status_out)
+int decode_device(mcraw_ctx *c, const mcraw_frame *frames, int n, hipStream_t user, size_t *written, int32_t *status_out)
 {
+    // The batch in flight before this one (if any): is it still running?  Asked BEFORE acquire_slot may wait for an older one.
+    bool busy_before = false;
+    if (!user && c->side && c->last_slot >= 0 && c->dslots[c->last_slot].busy) {
+        busy_before = hipEventQuery(c->dslots[c->last_slot].done) == hipErrorNotReady;
+        (void)hipGetLastError();
+    }
     Slot *sp = nullptr;
     if (int rc = acquire_slot(c, &sp, true))
         return rc;
     Slot &s = *sp;
-    if (int rc = submit(c, s, frames, n, nullptr, nullptr, nullptr, st, &s.status_off))
+    hipStream_t st = user, side_st = nullptr;
+    if (!user) {
+        // The context's own stream: nothing of the caller's can be ordered against it except through the host, so the frames'
+        // inputs are complete now -- k7_side of this batch may start while the batch in front of it is still unpacking.  It
+        // goes to the side stream when it has that company to hide behind; alone on an idle chip its chains are done sooner
+        // in line with the tile kernel, as fat workgroups.
+        st = c->stream;
+        if (c->side && busy_before)
+            side_st = c->side;
+        if (c->tmain) { // (CU partition, an experiment: batches of the current encoding alone leave k7_side's CUs alone)
+            bool all7 = true;
+            for (int i = 0; i < n && all7; i++)
+                all7 = frames[i].type == MCRAW_TYPE_BLOCK;
+            if (all7)
+                st = c->tmain;
+            if (c->last_own && c->last_own != st) { // (the two streams take turns only when the kind of batch changes)
+                HIP_TRY(hipEventRecord(c->chain, c->last_own));
+                HIP_TRY(hipStreamWaitEvent(st, c->chain, 0));
+            }
+            c->last_own = st;
+        }
+    }
+    if (int rc = submit(c, s, frames, n, nullptr, nullptr, nullptr, st, &s.status_off, side_st))
         return rc;
     HIP_TRY(hipEventRecord(s.done, st));
     s.busy = true;
@@ -1345,6 +1399,50 @@ int mcraw_ctx_create(int device, mcraw_ctx **out)
     HIP_TRY(hipStreamCreateWithFlags(&c->h2d, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->d2h, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->legacy, hipStreamNonBlocking));
+    {
+        // k7_side of the next batch beside the tile kernel of the one in flight (see mcraw_ctx::side).  MCRAW_SIDE_CUS: -1 (default)
+        // a stream of the LOWEST priority -- a queue of its own (streams of one priority share four hardware queues, and two
+        // kernels in one queue never overlap), whose workgroups take what the tile kernel's leave; 0: off, every kernel of a batch
+        // on one stream; r > 0 (experiment, docs/lab_notes.md): r CUs of every XCD for k7_side alone and the rest for the other
+        // kernels, as CU masks of two streams -- a queue's CU mask is dealt bit by bit to the XCDs (bit i: XCD i mod 8, then
+        // shader engine by shader engine), so the low 8 r bits are r CUs of every XCD.
+        int per_xcd = -1;
+        if (const char *e = std::getenv("MCRAW_SIDE_CUS"))
+            per_xcd = std::atoi(e);
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        const int ncu = prop.multiProcessorCount, nxcd = 8;
+        if (per_xcd < 0) {
+            int lo = 0, hi = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            int ps = lo, pt = (lo + hi) / 2;
+            if (const char *e = std::getenv("MCRAW_SIDE_PRIO")) // experiment: "s,t" = priorities of the side stream and of the other one
+                (void)std::sscanf(e, "%d,%d", &ps, &pt);
+            HIP_TRY(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, ps));
+            // (the context's own stream is created again, beside it: as the stream it was, the first of the context's twenty-odd,
+            // the tile kernel ran 8 % longer with k7_side beside it and k7_side did not hide -- tools/ab_env.sh, docs/lab_notes.md)
+            hipStream_t own = nullptr;
+            HIP_TRY(hipStreamCreateWithPriority(&own, hipStreamNonBlocking, pt));
+            (void)hipStreamDestroy(c->stream);
+            c->stream = own;
+        } else if (per_xcd > 0 && ncu % 32 == 0 && per_xcd * nxcd * 2 <= ncu) {
+            const int words = ncu / 32, r = per_xcd * nxcd;
+            std::vector<uint32_t> ms(words, 0u), mt(words, 0xffffffffu);
+            for (int b = 0; b < r; b++) {
+                ms[b / 32] |= 1u << (b % 32);
+                mt[b / 32] &= ~(1u << (b % 32));
+            }
+            hipError_t e1 = hipExtStreamCreateWithCUMask(&c->side, static_cast<uint32_t>(words), ms.data());
+            hipError_t e2 = e1 == hipSuccess ? hipExtStreamCreateWithCUMask(&c->tmain, static_cast<uint32_t>(words), mt.data()) : e1;
+            if (e1 != hipSuccess || e2 != hipSuccess) { // no partition on this runtime: everything on the one stream
+                (void)hipGetLastError();
+                if (c->side)
+                    (void)hipStreamDestroy(c->side);
+                c->side = c->tmain = nullptr;
+            } else
+                HIP_TRY(hipEventCreateWithFlags(&c->chain, hipEventDisableTiming));
+        }
+    }
     for (Slot *sp : {&c->rslot}) {
         HIP_TRY(hipEventCreateWithFlags(&sp->fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&sp->join, hipEventDisableTiming));
@@ -1358,6 +1456,7 @@ int mcraw_ctx_create(int device, mcraw_ctx **out)
         HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     }
     for (Slot &s : c->dslots) {
+        HIP_TRY(hipEventCreateWithFlags(&s.side_done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
@@ -1384,6 +1483,7 @@ void mcraw_ctx_destroy(mcraw_ctx *c)
         if (s.done) (void)hipEventDestroy(s.done);
         if (s.fork) (void)hipEventDestroy(s.fork);
         if (s.join) (void)hipEventDestroy(s.join);
+        if (s.side_done) (void)hipEventDestroy(s.side_done);
         if (s.uploaded) (void)hipEventDestroy(s.uploaded);
         if (s.decoded) (void)hipEventDestroy(s.decoded);
         if (s.stream) (void)hipStreamDestroy(s.stream);
@@ -1403,8 +1503,19 @@ void mcraw_ctx_destroy(mcraw_ctx *c)
             (void)hipEventDestroy(p.a);
             (void)hipEventDestroy(p.b);
         }
+    for (auto &t : c->side_tunes)
+        for (auto &p : t.pending) {
+            (void)hipEventDestroy(p.a);
+            (void)hipEventDestroy(p.b);
+        }
     for (hipEvent_t e : c->event_pool)
         (void)hipEventDestroy(e);
+    if (c->chain)
+        (void)hipEventDestroy(c->chain);
+    if (c->side)
+        (void)hipStreamDestroy(c->side);
+    if (c->tmain)
+        (void)hipStreamDestroy(c->tmain);
     if (c->stream)
         (void)hipStreamDestroy(c->stream);
     if (c->aux)
@@ -1430,7 +1541,7 @@ int mcraw_decode_batch(mcraw_ctx *c, const mcraw_frame *frames, int nframes, int
     std::lock_guard<std::mutex> lk(c->mu);
     HIP_TRY(hipSetDevice(c->device));
     if (mem == MCRAW_MEM_DEVICE)
-        return decode_device(c, frames, nframes, stream ? static_cast<hipStream_t>(stream) : c->stream, written, status);
+        return decode_device(c, frames, nframes, static_cast<hipStream_t>(stream), written, status);
     if (mem == MCRAW_MEM_HOST)
         return decode_host(c, frames, nframes, written, status);
     g_err = "mcraw_decode_batch: unknown memory kind";

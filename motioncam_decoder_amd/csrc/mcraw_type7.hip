@@ -160,19 +160,34 @@ __device__ __forceinline__ Unpacked unpack8(const uint8_t *__restrict__ base, ui
 #ifndef MCRAW_SIDE_T
 #define MCRAW_SIDE_T 512
 #endif
-constexpr uint32_t SIDE_T = MCRAW_SIDE_T;                   // threads per workgroup
 #ifndef MCRAW_SIDE_LPT
 #define MCRAW_SIDE_LPT 4
 #endif
 #ifndef MCRAW_SIDE_LCAP
 #define MCRAW_SIDE_LCAP 512
 #endif
-constexpr uint32_t SIDE_LPT = MCRAW_SIDE_LPT;               // 16-byte lines per thread and piece
-constexpr uint32_t SIDE_PIECE = 16 * SIDE_T * SIDE_LPT;     // stream bytes per piece
-constexpr uint32_t SIDE_HALF = SIDE_PIECE / 2;              // candidate positions per piece (2 bytes apart)
+#ifndef MCRAW_SPEC_WARM
+#define MCRAW_SPEC_WARM 8192
+#endif
+// The kernel comes in two sizes (template parameters: threads per workgroup, 16-byte lines per thread and piece, records per
+// UNIT of the walk / decode pipeline, candidates in front of its pieces at which a speculative count starts):
+//   fat   512 threads, pieces of 32 KiB, 57 KB of LDS: the shortest chain -- what a batch runs when nothing else is on the chip;
+//   thin  256 threads, pieces of 12 KiB, 23 KB of LDS, one wave per SIMD: the footprint that fits beside the tile kernel's
+//         workgroups (a CU full of them has 10 KB of LDS and 192 VGPRs per SIMD to spare; one of them leaving makes room for
+//         one of these) -- what a batch runs whose k7_side hides behind the tile kernel of the batch in front (mcraw_abi.hip).
+#ifndef MCRAW_THIN_T
+#define MCRAW_THIN_T 256
+#endif
+#ifndef MCRAW_THIN_LPT
+#define MCRAW_THIN_LPT 3
+#endif
+#ifndef MCRAW_THIN_LCAP
+#define MCRAW_THIN_LCAP 256
+#endif
+#ifndef MCRAW_THIN_WARM
+#define MCRAW_THIN_WARM 4096
+#endif
 constexpr uint32_t SIDE_XL = 9;                             // lines behind the piece: 130 (reach of its last record) + 8 (read slack) bytes
-constexpr uint32_t SIDE_BYTES = SIDE_PIECE + SIDE_XL * 16 + 16;
-constexpr uint32_t SIDE_LCAP = MCRAW_SIDE_LCAP;              // records per UNIT of the walk / decode pipeline
 constexpr uint32_t SIDE_OUT = 0xFFu;                        // stride table: "behind the piece"
 constexpr uint32_t SIDE_DEAD = 0xFEu;                       // stride table: a record here would cross `len`
 static_assert(ITEM_SPLIT == 2, "k7_side sums the block lengths of half a record per item");
@@ -227,8 +242,12 @@ __device__ unsigned long long g_side_prof[2][256];
 #define SIDE_STAMP(slot)
 #endif
 
+template <uint32_t SIDE_T, uint32_t SIDE_LPT, uint32_t SIDE_LCAP, uint32_t SPEC_WARM>
 __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) void k7_side(const Work7 W)
 {
+    constexpr uint32_t SIDE_PIECE = 16 * SIDE_T * SIDE_LPT;     // stream bytes per piece
+    constexpr uint32_t SIDE_HALF = SIDE_PIECE / 2;              // candidate positions per piece (2 bytes apart)
+    constexpr uint32_t SIDE_BYTES = SIDE_PIECE + SIDE_XL * 16 + 16;
     __shared__ __attribute__((aligned(16))) uint8_t s_b[SIDE_BYTES];       // bytes of the piece the decoders work on
     __shared__ __attribute__((aligned(16))) uint8_t s_T[SIDE_HALF + 80];   // strides of the piece the walker is in; [SIDE_HALF ..] = SIDE_OUT (the reach of a record)
     __shared__ __attribute__((aligned(16))) uint16_t s_L[2][SIDE_LCAP];
@@ -257,6 +276,10 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     //            one whose predecessor never speaks (workgroups started out of order and the chip is full) follows the chain
     //            from the stream's first record by itself.  Payload offsets are relative to the part's first item; k7_tiles adds
     //            the totals of the parts in front (Frame7::part_item, part_len).
+#ifdef MCRAW_THIN_PRIO
+    if (SIDE_T <= 256u) // the thin workgroups run beside the tile kernel's: their chain of dependent steps goes first at issue
+        __builtin_amdgcn_s_setprio(MCRAW_THIN_PRIO);
+#endif
     const uint32_t nfr = static_cast<uint32_t>(W.n7), nsb = W.nsplit[0], nsr = W.nsplit[1];
     const uint32_t bq = blockIdx.x / nfr, f = blockIdx.x - bq * nfr;
     const uint32_t s = bq < nsr ? 1u : 0u, part = s ? bq : bq - nsr, nsp = s ? nsr : nsb; // (the longer stream's parts first)
@@ -385,14 +408,10 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     bool dead = false;                     // uniform: the chain ended before R records
     uint32_t decode_from = 0u;             // units of pieces in front of this one are walked, not decoded
     constexpr uint32_t NOENTRY = 0xFFFFFFFEu;
-#ifndef MCRAW_SPEC_WARM
-#define MCRAW_SPEC_WARM 8192
-#endif
     // candidates (2 bytes each) in front of its pieces at which a speculative count starts.  Half a piece: with 2 KiB (what the
     // segment walkers start with) enough counts of four-part streams arrived on a wrong chain -- and then decode from what the
     // part in front says, one part after the other -- that four parts were slower than two (tools/side_warm2.sh: 16 x 12 MP
     // natural frames 110 -> 85 us, 14-bit noise 205 -> 162 us with 16 KiB)
-    constexpr uint32_t SPEC_WARM = MCRAW_SPEC_WARM;
     static_assert(SPEC_WARM <= SIDE_HALF, "a speculative count starts inside the piece in front of the part's first");
 
     // registers -> bytes of a piece (what the decoders read)
@@ -1255,12 +1274,17 @@ extern "C" uint32_t mcraw_tile_order(uint32_t b, uint32_t n, uint32_t runs)
     return runs ? xcd_chunked(b, n, runs) : xcd_remap(b, n);
 }
 
-void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st)
+void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st, bool thin)
 {
     const uint32_t n7 = static_cast<uint32_t>(W.n7);
     switch (stage) {
     case MCRAW_K7_SIDE:
-        hipLaunchKernelGGL(k7_side, dim3(n7 * (W.nsplit[0] + W.nsplit[1])), dim3(SIDE_T), 0, st, W);
+        if (thin)
+            hipLaunchKernelGGL((k7_side<MCRAW_THIN_T, MCRAW_THIN_LPT, MCRAW_THIN_LCAP, MCRAW_THIN_WARM>), dim3(n7 * (W.nsplit[0] + W.nsplit[1])),
+                               dim3(MCRAW_THIN_T), 0, st, W);
+        else
+            hipLaunchKernelGGL((k7_side<MCRAW_SIDE_T, MCRAW_SIDE_LPT, MCRAW_SIDE_LCAP, MCRAW_SPEC_WARM>), dim3(n7 * (W.nsplit[0] + W.nsplit[1])),
+                               dim3(MCRAW_SIDE_T), 0, st, W);
         break;
     case MCRAW_K7_TILES: {
 #ifdef MCRAW_DIAG // timing experiments of the same kernel (see item_decode); not in the product library
