@@ -22,8 +22,11 @@ Prints ONE JSON line on rank 0 (see the keys at the bottom).
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
+import math
 import os
+import struct
 import subprocess
 import sys
 import time
@@ -98,7 +101,14 @@ class Workload:
         frame g is generated from seed 1000 * 3 + g (config 3 of SURVEY 8d)."""
         self.w, self.h = args.width, args.height
         self.frames = args.frames
-        seeds = [1000 * args.config + g for g in gidx[: min(args.distinct, args.frames)]]
+        # What a frame holds depends on its GLOBAL index alone -- frame g is image (g mod distinct) -- so that the per-frame
+        # checksums of a job do not depend on how many ranks share it.  Local frame i is global frame rank + i * world; the
+        # images a rank needs repeat with period d = distinct / gcd(world, distinct): pairs[i % d] is local frame i's.
+        D = max(1, args.distinct)
+        stride_g = (gidx[1] - gidx[0]) if len(gidx) > 1 else 1
+        d = max(1, min(D // math.gcd(stride_g, D), self.frames))
+        self.gidx = list(gidx[: self.frames])
+        seeds = [1000 * args.config + (g % D) for g in gidx[:d]]
         self.pairs = make_frames(L, seeds, self.w, self.h, args.nbits, dist, args.sigma)
         lens = [p[1].size for p in self.pairs]
         d = len(self.pairs)
@@ -140,6 +150,28 @@ class Workload:
             if not np.array_equal(got.reshape(self.h, self.w), self.pairs[i % d][0]):
                 return False
         return True
+
+
+def buffer_checksum(torch, t, wgt_cache={}):
+    """32-bit position-weighted checksum of one decoded frame (a uint8 tensor on a GPU), computed there."""
+    n32 = t.numel() // 4
+    key = (str(t.device), n32)
+    if key not in wgt_cache:
+        wgt_cache.clear()
+        wgt_cache[key] = (torch.arange(n32, device=t.device, dtype=torch.int64) % 65521) + 1
+    return int((t[: n32 * 4].view(torch.int32).to(torch.int64) * wgt_cache[key]).sum().item()) & 0xFFFFFFFF
+
+
+def frame_checksums(torch, comm, wl, nglobal):
+    """32-bit checksums of the decoded global frames 0 .. nglobal - 1 of the job (every rank sums the ones it holds, on its GPU;
+    one SUM all-reduce merges the slots) and a digest over them: equal at every rank count, since frame g's content depends on g
+    alone (Workload) and its pixels on nothing but its bytes (lib/RawData.cpp:528-612 is a pure function of one buffer)."""
+    slots = [0.0] * nglobal
+    for i, g in enumerate(wl.gidx):
+        if g < nglobal:
+            slots[g] = float(buffer_checksum(torch, wl.t_out[i * wl.out_stride:(i + 1) * wl.out_stride]))
+    vals = [int(v) for v in comm.sum(slots)]
+    return vals, hashlib.sha1(struct.pack("<%dI" % len(vals), *vals)).hexdigest()[:16]
 
 
 def run_timed(torch, comm, ctx, M, wl, args):
@@ -483,8 +515,11 @@ def pool_leg(torch, M, L, wl, devices, link=None, nframes=240, reps=2):
         ok = all(s == 0 for s in status)
         got = tout[n - 1].cpu().numpy().view(np.uint16).reshape(wl.h, wl.w)
         ok = ok and np.array_equal(got, wl.pairs[(n - 1) % d][0])
+        # every frame against what ONE context on ONE GPU made of it (the bench line's buffers): per-frame checksums
+        same = sum(1 for i in range(n) if buffer_checksum(torch, tout[i]) == buffer_checksum(torch, wl.t_out[i * wl.out_stride:(i + 1) * wl.out_stride]))
         res["resident"] = {"frames": n, "ms_per_batch": round(t * 1e3, 4), "frames_per_s": round(n / t, 1),
                            "mpix_s": round(n * wl.w * wl.h / t / 1e6, 1), "bit_exact": bool(ok),
+                           "frames_equal_to_single_gpu_decode": same,
                            "note": "synchronous call: host hand-off, kernels and status read-back of every member"}
         # the same batches queued back to back (no status asked for), one mcraw_pool_synchronize behind them
         for _ in range(8):
@@ -707,6 +742,10 @@ def stub_main(args):
     if "RANK" in os.environ and "MASTER_ADDR" in os.environ:
         dist_mod.init_process_group("gloo")
     comm = benchlib.Comm(dist_mod, "cpu")
+    ranks_seen = int(round(comm.sum([1.0])[0]))
+    if ranks_seen != args.gpus:
+        print("bench.py: %d rank(s) took part, --gpus %d" % (ranks_seen, args.gpus), file=sys.stderr)
+        return 2
     mine = shard.shard_frames(world * args.frames, rank, world)
     assert len(mine) == args.frames
     per_step = 0.002 * (1 + rank)  # the slower rank sets the job's time
@@ -716,7 +755,7 @@ def stub_main(args):
         st = benchlib.round_stats(times, args.steps)
         pixels = world * args.frames * args.width * args.height
         print(json.dumps({"metric": METRIC, "value": round(pixels / (st["median"] * 1e-3) / 1e6, 1), "unit": "MPixels/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(st["median"], 4),
+                          "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(st["median"], 4),
                           "ms_per_step_min": round(st["min"], 4), "ms_per_step_max": round(st["max"], 4), "rounds": st["rounds"],
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16",
                           "data": "stub: no decode (CPU rehearsal of the multi-rank protocol)", "bit_exact": ok,
@@ -729,8 +768,44 @@ def stub_main(args):
 METRIC = "MPixels/s unpacked + achieved HBM GB/s %peak, 4K 12-bit, 1/2/4/8 GPUs"
 
 
+def visible_gpus():
+    """GPUs this process could use, counted WITHOUT touching HIP (sysfs: AMD render nodes, HIP_VISIBLE_DEVICES honoured)."""
+    from motioncam_decoder_amd import benchlib
+    n = len(benchlib.gpu_pci_devices())
+    vis = benchlib._visible_ordinals()
+    return n if vis is None else min(n, len(vis)) if n else len(vis)
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no RANK in the environment: this process starts the N ranks itself, the way the
+    driver does (torch.distributed.run, one process per GPU), as a CHILD process -- it never touches HIP and never exec()s --,
+    relays their output (rank 0's JSON line) and returns their exit code.  An N-GPU request never prints a 1-GPU line."""
+    need = 1 if (args.all_on_device0 or args.stub_decode) else args.gpus
+    have = visible_gpus()
+    if not args.stub_decode and have < need:
+        print("bench.py: --gpus %d asked for, %d GPU(s) visible here: refusing to measure fewer GPUs than requested "
+              "(use --all-on-device0 --dist-backend gloo to rehearse the multi-rank path on one GPU)" % (args.gpus, have), file=sys.stderr)
+        return 3
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    world_env = int(os.environ.get("WORLD_SIZE", "1")) if "RANK" in os.environ else None
+    if world_env is None and args.gpus > 1:
+        return spawn_ranks(args)
+    if world_env is not None and world_env != args.gpus:
+        print("bench.py: launched with WORLD_SIZE=%d but --gpus %d: the two must agree" % (world_env, args.gpus), file=sys.stderr)
+        return 2
     if args.stub_decode:
         return stub_main(args)
     rank = int(os.environ.get("RANK", "0"))
@@ -744,6 +819,10 @@ def main():
     import torch
     import torch.distributed as dist_mod
 
+    if not args.all_on_device0 and torch.cuda.device_count() < max(world, local + 1):  # (counting devices does not initialise HIP)
+        print("bench.py: rank %d of %d needs cuda:%d, %d GPU(s) visible: refusing to measure fewer GPUs than requested" % (
+            rank, world, local, torch.cuda.device_count()), file=sys.stderr)
+        return 3
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -754,6 +833,10 @@ def main():
         else:
             dist_mod.init_process_group(args.dist_backend)
     comm = benchlib.Comm(dist_mod, dev if args.dist_backend == "nccl" else "cpu")
+    ranks_seen = int(round(comm.sum([1.0])[0]))  # every rank that takes part says so: the line's n_gpus is counted, not assumed
+    if ranks_seen != args.gpus:
+        print("bench.py: %d rank(s) took part, --gpus %d" % (ranks_seen, args.gpus), file=sys.stderr)
+        return 2
 
     import motioncam_decoder_amd as M
     from motioncam_decoder_amd import build as B
@@ -778,6 +861,12 @@ def main():
 
     wl = results[args.dist]["wl"]
     extra = {}
+    sums, digest = frame_checksums(torch, comm, wl, args.frames)
+    # which GPU every rank decoded on (PCI bus of its device), gathered like the checksums
+    prop = torch.cuda.get_device_properties(local)
+    code = float((getattr(prop, "pci_domain_id", 0) << 16) | (getattr(prop, "pci_bus_id", 0) << 8) | getattr(prop, "pci_device_id", 0))
+    codes = [int(v) for v in comm.sum([code if r == rank else 0.0 for r in range(world)])]
+    devices_seen = ["%04x:%02x:%02x" % (c >> 16, (c >> 8) & 0xff, c & 0xff) for c in codes]
     if not args.no_pcie and not args.no_cpu:
         # the host-buffer legs run on EVERY rank at once: what limits a node is its PCIe links and the host
         # memory feeding them, not the HBM-resident kernels
@@ -838,6 +927,8 @@ def main():
             "value": round(s["mpix_s"], 1),
             "unit": "MPixels/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
+            "devices": devices_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(s["st"]["median"], 4),
@@ -851,6 +942,11 @@ def main():
             "data": "synthetic: %d seeded distinct frames per rank (own encoder), replicated to %d frames at distinct "
                     "HBM addresses; inputs resident in HBM before the timed region" % (len(wl.pairs), args.frames),
             "bit_exact": results[args.dist]["ok"],
+            "frame_checksums": {"frames": len(sums), "digest": digest, "first": sums[:4],
+                                "note": "32-bit checksums of the decoded global frames 0..%d of the job (frame g = image g mod %d, decoded by "
+                                        "rank g mod n_gpus), gathered over the ranks; sha1 digest over them: the same at every --gpus N"
+                                        % (len(sums) - 1, args.distinct)},
+            "distinct_devices": len(set(devices_seen)),
             "bit_exact_scope": "sanity flag: sampled output frames of the timed buffers equal the images the encoder was given; "
                                "parity against the oracle / reference is what tests/ -m gpu checks",
             "frames_per_s": round(world * args.frames / (s["st"]["median"] * 1e-3), 1),
@@ -928,4 +1024,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

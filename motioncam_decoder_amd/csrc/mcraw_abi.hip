@@ -131,12 +131,12 @@ struct mcraw_ctx {
     Slot rslot;          // frames planned a second time (always drained before the call returns)
     hipStream_t aux = nullptr; // deferred second plans of batches whose caller stream is not known any more
     hipStream_t legacy = nullptr; // the legacy kernel of a batch that holds both encodings (beside the type-7 kernels)
-    // Batches that follow each other on the context's OWN stream (caller's stream NULL): k7_side is a chain per side stream
-    // (lib/RawData.cpp:463-498) that has to be done before the tile loop (:556-562 -> :571-608), a handful of latency-bound
-    // workgroups.  k7_side of batch n + 1 runs on `side` -- a stream of the lowest priority, a hardware queue of its own --
-    // while k7_tiles of batch n streams: as THIN workgroups (one wave per SIMD, 23 KB of LDS), which find room on a CU whenever
-    // one of the tile kernel's leaves (the fat ones, 57 KB and two waves per SIMD, starve until the tile kernel is through).
-    // `tmain`: only with a CU partition (MCRAW_SIDE_CUS > 0, an experiment).
+    // EXPERIMENT (off by default, MCRAW_SIDE_CUS; see mcraw_ctx_create).  Batches that follow each other on the context's OWN
+    // stream (caller's stream NULL): k7_side is a chain per side stream (lib/RawData.cpp:463-498) that has to be done before the
+    // tile loop (:556-562 -> :571-608), a handful of latency-bound workgroups.  k7_side of batch n + 1 can run on `side` -- a
+    // stream of the lowest priority, a hardware queue of its own -- while k7_tiles of batch n streams: as THIN workgroups (one
+    // wave per SIMD, 23 KB of LDS), which find room on a CU whenever one of the tile kernel's leaves (the fat ones, 57 KB and two
+    // waves per SIMD, starve until the tile kernel is through).  `tmain`: only with a CU partition (MCRAW_SIDE_CUS > 0).
     hipStream_t side = nullptr, tmain = nullptr;
     hipStream_t last_own = nullptr;  // which of the context's own streams the last own-stream batch went to
     hipEvent_t chain = nullptr;      // orders two own-stream batches that went to different streams
@@ -549,6 +549,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     // `st` behind an event
     hipStream_t sst = side_st && n7 > 0 && s.side_done && !geom_override && !dev_in ? side_st : nullptr;
     static const bool no_thin = std::getenv("MCRAW_SIDE_FAT") != nullptr; // timing experiment: the fat workgroups there too
+    static const bool all_thin = std::getenv("MCRAW_SIDE_THIN") != nullptr; // tests: every k7_side launch as thin workgroups
 
     // Type-7 plans in order of decreasing size, cut into size classes: the unpack kernel is launched
     // once per class with that class's group count, so a batch that mixes small and large frames does
@@ -770,7 +771,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
             }
             {
                 KTimer t(c, static_cast<int>(stage), kst);
-                launch_k7(W, stage, kst, stage == MCRAW_K7_SIDE && sst != nullptr && !no_thin);
+                launch_k7(W, stage, kst, stage == MCRAW_K7_SIDE && (all_thin || (sst != nullptr && !no_thin)));
             }
             if (ta && tb) {
                 (void)hipEventRecord(tb, kst);
@@ -1400,13 +1401,17 @@ int mcraw_ctx_create(int device, mcraw_ctx **out)
     HIP_TRY(hipStreamCreateWithFlags(&c->d2h, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&c->legacy, hipStreamNonBlocking));
     {
-        // k7_side of the next batch beside the tile kernel of the one in flight (see mcraw_ctx::side).  MCRAW_SIDE_CUS: -1 (default)
-        // a stream of the LOWEST priority -- a queue of its own (streams of one priority share four hardware queues, and two
-        // kernels in one queue never overlap), whose workgroups take what the tile kernel's leave; 0: off, every kernel of a batch
-        // on one stream; r > 0 (experiment, docs/lab_notes.md): r CUs of every XCD for k7_side alone and the rest for the other
-        // kernels, as CU masks of two streams -- a queue's CU mask is dealt bit by bit to the XCDs (bit i: XCD i mod 8, then
-        // shader engine by shader engine), so the low 8 r bits are r CUs of every XCD.
-        int per_xcd = -1;
+        // k7_side of the next batch beside the tile kernel of the one in flight (see mcraw_ctx::side): MEASURED, NOT SHIPPED --
+        // off unless MCRAW_SIDE_CUS says otherwise (docs/lab_notes.md, round 5, has the tables):
+        //   -1   a side stream of the LOWEST priority -- a hardware queue of its own: streams of one priority share four queues,
+        //        and two kernels in one queue never overlap -- on which k7_side runs as thin workgroups.  It hides (the step is
+        //        the tile kernel + 10-16 us instead of + 57 us), and the tile kernel pays for it: k7_side's 480 thin workgroups
+        //        hold a quarter of the chip's wave slots for 0.2 ms, the tile kernel runs 3-5 % longer, the step is where it was;
+        //   r>0  r CUs of every XCD for k7_side alone and the rest for the other kernels, as CU masks of two streams (a queue's CU
+        //        mask is dealt bit by bit to the XCDs: bit i is XCD i mod 8, then shader engine by shader engine, so the low 8 r
+        //        bits are r CUs of every XCD).  k7_side hides completely -- and the tile kernel, which runs at the CUs' memory
+        //        pipelines' rate, loses more than its share: +4.6 / +9 / +9 / +8 / +16 % with 8 / 16 / 24 / 32 / 48 CUs away.
+        int per_xcd = 0;
         if (const char *e = std::getenv("MCRAW_SIDE_CUS"))
             per_xcd = std::atoi(e);
         hipDeviceProp_t prop;

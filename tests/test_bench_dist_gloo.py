@@ -32,7 +32,7 @@ def test_bench_protocol_world2_gloo():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout          # rank 0 alone prints, once
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["rounds"] >= 2                   # 3 steps of 4 ms: several rounds to cover 0.1 s
     # the slower rank (4 ms per step) sets the time; the faster one (2 ms) does not
     # (upper bound generous: sleeps overshoot on a loaded host -- the build may still be running beside the tests)
@@ -40,6 +40,36 @@ def test_bench_protocol_world2_gloo():
     assert d["bit_exact"] is True
     px = 2 * 5 * 3840 * 2160
     assert abs(d["value"] - px / (d["ms_per_step"] * 1e-3) / 1e6) < 1.0   # whole-job rate over both ranks
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no RANK in the environment: the parent (which never touches HIP) starts two ranks as a
+    child process and relays rank 0's line -- an N-GPU request never comes back as a one-rank measurement."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--stub-decode",
+           "--min-seconds", "0.02", "--frames", "3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2
+
+
+def test_bench_refuses_to_measure_fewer_gpus_than_asked_for():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    from motioncam_decoder_amd import benchlib as bl
+    have = len(bl.gpu_pci_devices())
+    # more GPUs than the machine has (none in the CPU container): no line, a message, a non-zero exit code
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 2), "--steps", "1"], capture_output=True,
+                       text=True, timeout=120, cwd=ROOT, env=env)
+    assert r.returncode != 0 and "refusing" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    # a launcher whose world size disagrees with --gpus
+    env2 = dict(env, RANK="0", WORLD_SIZE="4", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub-decode", "--steps", "1"], capture_output=True,
+                       text=True, timeout=120, cwd=ROOT, env=env2)
+    assert r.returncode != 0 and "must agree" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
 
 def test_timed_rounds_single_process():

@@ -153,23 +153,29 @@ def test_bench_multi_rank_path_on_one_gpu(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    # `bench.py --gpus 2` starts its two ranks itself (a child process: torch.distributed.run); the line says how many took part
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--frames", "24", "--distinct", "4", "--min-seconds", "0.05", "--dist-backend", "gloo", "--all-on-device0",
            "--cpu-seconds", "0.2"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["bit_exact"] is True and d["scaling"] == "weak"
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["bit_exact"] is True and d["scaling"] == "weak"
+    assert d["distinct_devices"] == 1 and len(d["devices"]) == 2  # (both ranks on cuda:0 here, and the line says so)
     assert d["config"]["frames_per_gpu"] == 24
     assert abs(d["value"] / (2 * 24 * 3840 * 2160 / (d["ms_per_step"] * 1e-3) / 1e6) - 1.0) < 2e-3  # (ms_per_step is rounded)
     assert d["roofline"]["step_frac"] > 0 and d["roofline"]["frac"] > 0
+    # the job's first 24 frames decode to the same pixels whether one rank holds them all or two share them
+    r1 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--frames", "24",
+                         "--distinct", "4", "--min-seconds", "0.02", "--no-pcie", "--no-cpu", "--no-also"], capture_output=True, text=True,
+                        timeout=600, cwd=root, env=env)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    d1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][0])
+    assert d1["n_gpus"] == 1 and d1["ranks_seen"] == 1
+    assert d1["frame_checksums"]["frames"] == 24 and d1["frame_checksums"] == d["frame_checksums"]
     p = d["pcie_inclusive"]
     assert p["bit_exact"] is True and p["frames_per_rank"] == 24 and abs(p["frames_per_s"] - 2 * p["frames_per_s_per_rank"]) < 1.0
 
