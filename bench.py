@@ -33,7 +33,7 @@ import time
 from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "tests")):
+for p in (ROOT, os.path.join(ROOT, "oracle")):  # the package; the checkers' doors (oracle/doors.py: verification and cpu_baseline only)
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -80,8 +80,15 @@ def parse():
 
 
 def synth_lib():
-    import _libs as L
-    return L
+    """One namespace for the helpers the legs use: the build's encoder and image generator (the package's synthlib) and the
+    checkers' doors (oracle/doors.py -- the oracle and the real reference: algorithmic byte counts, verification outside the timed
+    regions, cpu_baseline; never the thing measured)."""
+    import types
+    import doors
+    from motioncam_decoder_amd import synthlib
+    ns = {k: v for k, v in vars(synthlib).items() if not k.startswith("__")}
+    ns.update({k: v for k, v in vars(doors).items() if not k.startswith("__")})
+    return types.SimpleNamespace(**ns)
 
 
 def make_frames(L, seeds, w, h, nbits, dist, sigma):
@@ -176,7 +183,7 @@ def frame_checksums(torch, comm, wl, nglobal):
 
 def run_timed(torch, comm, ctx, M, wl, args):
     """Warm-up, per-kernel breakdown (untimed), then the timed rounds.  Returns (round times [s, max over
-    ranks], kernels_ms_per_step, (k7_tiles ms summed over the timed rounds, launches), steps timed, ok)."""
+    ranks], kernels_ms_bracketed, (k7_tiles ms summed over the timed rounds, launches), steps timed, ok)."""
     from motioncam_decoder_amd import benchlib
     steps, warmup = args.steps, args.warmup
     nset = len(wl.desc_sets)
@@ -329,8 +336,12 @@ def cpu_baseline(L, wl, seconds):
     ref = L.ref()
     if ref is not None:
         kind, fn = "reference", ref.mcraw_ref_time_batch
+        # (the library was built in the build container and travels prebuilt: -march=native there would be another CPU's)
+        flags = "g++ -O3 -march=x86-64-%s -include cstring -include algorithm (oracle/Makefile ref; %s)" % (
+            "v3" if "_v3" in (L.ref_path() or "") else "v2", os.path.basename(L.ref_path() or ""))
     else:
         kind = "port"
+        flags = "gcc -O3 -march=native (oracle/mcraw_oracle.c, built on this host)"
         native = os.path.join(ROOT, "oracle", "libmcraw_oracle_native.so")
         try:
             subprocess.run(["gcc", "-O3", "-march=native", "-fPIC", "-std=c11", "-shared", "-o", native,
@@ -368,6 +379,7 @@ def cpu_baseline(L, wl, seconds):
     except OSError:
         pass
     return {"value": round(res["all"], 1), "unit": "MPixels/s", "cores": cores, "kind": kind,
+            "flags": flags,
             "value_1thread": round(res["one"], 1), "cpu": model,
             "sample": "%d distinct %dx%d %d-bit frames of this workload, decode only (inputs in RAM), "
                       "%.1f s on %d threads + %.1f s on 1 thread" % (n, wl.w, wl.h, 12, res["all_s"], cores, res["one_s"])}
@@ -537,12 +549,12 @@ def pool_leg(torch, M, L, wl, devices, link=None, nframes=240, reps=2):
     return res
 
 
-def post_stage(torch, ctx, M, L, wl, steps):
+def post_stage(torch, ctx, M, L, wl, steps, bits=12):
     """The same batch with the fused post-decode stage: black levels subtracted and rows
-    written as 12-bit DNG strips -- 1.5 instead of 2 output bytes per sample.  Not the bench line."""
+    written as `bits`-bit DNG strips -- 1.5 (1.25, 1.75) instead of 2 output bytes per sample.  Not the bench line."""
     stream = torch.cuda.current_stream().cuda_stream
-    black = [256, 256, 256, 256]
-    ctx.set_post(black=black, pack12=True)
+    black = [256, 256, 256, 256] if bits != 10 else [64, 64, 64, 64]
+    ctx.set_post(black=black, bits=bits)
     try:
         for t in wl.t_outs[:1]:
             t.zero_()
@@ -558,21 +570,24 @@ def post_stage(torch, ctx, M, L, wl, steps):
         el = time.perf_counter() - t0
         st = ctx.synchronize(wl.frames)
         tile_ms, tile_n = ctx.kernel_ms("k7_tiles", reset=True)
-        rb = L.post_row_bytes(wl.w, True)
+        rb = L.post_row_bytes(wl.w, bits=bits)
         ok = all(s == 0 for s in st)
         d = len(wl.pairs)
         for i in sorted({0, wl.frames - 1}):
             got = wl.t_out[i * wl.out_stride: i * wl.out_stride + wl.h * rb].cpu().numpy().reshape(wl.h, rb)
-            ok = ok and np.array_equal(got, L.oracle_post(wl.pairs[i % d][0], black, True))
+            ok = ok and np.array_equal(got, L.oracle_post(wl.pairs[i % d][0], black, bits=bits))
         out_b = wl.frames * wl.h * rb
         ach = (wl.in_bytes + out_b) / (tile_ms / max(tile_n, 1) * 1e-3) / 1e9
-        return {"stage": "black levels %s subtracted, rows as 12-bit strips" % black, "ms_per_step": round(1e3 * el / steps, 4),
+        bound = {12: "the memory pipeline's instruction rate: two stores per lane and call like the plain kernel, 12 instead of 16 bytes each "
+                     "(768 B per wave instruction); the stage's arithmetic is 14 vector instructions per lane and call for items "
+                     "that take the lean path (DESIGN 3)",
+                 10: "four stores per lane and call (8 + 2 bytes per row piece at 2-byte alignment) and the clamp / shift arithmetic of every "
+                     "sample (these 12-bit frames saturate at 1023 on the way, like the oracle's)",
+                 14: "four stores per lane and call (12 + 2 bytes per row piece at 2-byte alignment) and the shift arithmetic of every sample"}[bits]
+        return {"stage": "black levels %s subtracted, rows as %d-bit strips" % (black, bits), "ms_per_step": round(1e3 * el / steps, 4),
                 "mpix_s": round(wl.pixels * steps / el / 1e6, 1), "tiles_ms_per_launch": round(tile_ms / max(tile_n, 1), 4),
                 "algorithmic_bytes_per_launch": wl.in_bytes + out_b, "achieved_gbs": round(ach, 1),
-                "frac": round(ach / HBM_PEAK_GBS, 4), "xcd_runs": ctx.xcd_runs(), "bit_exact": bool(ok),
-                "bound": "the memory pipeline's instruction rate: two stores per lane and call like the plain kernel, 12 instead of 16 bytes each "
-                         "(768 B per wave instruction); the stage's arithmetic is 14 vector instructions per lane and call for items "
-                         "that take the lean path (DESIGN 3)"}
+                "frac": round(ach / HBM_PEAK_GBS, 4), "xcd_runs": ctx.xcd_runs(), "bit_exact": bool(ok), "bound": bound}
     finally:
         ctx.set_post()
         ctx.profile(True)
@@ -675,7 +690,7 @@ def config5_leg(torch, ctx, M, L, dev, n=120, w=7680, h=4320, nbits=12, sigma=12
     kms = {k: round(ctx.kernel_ms(k, reset=True)[0] / 3.0, 4) for k in ("k7_side", "k7_tiles")}
     out = {"workload": "config 5, one rank's share: %d x %dx%d %d-bit type-7 frames, Nat" % (n, w, h, nbits), "ms_per_step": round(t * 1e3, 4),
            "steps_timed": reps, "mpix_s": round(n * w * h / t / 1e6, 1), "algorithmic_bytes_per_step": byts,
-           "step_frac": round(byts / t / 1e9 / HBM_PEAK_GBS, 4), "kernels_ms_per_step": kms, "xcd_runs": ctx.xcd_runs(),
+           "step_frac": round(byts / t / 1e9 / HBM_PEAK_GBS, 4), "kernels_ms_bracketed": kms, "xcd_runs": ctx.xcd_runs(),
            "side_parts": ctx.side_parts(), "bit_exact": bool(ok)}
     if kms["k7_tiles"] > 0:
         out["frac"] = round(byts / (kms["k7_tiles"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
@@ -719,16 +734,46 @@ def rotating_outputs_leg(torch, ctx, M, wl, dev, sets=8, reps=64):
     return res
 
 
-def traffic_from_profile(workload_key):
-    """HBM bytes per k7_tiles launch from the committed rocprofv3 --pmc summary, if present."""
+def traffic_from_profile(workload_key, algorithmic_bytes=None):
+    """HBM bytes per k7_tiles launch from the committed rocprofv3 --pmc summary (profiles/traffic.json): the entry of this
+    (geometry, bit depth, frames, distribution) when there is one; else the measured traffic / algorithmic ratio of the entry
+    with the same distribution (any geometry: the ratio is a property of the kernel's access pattern -- 1.007 at UHD and 8K alike)
+    times this run's algorithmic bytes.  Returns (bytes or None, where it comes from)."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(p) as f:
             t = json.load(f)
-        e = t.get(workload_key)
-        return e.get("hbm_bytes_per_launch") if e else None  # per k7_tiles launch, like `achieved`
     except Exception:
-        return None
+        return None, None
+    e = t.get(workload_key)
+    if e and e.get("hbm_bytes_per_launch"):
+        return e["hbm_bytes_per_launch"], ("profiles/traffic.json[%s] (rocprofv3 --pmc passes of this workload, profile %s, committed; not "
+                                           "measured in this run)" % (workload_key, e.get("profile")))
+    dist = workload_key.rsplit("_", 1)[-1]
+    for k, e in t.items():
+        if k.rsplit("_", 1)[-1] == dist and e.get("hbm_bytes_per_launch") and e.get("algorithmic_bytes") and algorithmic_bytes:
+            ratio = e["hbm_bytes_per_launch"] / e["algorithmic_bytes"]
+            return ratio * algorithmic_bytes, ("ratio %.4f of profiles/traffic.json[%s] (profile %s) x this run's algorithmic bytes: no --pmc "
+                                               "pass of this geometry is committed" % (ratio, k, e.get("profile")))
+    return None, None
+
+
+def profile_launch_ms(dist):
+    """Average k7_tiles launch of the committed rocprofv3 --kernel-trace --stats summary of this workload (profiles/rNN_<dist>_kernel_stats.csv,
+    the newest round), or (None, None)."""
+    import csv
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s_kernel_stats.csv" % dist)), reverse=True):
+        try:
+            with open(path) as f:
+                rows = list(csv.reader(line for line in f if not line.startswith("#")))
+            hdr = rows[0]
+            for r in rows[1:]:
+                if "k7_tiles" in r[hdr.index("Name")]:
+                    return float(r[hdr.index("AverageNs")]) * 1e-6, os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, None
 
 
 def stub_main(args):
@@ -914,14 +959,15 @@ def main():
                 "step_gbs": bytes_step / (st["median"] * 1e-3) / 1e9,
                 "bytes_per_launch": bytes_step,
                 "bpp": wl.bpp,
-                "kernels_ms_per_step": r["kms"],  # untimed pass with every kernel bracketed
+                "kernels_ms_bracketed": r["kms"],  # untimed pass with every kernel bracketed
             }
 
         s = summarize(results[args.dist])
         wname = "%dx%d %d-bit type-7 x %d frames/GPU, %s" % (args.width, args.height, args.nbits, args.frames,
                                                              "Nat (smooth field + noise sigma %g)" % args.sigma if args.dist == "nat" else "U (uniform)")
         key = "%dx%d_%dbit_%d_%s" % (args.width, args.height, args.nbits, args.frames, args.dist)
-        traffic = traffic_from_profile(key)
+        traffic, traffic_src = traffic_from_profile(key, s["bytes_per_launch"])
+        prof_ms, prof_path = profile_launch_ms(args.dist) if (args.width, args.height, args.frames, args.nbits) == (3840, 2160, 240, 12) else (None, None)
         out = {
             "metric": METRIC,
             "value": round(s["mpix_s"], 1),
@@ -957,15 +1003,23 @@ def main():
                          "unit": "GB/s", "frac": round(s["achieved_gbs"] / HBM_PEAK_GBS, 4),
                          # the whole step (every launch of the path) against the same peak: what a caller sees
                          "step_achieved": round(s["step_gbs"], 1), "step_frac": round(s["step_gbs"] / HBM_PEAK_GBS, 4),
-                         "traffic": traffic,
-                         "traffic_source": ("profiles/traffic.json (rocprofv3 --pmc passes of this command, committed; not "
-                                            "measured in this run)") if traffic else None,
+                         # the same bytes over the committed rocprofv3 average of this kernel on this workload (another box, another
+                         # day: boxes differ by several per cent): what a reader can reproduce from profiles/ alone
+                         "frac_profile": round(s["bytes_per_launch"] / (prof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if prof_ms else None,
+                         "frac_profile_source": ("%s: k7_tiles AverageNs %.0f" % (prof_path, prof_ms * 1e6)) if prof_ms else None,
+                         "traffic": round(traffic) if traffic else None,
+                         "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": round(s["bytes_per_launch"]),
                          "avg_launch_ms": round(s["tiles_ms_per_launch"], 4),
                          "launches_per_step": 1.0, "kernel_launches_per_step": 2,
-                         "xcd_runs": s["kernels_ms_per_step"].get("xcd_runs"),
+                         "xcd_runs": s["kernels_ms_bracketed"].get("xcd_runs"),
+                         "xcd_recheck_share": "1 launch in 64 is timed, the chosen mapping and the other one in turn: 1 in 128 runs the mapping that "
+                                              "was NOT chosen (+0 .. 8 % for that launch, < 0.07 % of the step)",
                          "timed_with": "HIP events on the launch stream around every 8th k7_tiles launch of the timed rounds"},
-            "kernels_ms_per_step": {k: round(v, 4) for k, v in s["kernels_ms_per_step"].items() if k != "xcd_runs"},
+            "kernels_ms_bracketed": {k: round(v, 4) for k, v in s["kernels_ms_bracketed"].items() if k != "xcd_runs"},
+            "kernels_ms_bracketed_note": "three UNTIMED steps behind the timed rounds with EVERY kernel between two event records (each "
+                                         "bracket costs the stream several microseconds, so these read above roofline.avg_launch_ms and "
+                                         "their sum above ms_per_step): a breakdown, not a timing",
         }
         calib_after = box_calibration(torch, dev)
         out["box_calibration"] = {"before": calib, "after": calib_after,
@@ -978,9 +1032,9 @@ def main():
                                 "frac": round(s2["achieved_gbs"] / HBM_PEAK_GBS, 4),
                                 "step_frac": round(s2["step_gbs"] / HBM_PEAK_GBS, 4),
                                 "algorithmic_bytes_per_launch": round(s2["bytes_per_launch"]), "avg_launch_ms": round(s2["tiles_ms_per_launch"], 4),
-                                "traffic": traffic_from_profile(key2),
-                                "kernels_ms_per_step": {k: round(v, 4) for k, v in s2["kernels_ms_per_step"].items() if k != "xcd_runs"},
-                                "xcd_runs": s2["kernels_ms_per_step"].get("xcd_runs"),
+                                "traffic": (lambda tv: round(tv) if tv else None)(traffic_from_profile(key2, s2["bytes_per_launch"])[0]),
+                                "kernels_ms_bracketed": {k: round(v, 4) for k, v in s2["kernels_ms_bracketed"].items() if k != "xcd_runs"},
+                                "xcd_runs": s2["kernels_ms_bracketed"].get("xcd_runs"),
                                 "bit_exact": results[d]["ok"]}
         out.update(extra)
         if not args.no_cpu: # (rank 0 alone, at every N: the other ranks wait at the barrier below)
@@ -1003,10 +1057,11 @@ def main():
                 out["mixed64"] = mixed64_leg(torch, ctx, M, L, dev)
             except Exception as e:
                 out["mixed64"] = {"error": repr(e)}
-            try:
-                out["post_stage"] = post_stage(torch, ctx, M, L, wl, max(2, args.steps // 2))
-            except Exception as e:
-                out["post_stage"] = {"error": repr(e)}
+            for key_, bits_ in (("post_stage", 12), ("post_stage10", 10), ("post_stage14", 14)):
+                try:
+                    out[key_] = post_stage(torch, ctx, M, L, wl, max(2, args.steps // 2), bits=bits_)
+                except Exception as e:
+                    out[key_] = {"error": repr(e)}
             try:
                 if world > 1: # this rank was bound to its GPU's NUMA node: the baseline is the NODE's cores
                     try:

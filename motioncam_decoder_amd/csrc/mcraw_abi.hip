@@ -138,6 +138,8 @@ struct mcraw_ctx {
     // wave per SIMD, 23 KB of LDS), which find room on a CU whenever one of the tile kernel's leaves (the fat ones, 57 KB and two
     // waves per SIMD, starve until the tile kernel is through).  `tmain`: only with a CU partition (MCRAW_SIDE_CUS > 0).
     hipStream_t side = nullptr, tmain = nullptr;
+    bool side_fat = false;  // MCRAW_SIDE_FAT (timing experiment): the fat workgroups on the side stream too
+    bool side_thin = false; // MCRAW_SIDE_THIN (tests, experiments): every k7_side launch as thin workgroups
     hipStream_t last_own = nullptr;  // which of the context's own streams the last own-stream batch went to
     hipEvent_t chain = nullptr;      // orders two own-stream batches that went to different streams
     uint32_t profile = 0; // bit id: bracket launches of kernel id with events
@@ -548,8 +550,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     // k7_side on the context's side stream (as thin workgroups that find room beside the tile kernel's), the rest of the batch on
     // `st` behind an event
     hipStream_t sst = side_st && n7 > 0 && s.side_done && !geom_override && !dev_in ? side_st : nullptr;
-    static const bool no_thin = std::getenv("MCRAW_SIDE_FAT") != nullptr; // timing experiment: the fat workgroups there too
-    static const bool all_thin = std::getenv("MCRAW_SIDE_THIN") != nullptr; // tests: every k7_side launch as thin workgroups
+    const bool no_thin = c->side_fat, all_thin = c->side_thin; // (experiments and tests: MCRAW_SIDE_FAT, MCRAW_SIDE_THIN)
 
     // Type-7 plans in order of decreasing size, cut into size classes: the unpack kernel is launched
     // once per class with that class's group count, so a batch that mixes small and large frames does
@@ -1411,6 +1412,8 @@ int mcraw_ctx_create(int device, mcraw_ctx **out)
         //        mask is dealt bit by bit to the XCDs: bit i is XCD i mod 8, then shader engine by shader engine, so the low 8 r
         //        bits are r CUs of every XCD).  k7_side hides completely -- and the tile kernel, which runs at the CUs' memory
         //        pipelines' rate, loses more than its share: +4.6 / +9 / +9 / +8 / +16 % with 8 / 16 / 24 / 32 / 48 CUs away.
+        c->side_fat = std::getenv("MCRAW_SIDE_FAT") != nullptr;
+        c->side_thin = std::getenv("MCRAW_SIDE_THIN") != nullptr;
         int per_xcd = 0;
         if (const char *e = std::getenv("MCRAW_SIDE_CUS"))
             per_xcd = std::atoi(e);

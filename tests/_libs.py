@@ -1,294 +1,17 @@
-"""ctypes doors for the test-side libraries (TEST INFRASTRUCTURE).
+"""Doors for the tests: the build's encoder / image generator (motioncam_decoder_amd/synthlib.py) and the checkers
+(oracle/doors.py: the oracle and, where it was built, the real reference).  TEST INFRASTRUCTURE.
 
-* oracle/libmcraw_oracle.so      -- own scalar C restatement of the reference codecs
-* oracle/_ref/libmcraw_ref_*.so  -- the real reference codec (built only where
-                                    /root/reference exists; travels to the GPU box prebuilt)
-* motioncam_decoder_amd/synth/libmcraw_synth.so -- encoder / image generator
-
-The product library (libmcraw_hip.so) is loaded by motioncam_decoder_amd itself.
-"""
-import ctypes as C
+The product library (libmcraw_hip.so) is loaded by motioncam_decoder_amd itself."""
 import os
-import subprocess
-
-import numpy as np
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ORACLE_DIR = os.path.join(ROOT, "oracle")
-SYNTH_DIR = os.path.join(ROOT, "motioncam_decoder_amd", "synth")
+for _p in (ROOT, os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
 
-u8p = C.POINTER(C.c_uint8)
-u16p = C.POINTER(C.c_uint16)
-
-
-def _cpu_has(flag):
-    try:
-        with open("/proc/cpuinfo") as f:
-            for line in f:
-                if line.startswith("flags"):
-                    return flag in line.split()
-    except OSError:
-        pass
-    return False
-
-
-def _ensure(path, cmd, cwd):
-    if not os.path.exists(path):
-        subprocess.run(cmd, cwd=cwd, check=True, stdout=subprocess.DEVNULL)
-    return path
-
-
-_oracle = None
-_ref = None
-_synth = None
-
-
-def oracle():
-    global _oracle
-    if _oracle is None:
-        p = _ensure(os.path.join(ORACLE_DIR, "libmcraw_oracle.so"), ["make", "-s"], ORACLE_DIR)
-        lib = C.CDLL(p)
-        for name in ("mcraw_oracle_decode7", "mcraw_oracle_decode6"):
-            fn = getattr(lib, name)
-            fn.restype = C.c_size_t
-            fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
-        lib.mcraw_oracle_block7.restype = C.c_int
-        lib.mcraw_oracle_block7.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-        lib.mcraw_oracle_block6.restype = C.c_int
-        lib.mcraw_oracle_block6.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-        lib.mcraw_oracle_len_used7.restype = C.c_size_t
-        lib.mcraw_oracle_len_used7.argtypes = [C.c_void_p, C.c_size_t]
-        lib.mcraw_oracle_post.restype = C.c_size_t
-        lib.mcraw_oracle_post.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint, C.c_void_p]
-        lib.mcraw_oracle_time_batch.restype = C.c_double
-        lib.mcraw_oracle_time_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
-                                                C.c_int, C.c_int, C.c_int]
-        _oracle = lib
-    return _oracle
-
-
-def ref_path():
-    for v in (("v3",) if _cpu_has("avx2") else ()) + ("v2",):
-        p = os.path.join(ORACLE_DIR, "_ref", "libmcraw_ref_%s.so" % v)
-        if os.path.exists(p):
-            return p
-    return None
-
-
-def ref():
-    """The real reference codec, or None when it was never built (no /root/reference)."""
-    global _ref
-    if _ref is None:
-        p = ref_path()
-        if p is None and os.path.isdir("/root/reference/lib"):
-            subprocess.run(["make", "-s", "ref"], cwd=ORACLE_DIR, check=True, stdout=subprocess.DEVNULL)
-            p = ref_path()
-        if p is None:
-            return None
-        lib = C.CDLL(p)
-        for name in ("mcraw_ref_decode7", "mcraw_ref_decode6"):
-            fn = getattr(lib, name)
-            fn.restype = C.c_size_t
-            fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
-        lib.mcraw_ref_time_batch.restype = C.c_double
-        lib.mcraw_ref_time_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
-                                             C.c_int, C.c_int, C.c_int]
-        _ref = lib
-    return _ref
-
-
-def synth():
-    global _synth
-    if _synth is None:
-        p = os.path.join(SYNTH_DIR, "libmcraw_synth.so")
-        if not os.path.exists(p):
-            subprocess.run(["gcc", "-O3", "-march=x86-64-v3", "-fPIC", "-std=c11", "-shared", "-o", p,
-                            os.path.join(SYNTH_DIR, "mcraw_synth.c"), "-lm"], check=True)
-        lib = C.CDLL(p)
-        lib.mcraw_synth_bound7.restype = C.c_size_t
-        lib.mcraw_synth_bound7.argtypes = [C.c_int, C.c_int]
-        lib.mcraw_synth_bound6.restype = C.c_size_t
-        lib.mcraw_synth_bound6.argtypes = [C.c_int, C.c_int]
-        for name in ("mcraw_synth_encode7", "mcraw_synth_encode6"):
-            fn = getattr(lib, name)
-            fn.restype = C.c_size_t
-            fn.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
-        lib.mcraw_synth_image.restype = None
-        lib.mcraw_synth_image.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
-                                          C.c_uint64]
-        lib.mcraw_synth_pack_block7.restype = C.c_int
-        lib.mcraw_synth_pack_block7.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-        _synth = lib
-    return _synth
-
-
-# ---------------------------------------------------------------- helpers
-
-def _ptr(a):
-    return a.ctypes.data_as(C.c_void_p) if a is not None else None
-
-
-def encode7(img, min_bits=None, flags=0):
-    img = np.ascontiguousarray(img, dtype=np.uint16)
-    h, w = img.shape
-    s = synth()
-    buf = np.zeros(s.mcraw_synth_bound7(w, h), dtype=np.uint8)
-    mb = None if min_bits is None else np.ascontiguousarray(min_bits, dtype=np.uint8)
-    n = s.mcraw_synth_encode7(_ptr(buf), buf.size, _ptr(img), w, h, _ptr(mb), flags)
-    assert n > 0
-    return buf[:n].copy()
-
-
-def encode6(img, min_bits=None, flags=0):
-    img = np.ascontiguousarray(img, dtype=np.uint16)
-    h, w = img.shape
-    s = synth()
-    buf = np.zeros(s.mcraw_synth_bound6(w, h), dtype=np.uint8)
-    mb = None if min_bits is None else np.ascontiguousarray(min_bits, dtype=np.uint8)
-    n = s.mcraw_synth_encode6(_ptr(buf), buf.size, _ptr(img), w, h, _ptr(mb), flags)
-    assert n > 0
-    return buf[:n].copy()
-
-
-def synth_image(w, h, nbits, dist, sigma, seed):
-    img = np.empty((h, w), dtype=np.uint16)
-    synth().mcraw_synth_image(_ptr(img), w, h, nbits, dist, float(sigma), seed)
-    return img
-
-
-def _decode(fn, buf, w, h, rows_alloc=None, fill=0xA5A5):
-    """Call a 5-argument decode entry; returns (ret, out[h_alloc, w])."""
-    buf = np.ascontiguousarray(buf, dtype=np.uint8)
-    rows = rows_alloc if rows_alloc is not None else h
-    out = np.full((rows, w), fill, dtype=np.uint16)
-    ret = fn(_ptr(out), w, h, _ptr(buf), buf.size)
-    return ret, out
-
-
-def oracle_decode7(buf, w, h, **kw):
-    return _decode(oracle().mcraw_oracle_decode7, buf, w, h, **kw)
-
-
-def oracle_decode6(buf, w, h, **kw):
-    return _decode(oracle().mcraw_oracle_decode6, buf, w, h, **kw)
-
-
-def ref_decode7(buf, w, h, **kw):
-    # the reference writes width*encodedHeight: give it 4 spare rows
-    kw.setdefault("rows_alloc", h + 4)
-    return _decode(ref().mcraw_ref_decode7, buf, w, h, **kw)
-
-
-def ref_decode6(buf, w, h, **kw):
-    return _decode(ref().mcraw_ref_decode6, buf, w, h, **kw)
-
-
-def _strip_bits(pack12, bits):
-    """Bits per sample of a strip row: `bits` (10, 12, 14 or 16/None), or 12 for the older pack12=True."""
-    b = int(bits) if bits else (12 if pack12 else 16)
-    assert b in (10, 12, 14, 16)
-    return b
-
-
-def post_row_bytes(w, pack12=False, bits=None):
-    return (w * _strip_bits(pack12, bits) + 7) // 8
-
-
-def oracle_post(img, black=None, pack12=False, bits=None):
-    """The post stage (mcraw_ctx_set_post) applied to a decoded mosaic by the oracle: bytes [h, row_bytes]."""
-    img = np.ascontiguousarray(img, dtype=np.uint16)
-    h, w = img.shape
-    b = _strip_bits(pack12, bits)
-    out = np.zeros((h, post_row_bytes(w, bits=b)), dtype=np.uint8)
-    bl = np.ascontiguousarray(black if black is not None else [0, 0, 0, 0], dtype=np.uint16)
-    flags = (1 if black is not None else 0) | {16: 0, 12: 2, 10: 4, 14: 8}[b]
-    n = oracle().mcraw_oracle_post(_ptr(out), _ptr(img), w, h, flags, _ptr(bl))
-    assert n == out.size
-    return out
-
-
-def post_np(img, black=None, pack12=False, bits=None):
-    """Independent numpy statement of the same stage (checks the oracle's)."""
-    v = img.astype(np.int64)
-    h, w = v.shape
-    nb = _strip_bits(pack12, bits)
-    if black is not None:
-        b = np.asarray(black, dtype=np.int64).reshape(2, 2)
-        v = np.maximum(v - np.tile(b, ((h + 1) // 2, (w + 1) // 2))[:h, :w], 0)
-    if nb == 16:
-        return v.astype("<u2").view(np.uint8).reshape(h, w * 2)
-    v = np.minimum(v, (1 << nb) - 1)
-    bits = ((v[:, :, None] >> np.arange(nb - 1, -1, -1)) & 1).astype(np.uint8).reshape(h, w * nb)
-    pad = (-bits.shape[1]) % 8
-    if pad:
-        bits = np.concatenate([bits, np.zeros((h, pad), np.uint8)], axis=1)
-    return np.packbits(bits, axis=1)
-
-
-def natural_image_np(w, h, nbits, sigma, seed):
-    """SURVEY 8(d) "Nat" distribution, numpy flavour (used for golden vectors)."""
-    rng = np.random.default_rng(seed)
-    maxv = (1 << nbits) - 1
-    x = np.arange(w)[None, :]
-    y = np.arange(h)[:, None]
-    field = 0.8 * maxv * (0.5 + 0.45 * np.sin(x / 211.0) * np.cos(y / 173.0)) + maxv / 16.0
-    img = field + rng.normal(0.0, sigma, size=(h, w))
-    return np.clip(np.rint(img), 0, maxv).astype(np.uint16)
-
-
-def uniform_image_np(w, h, nbits, seed):
-    rng = np.random.default_rng(seed)
-    return rng.integers(0, 1 << nbits, size=(h, w), dtype=np.uint16)
-
-
-# ---------------------------------------------------------------- .mcraw container writer
-
-def write_mcraw(path, frames, audio_chunks=(), camera_extra=None, audio_rate=48000, audio_channels=2):
-    """Write a synthetic .mcraw container (layout: SURVEY Appendix A.5).
-
-    frames: list of (timestamp, type, width, height, encoded bytes), written in the given order
-    (the reader sorts by timestamp).  audio_chunks: list of (timestamp_ns or None, int16 array).
-    """
-    import json
-    import struct
-    camera = {"blackLevel": [64, 64, 64, 64], "whiteLevel": 1023.0, "sensorArrangment": "rggb",
-              "colorMatrix1": [1, 0, 0, 0, 1, 0, 0, 0, 1], "colorMatrix2": [1, 0, 0, 0, 1, 0, 0, 0, 1],
-              "forwardMatrix1": [1, 0, 0, 0, 1, 0, 0, 0, 1], "forwardMatrix2": [1, 0, 0, 0, 1, 0, 0, 0, 1],
-              "extraData": {"audioSampleRate": audio_rate, "audioChannels": audio_channels}}
-    if camera_extra:
-        camera.update(camera_extra)
-    BUFFER_INDEX, BUFFER_INDEX_DATA, BUFFER, METADATA, AUDIO_INDEX, AUDIO_DATA, AUDIO_DATA_METADATA = range(7)
-
-    def item(t, size):
-        return struct.pack("<II", t, size)
-
-    out = bytearray(b"MOTION " + bytes([3]))
-    cj = json.dumps(camera).encode()
-    out += item(METADATA, len(cj)) + cj
-    offsets = []
-    for ts, typ, w, h, buf in frames:
-        offsets.append((len(out), ts))
-        b = bytes(np.ascontiguousarray(buf, dtype=np.uint8))
-        out += item(BUFFER, len(b)) + b
-        fj = json.dumps({"width": w, "height": h, "compressionType": typ, "asShotNeutral": [1.0, 1.0, 1.0],
-                         "timestamp": str(ts)}).encode()
-        out += item(METADATA, len(fj)) + fj
-    audio_offsets = []
-    for ts, samples in audio_chunks:
-        audio_offsets.append((len(out), ts if ts is not None else -1))
-        b = np.ascontiguousarray(samples, dtype=np.int16).tobytes()
-        out += item(AUDIO_DATA, len(b)) + b
-        if ts is not None:
-            out += item(AUDIO_DATA_METADATA, 8) + struct.pack("<q", ts)
-    if audio_offsets:
-        out += item(AUDIO_INDEX, 16 + 16 * len(audio_offsets)) + struct.pack("<qq", len(audio_offsets), 0)
-        for off, ts in audio_offsets:
-            out += struct.pack("<qq", off, ts)
-    out += item(BUFFER_INDEX_DATA, 16 * len(offsets))
-    index_data_offset = len(out)
-    for off, ts in offsets:
-        out += struct.pack("<qq", off, ts)
-    out += item(BUFFER_INDEX, 16) + struct.pack("<iiq", np.int32(np.uint32(0x8A905612)), len(offsets), index_data_offset)
-    with open(path, "wb") as f:
-        f.write(out)
-    return path
+from motioncam_decoder_amd.synthlib import *  # noqa: F401,F403,E402
+from motioncam_decoder_amd.synthlib import _ptr, _strip_bits  # noqa: F401,E402
+from doors import *  # noqa: F401,F403,E402
+from doors import ORACLE_DIR, _decode, _cpu_has  # noqa: F401,E402
+from motioncam_decoder_amd.synthlib import SYNTH_DIR  # noqa: F401,E402

@@ -10,7 +10,7 @@ import json, sys
 try:
     d = json.load(open("/tmp/line.json"))
     print(sys.argv[1], "side_cus", sys.argv[2], "ms_per_step", d["ms_per_step"], "step_frac", d["roofline"]["step_frac"], "tiles_avg", d["roofline"]["avg_launch_ms"],
-          "frac", d["roofline"]["frac"], d["kernels_ms_per_step"], "ok", d["bit_exact"], flush=True)
+          "frac", d["roofline"]["frac"], d["kernels_ms_bracketed"], "ok", d["bit_exact"], flush=True)
 except Exception as e:
     print(sys.argv[1], sys.argv[2], "failed", e, open("/tmp/err.txt").read()[-600:], flush=True)
 PY

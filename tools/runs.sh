@@ -6,7 +6,7 @@ for i in $(seq 1 ${N:-8}); do
   python3 - <<'PY'
 import json
 d = json.load(open("/tmp/line.json"))
-print(d["ms_per_step"], d["kernels_ms_per_step"], d["roofline"]["avg_launch_ms"], d.get("box_calibration"))
+print(d["ms_per_step"], d["kernels_ms_bracketed"], d["roofline"]["avg_launch_ms"], d.get("box_calibration"))
 PY
   grep buffers /tmp/err.txt
 done

@@ -10,7 +10,7 @@ for path in sys.argv[1:]:
     r = d["roofline"]
     print(path, "ms_per_step", d["ms_per_step"], "value", d["value"], "frac", r["frac"], "step_frac", r.get("step_frac"), "xcd", r.get("xcd_runs"),
           "traffic_x", round(r["traffic"] / r["algorithmic_bytes_per_launch"], 4) if r.get("traffic") and r.get("algorithmic_bytes_per_launch") else None)
-    for k in ("also_u", "legacy", "config5", "mixed64", "post_stage", "rotating_outputs"):
+    for k in ("also_u", "legacy", "config5", "mixed64", "post_stage", "post_stage10", "post_stage14", "rotating_outputs"):
         v = d.get(k)
         if isinstance(v, dict):
             print("   ", k, {kk: vv for kk, vv in v.items() if kk in ("ms_per_step", "ms_per_batch", "frac", "step_frac", "side_parts", "tiles_ms_per_launch", "kernels_ms", "kernels", "traffic")})
