@@ -157,6 +157,8 @@ def load():
     lib.mcraw_pool_synchronize.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
     lib.mcraw_ctx_xcd_runs.restype = C.c_int
     lib.mcraw_ctx_xcd_runs.argtypes = [C.c_void_p]
+    lib.mcraw_ctx_side_parts.restype = C.c_int
+    lib.mcraw_ctx_side_parts.argtypes = [C.c_void_p]
     lib.mcraw_pool_decode_batch_device.restype = C.c_int
     lib.mcraw_pool_decode_batch_device.argtypes = [C.c_void_p, C.POINTER(Frame), C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
     lib.mcraw_pool_decode_batch_async.restype = C.c_int

@@ -95,7 +95,7 @@ struct Member {
     {
         const auto t0 = std::chrono::steady_clock::now();
         while (completed_a.load(std::memory_order_acquire) < seq) {
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(20000)) { // (a long task: block)
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(2000)) { // (a long task: block; a 240-frame batch is 1 ms)
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return completed >= seq; });
                 return;
@@ -302,6 +302,7 @@ void mcraw_pool_destroy(mcraw_pool *p)
 {
     if (!p)
         return;
+    g_queued.erase(p); // (the calling thread's record; other threads' records are told apart by the pool's id)
     for (Member *m : p->members) {
         {
             std::unique_lock<std::mutex> lk(m->mu);
@@ -459,15 +460,18 @@ int mcraw_pool_ticket_wait(mcraw_pool_ticket *t, size_t *written, int32_t *statu
 
 // Is `ptr` device memory of `device`?  hipPointerGetAttributes answers that (a look-up in the runtime's tables: ~0.3 us, 0.15 ms for
 // the 480 pointers of a 240-frame batch -- a seventh of the batch's decode time), so what it said about an ALLOCATION is
-// remembered per calling thread: a pointer inside a range that was seen before costs a binary search.  A range is asked about
-// again every 256th time it is hit (memory that was freed and allocated again on another GPU does not stay "known" for long).
+// remembered per calling thread FOR THE BATCH AT HAND: a pointer inside a range that was already asked about in this batch
+// costs a binary search, every allocation is asked about once per batch (two look-ups for the usual batch whose frames are
+// slices of one input and one output allocation) -- memory that was freed and allocated again elsewhere between two batches
+// is never taken for what it was.
 namespace {
 struct KnownRange {
     uintptr_t base, end;
     int device; // -1: not device memory
-    unsigned hits;
+    unsigned long long asked; // the batch (of this thread) in which the runtime was last asked about it
 };
 thread_local std::vector<KnownRange> g_ranges; // sorted by base
+thread_local unsigned long long g_batch_no = 0; // resident batches this thread has submitted
 } // namespace
 
 static bool resident_on(const void *ptr, int device)
@@ -483,7 +487,7 @@ static bool resident_on(const void *ptr, int device)
         else
             hi = mid;
     }
-    if (lo > 0 && a < g_ranges[lo - 1].end && (++g_ranges[lo - 1].hits & 255u) != 0u)
+    if (lo > 0 && a < g_ranges[lo - 1].end && g_ranges[lo - 1].asked == g_batch_no)
         return g_ranges[lo - 1].device == device;
     hipPointerAttribute_t at;
     int dev = -1;
@@ -496,11 +500,11 @@ static bool resident_on(const void *ptr, int device)
     if (dev >= 0 && hipMemGetAddressRange(reinterpret_cast<hipDeviceptr_t *>(&base), &size, const_cast<void *>(ptr)) == hipSuccess && size) {
         const uintptr_t b = reinterpret_cast<uintptr_t>(base);
         if (lo > 0 && g_ranges[lo - 1].base == b) {
-            g_ranges[lo - 1] = {b, b + size, dev, 1u};
+            g_ranges[lo - 1] = {b, b + size, dev, g_batch_no};
         } else {
             if (g_ranges.size() >= 4096) // (a caller with very many allocations: start over)
                 g_ranges.clear(), lo = 0;
-            g_ranges.insert(g_ranges.begin() + static_cast<long>(lo), KnownRange{b, b + size, dev, 1u});
+            g_ranges.insert(g_ranges.begin() + static_cast<long>(lo), KnownRange{b, b + size, dev, g_batch_no});
             // a new allocation may overlap stale neighbours (their memory was freed): drop them
             for (size_t k = g_ranges.size(); k-- > 0;)
                 if (k != lo && g_ranges[k].base < b + size && g_ranges[k].end > b)
@@ -524,6 +528,7 @@ int mcraw_pool_decode_batch_device(mcraw_pool *p, const mcraw_frame *frames, int
     std::vector<std::vector<mcraw_frame>> sub(G);
     std::vector<std::vector<int>> index(G);
     std::vector<int32_t> host_status(nframes, 0);
+    g_batch_no++; // (what was learnt about an allocation in an earlier batch is asked again)
     for (int i = 0; i < nframes; i++) { // frame i -> member i mod G: its buffers live in THAT member's HBM
         const int m = mcraw_shard_of(i, G);
         // (checked, not assumed: a frame on another GPU would be decoded over xGMI at a fraction of the rate or fault, a
@@ -618,6 +623,8 @@ int mcraw_pool_synchronize(mcraw_pool *p, int32_t *status, int nframes)
                 const int r = mcraw_ctx_batch_status(mem->ctx, mine.serial[m], st[m].data(), static_cast<int>(st[m].size()));
                 if (r < 0)
                     rcs[m] = r;
+                else if (r == 1) // the member has forgotten this batch (other threads queued more than 64 behind it): its frames'
+                    st[m].assign(st[m].size(), MCRAW_E_DEVICE); // outcome is UNKNOWN to this caller, which is not "decoded"
             }
             if (rcs[m] != 0)
                 errs[m] = mcraw_last_error();
@@ -633,10 +640,11 @@ int mcraw_pool_synchronize(mcraw_pool *p, int32_t *status, int nframes)
             g_pool_err = errs[m];
         }
         any |= sticky[m];
-        if (status)
-            for (size_t k = 0; k < mine.index[m].size(); k++)
-                if (mine.index[m][k] < nframes)
-                    status[mine.index[m][k]] = st[m][k];
+        for (size_t k = 0; k < mine.index[m].size(); k++) {
+            any |= st[m][k];
+            if (status && mine.index[m][k] < nframes)
+                status[mine.index[m][k]] = st[m][k];
+        }
     }
     for (int i = 0; i < mine.n && i < static_cast<int>(mine.host_status.size()); i++)
         if (mine.host_status[i]) {

@@ -11,11 +11,18 @@
 // A translation unit must see ONE version of the library (its namespace is version-tagged from 3.11 on): a program that
 // includes the reference's copy first -- the reference's example.cpp does -- gets that one, through its include guard.
 #pragma once
+// (a helper macro first: `defined(X) && X(...)` in one #if is ill-formed where the preprocessor does not know X -- the identifier
+// becomes 0 and `0(<...>)` does not parse, whatever defined() said)
+#if defined(__has_include_next)
+#  if __has_include_next(<nlohmann/json.hpp>)
+#    define MCRAW_JSON_NEXT_ON_PATH 1
+#  endif
+#endif
 #if defined(MCRAW_NLOHMANN_JSON_HPP)
 #  include MCRAW_NLOHMANN_JSON_HPP
 #elif __has_include("_vendored/json.hpp")
 #  include "_vendored/json.hpp"
-#elif defined(__has_include_next) && __has_include_next(<nlohmann/json.hpp>)
+#elif defined(MCRAW_JSON_NEXT_ON_PATH)
 #  include_next <nlohmann/json.hpp>
 #elif __has_include("/usr/include/nlohmann/json.hpp")
 #  include "/usr/include/nlohmann/json.hpp"
