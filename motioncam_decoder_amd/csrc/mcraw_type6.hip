@@ -304,6 +304,28 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     if (tid == 0)
         s_ticket = K6_ABL >= 8 ? 0u : atomicAdd(tickets + f * TICKET_STRIDE6, 1u);
     uint32_t seg = (all_in ? 0u : wg_tab[nframes + 1u + stage]) + wrel / inplay;
+#ifdef MCRAW_K6_LDSDMA
+    // The stream goes from memory INTO the LDS (gfx950: buffer_load_dwordx4 ... lds, 16 bytes per lane, a wave's 64 lanes to 1 KiB
+    // in a row; the same bounds-checked descriptor: bytes past `len` arrive as zeros): no registers hold the stage on its way, no
+    // ds_write pass behind the loads.  MEASURED AND NOT SHIPPED (docs/lab_notes.md, round 5: 0.360 against 0.353 ms -- the barrier
+    // behind the ticket now waits for every wave's loads, the eight-record bit map needs the bytes read back; a workgroup's later
+    // stages get shorter by as much as its first ones get longer); tests/test_gpu_k6_waves.py keeps the build parity-green.
+    auto fetch = [&]() {
+#pragma unroll
+        for (uint32_t r = 0; r < NROUND; r++) {
+            const uint32_t i = tid + r * DEC_T;
+            const uint32_t off = seg * OWN - FRONT6 + i * 16u;
+            uint8_t *dst = s_stage + (r * DEC_T + wave * 64u) * 16u; // wave-uniform; the hardware adds lane * 16
+            if (i < NPIECE) {
+                if (seg || i >= FRONT6 / 16u)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(dst), 16,
+                                                             static_cast<int>(off), 0, 0, 0);
+                else // (segment 0 has nothing in front of it)
+                    *reinterpret_cast<uint4 *>(s_stage + i * 16u) = make_uint4(0u, 0u, 0u, 0u);
+            } // (the lines behind the stage touched by a dword load each, as the plain form's last round fetches them: 0.377 against 0.361 ms)
+        }
+    };
+#else
     uint4 v[NROUND];
     auto fetch = [&]() { // piece i at stream offset (seg * DEC_CH - 1) * CHUNK6 + 16 i; past `len`: reads 0
 #pragma unroll
@@ -321,12 +343,16 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                 v[r] = ld_b128(rs, off);
         }
     };
+#endif
     fetch();
     __syncthreads();
     K6_STAMP(0, 0);
     K6_STAMP(8, RESOLVER * 64u);
     if (K6_ABL < 8 && s_ticket != seg) {
         seg = s_ticket;
+#ifdef MCRAW_K6_LDSDMA
+        __syncthreads(); // (nobody may still be reading s_ticket / the first stage when the second one lands)
+#endif
         fetch();
     }
 
@@ -340,8 +366,12 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     bool notes_ok = false, lost = false;
     uint32_t spins = 0;
     const uint32_t cfirst = seg * DEC_CH;
-    if (cfirst >= nchunks)
+    if (cfirst >= nchunks) {
+#ifdef MCRAW_K6_LDSDMA
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (no load may still be on its way into LDS that the next workgroup gets)
+#endif
         return; // whole workgroup
+    }
     const uint32_t cnt = min(static_cast<uint32_t>(DEC_CH), nchunks - cfirst);
     const bool full = cnt == DEC_CH;
     // stage position of the stream's end (the stage starts FRONT6 bytes in front of the segment; cfirst * CHUNK6 < len)
@@ -351,15 +381,23 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
 
         // ---- stage the stream; note which pieces are eight 2-byte records in a row (a flat or clipped image region would
         // otherwise cost a step per record, 128 per quarter)
+#ifdef MCRAW_K6_LDSDMA
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (my own pieces have landed: a wave reads back what it loaded)
+#endif
 #pragma unroll
         for (uint32_t r = 0; r < NROUND; r++) {
             const uint32_t i = tid + r * DEC_T;
             bool ones = false;
             if (i < NPIECE && (seg || i >= FRONT6 / 16u)) {
-                *reinterpret_cast<uint4 *>(s_stage + i * 16u) = v[r];
+#ifdef MCRAW_K6_LDSDMA
+                const uint4 vr = *reinterpret_cast<const uint4 *>(s_stage + i * 16u);
+#else
+                const uint4 vr = v[r];
+                *reinterpret_cast<uint4 *>(s_stage + i * 16u) = vr;
+#endif
                 // every even byte has a zero high nibble: a walk that arrives on the piece's first byte passes eight records of
                 // two bytes; none of them may be the chain's end (RawData_Legacy.cpp:387-388: the last one ends at 16 i + 16)
-                ones = ((v[r].x | v[r].y | v[r].z | v[r].w) & 0x00F000F0u) == 0u && i * 16u + 16u < limP;
+                ones = ((vr.x | vr.y | vr.z | vr.w) & 0x00F000F0u) == 0u && i * 16u + 16u < limP;
             }
             const unsigned long long om = __ballot(ones);
             if (lane == 0u)
