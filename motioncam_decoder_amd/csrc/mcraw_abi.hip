@@ -642,6 +642,8 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     const size_t w_bits = carve(off, Rmax * 64 * n7);
     const size_t w_refs = carve(off, Rmax * 64 * sizeof(uint16_t) * n7);
     const size_t w_grp = carve(off, sizeof(uint32_t) * (Rmax * ITEM_SPLIT + 1) * n7);
+    // side streams in parts: where the records of a part's pieces start, left by its count for its decode (k7_side)
+    const size_t w_rpos = wpf > 2 ? carve(off, sizeof(uint16_t) * Rmax * 2 * MAX_SPLIT7 * n7) : 0;
     // k6_decode goes over the legacy frames round by round (round r: segment r of every frame that has one): the
     // frames by falling number of segments; stage t = the rounds in which all but the t smallest frames are in play
     uint32_t smax = 0; // segments of the longest legacy stream
@@ -732,6 +734,11 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
         W.bits = dev + w_bits;
         W.refs = reinterpret_cast<uint16_t *>(dev + w_refs);
         W.grp_off = reinterpret_cast<uint32_t *>(dev + w_grp);
+        W.rpos = wpf > 2 ? reinterpret_cast<uint16_t *>(dev + w_rpos) : nullptr;
+        // (one workgroup of k7_side per CU at most: 16 x 12 MP 14-bit noise 162 -> 108 us, natural 87 -> 72; 120 x 8K with 4 + 1
+        // parts 164 -> 206 us -- tools/ab_side.sh)
+        static const int lastc_env = []() { const char *e = std::getenv("MCRAW_SIDE_LASTC"); return e ? std::atoi(e) : -1; }();
+        W.side_lastc = lastc_env >= 0 ? static_cast<uint32_t>(lastc_env) : (static_cast<long>(n7) * wpf <= 256 ? 1u : 0u);
         W.Rmax = static_cast<uint32_t>(Rmax);
         W.n7 = n7;
         W.post = c->post;

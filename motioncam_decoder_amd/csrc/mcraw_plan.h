@@ -101,6 +101,11 @@ struct Work7 {
     uint64_t *sync;      // [n7][2][MAX_SPLIT7][2] what a part tells the next one (epoch-tagged words, never cleared): records up to
                          // the end of its pieces; where the chain enters the next part's first piece
     uint32_t epoch;      // ... of this launch
+    uint32_t side_lastc; // k7_side, streams in parts: the last part of a stream counts its pieces too while it waits for the part in front
+                         // (small batches: the chain of a stream gets a third shorter; a full chip only gets more to do)
+    uint16_t *rpos;      // [n7][2][MAX_SPLIT7][Rmax] (only when a stream has parts) where the records of a part's pieces start, in chain
+                         // order: candidate index inside its piece | 0x8000 on the first record of a piece -- written by the part's
+                         // count, read back by its decode, which then need not follow the chain a second time
     int32_t n7;
     Post post;           // fused post-decode stage (mode 0: none)
     uint32_t xcd_chunk;  // k7_tiles: logical items per XCD run (0: one run per XCD = the whole grid in eight parts)

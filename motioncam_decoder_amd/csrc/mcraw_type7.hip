@@ -242,7 +242,10 @@ __device__ unsigned long long g_side_prof[2][256];
 #define SIDE_STAMP(slot)
 #endif
 
-template <uint32_t SIDE_T, uint32_t SIDE_LPT, uint32_t SIDE_LCAP, uint32_t SPEC_WARM>
+// PARTS: streams may be cut into parts (W.nsplit); false: one workgroup per stream -- the instance every batch of UHD frames runs,
+// without the count, the hand-off and the replay in its code (the walker's loop is short of scalar registers as it is).
+// LASTC: the last part of a stream counts its pieces too (below) -- an instance of its own for the same reason.
+template <uint32_t SIDE_T, uint32_t SIDE_LPT, uint32_t SIDE_LCAP, uint32_t SPEC_WARM, bool PARTS, bool LASTC>
 __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) void k7_side(const Work7 W)
 {
     constexpr uint32_t SIDE_PIECE = 16 * SIDE_T * SIDE_LPT;     // stream bytes per piece
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     if (SIDE_T <= 256u) // the thin workgroups run beside the tile kernel's: their chain of dependent steps goes first at issue
         __builtin_amdgcn_s_setprio(MCRAW_THIN_PRIO);
 #endif
-    const uint32_t nfr = static_cast<uint32_t>(W.n7), nsb = W.nsplit[0], nsr = W.nsplit[1];
+    const uint32_t nfr = static_cast<uint32_t>(W.n7), nsb = PARTS ? W.nsplit[0] : 1u, nsr = PARTS ? W.nsplit[1] : 1u;
     const uint32_t bq = blockIdx.x / nfr, f = blockIdx.x - bq * nfr;
     const uint32_t s = bq < nsr ? 1u : 0u, part = s ? bq : bq - nsr, nsp = s ? nsr : nsb; // (the longer stream's parts first)
     const uint32_t fs = (nsb + nsr) * f + (s ? nsb : 0u) + part;
@@ -382,17 +385,28 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     // The pieces of this part.  Where the stream ends is not known before its chain has been followed; the split is made
     // on a guess -- the stream reaches to where the other one starts, or to the end of the frame, as encoders lay them
     // out -- and any guess gives a partition: the ranges are disjoint, the last part's is open-ended.
-    uint32_t m_lo = 0u, m_hi = 0xFFFFFFFFu;
+    constexpr uint32_t ENDX_ = 0xFFFFFFFFu;
+    uint32_t m_lo = 0u, m_hi = 0xFFFFFFFFu, np_guess = 0xFFFFFFFFu;
     if (nsp > 1u) {
         const uint32_t other = s ? bitsOff : refsOff;
         const uint64_t end_guess = other > so ? other : len;
         const uint64_t npieces = (end_guess - A0 + SIDE_PIECE - 1u) / SIDE_PIECE; // (A0 <= so + 4 <= len, end_guess > so)
+        np_guess = static_cast<uint32_t>(npieces);
         m_lo = static_cast<uint32_t>(part * npieces / nsp);
         if (part + 1u < nsp)
             m_hi = static_cast<uint32_t>((part + 1u) * npieces / nsp);
     }
     uint64_t *const sync = W.sync + (static_cast<size_t>(2u * f + s) * MAX_SPLIT7 + part) * 2u; // mine; sync[-2], sync[-1]: the part in front
-    constexpr uint32_t ENDX = 0xFFFFFFFFu; // hand-off: the stream is over (its last record lies in front, or the chain has ended)
+    // Round 5: what a part's count finds out -- where every record of its pieces starts -- is kept (W.rpos, this part's Rmax
+    // entries: the candidate index of a record inside its piece, bit 15 on a piece's first record) and its decode REPLAYS it:
+    // no second walk along the chain (the bits stream of coded frames is walk-bound: 13 000 cycles per unit of 512 records against
+    // 4 400 of decode), no stride tables for pieces that are replayed.  And the LAST part counts as well -- speculatively, up to
+    // where the stream is guessed to end -- instead of idling until the part in front has spoken.
+    uint16_t *const rp_base = (PARTS && nsp > 1u && W.rpos) ? W.rpos + (static_cast<size_t>(2u * f + s) * MAX_SPLIT7 + part) * W.Rmax : nullptr;
+    const __amdgpu_buffer_rsrc_t rsp = frame_rsrc(reinterpret_cast<const uint8_t *>(rp_base), rp_base ? 2u * W.Rmax : 0u);
+    uint32_t rleft = 0u, rnext = 0u, rexit = ENDX_; // (uniform, all threads) entries left to replay, the next one, where the chain enters the piece behind them
+    bool rdead = false;                            // ... or the chain ended behind them
+    constexpr uint32_t ENDX = ENDX_; // hand-off: the stream is over (its last record lies in front, or the chain has ended)
 
     uint8_t *bits = W.bits + static_cast<size_t>(f) * W.Rmax * 64u;
     uint16_t *refs = W.refs + static_cast<size_t>(f) * W.Rmax * 64u;
@@ -715,10 +729,19 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     if (nsp > 1u) {
         const bool empty = m_lo >= m_hi, lastp = part + 1u >= nsp;
         const bool owns0 = !empty && m_lo == 0u; // the part that owns piece 0 (part 0, or the parts in front of this one own nothing)
-        const bool spec = !empty && !lastp && !owns0;
+        // (the last part's pieces are open-ended; its count goes as far as the stream is guessed to reach -- any guess will do: what
+        // lies behind the count is walked by the decode as before)
+        const uint32_t m_chi = lastp ? np_guess : m_hi;
+        // (it pays while the chip has room -- the count is work on top, 8K frames' streams by the hundred run 25 % longer with
+        // it --: the host says so, W.side_lastc, and launches the instance that has it)
+        const bool lastc = LASTC && lastp && !owns0 && rp_base != nullptr && m_chi > m_lo && m_chi != 0xFFFFFFFFu;
+        const bool spec = !empty && !owns0 && (!lastp || lastc);
         uint32_t entry = NOENTRY, cnt1 = 0u, exit1 = ENDX; // where the chain enters piece m_lo; records of the part's pieces; where it enters piece m_hi
         bool dead1 = false;                                // ... it ended inside the part's pieces
-        if (!empty && !lastp) {
+        bool counted = false;
+        if (!empty && (!lastp || lastc)) {
+            counted = true;
+            uint32_t spiece = 0xFFFFFFFFu; // piece of the unit stored last (its first record carries the piece flag)
             // The count: the walker alone, over the part's pieces -- from the stream's first record, or (spec) from SPEC_WARM
             // candidates in front of them, on a byte that is most likely no record at all.
             uint32_t cpiece = spec ? m_lo - 1u : 0u, lst = 0u;
@@ -739,6 +762,13 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                 const uint32_t SU = __builtin_amdgcn_readfirstlane(st4.w);
                 const uint32_t npc = why == 2u ? cpiece + 1u : cpiece;
                 if (cpiece >= m_lo) {
+                    if (rp_base && total) { // the unit's records, for the decode (every thread stores; the walker is on the next unit soon)
+                        const uint16_t *Lc = s_L[lst];
+                        for (uint32_t i = tid; i < total; i += SIDE_T)
+                            if (cnt1 + i < W.Rmax)
+                                rp_base[cnt1 + i] = static_cast<uint16_t>(Lc[i] | ((i == 0u && cpiece != spiece) ? 0x8000u : 0u));
+                        spiece = cpiece;
+                    }
                     cnt1 += total;
                     dead1 = dead1 || why == 3u;
                 }
@@ -749,9 +779,9 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 #endif
                     seg_valid = false;
                 }
-                if (npc > cpiece && npc == m_hi)
+                if (npc > cpiece && npc == m_chi)
                     exit1 = pu - SIDE_HALF;
-                if ((!spec && cnt1 >= R) || why == 3u || npc >= m_hi)
+                if ((!spec && cnt1 >= R) || why == 3u || npc >= m_chi)
                     break;
                 if (npc > cpiece) { // (the walker has left the piece whose strides are in s_T)
                     build_strides(nx, npc);
@@ -765,7 +795,16 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                 lst ^= 1u;
             }
             SIDE_STAMP(20); // count over
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the stored positions are on their way to memory before any barrier below)
         }
+        const auto replay_from_count = [&]() { // the count stands: its records are replayed by the decode
+            if (rp_base && counted && cnt1) {
+                rleft = min(cnt1, W.Rmax);
+                rnext = 0u;
+                rexit = exit1;
+                rdead = dead1;
+            }
+        };
         // The hand-off: what the part in front says, what this part says, where its decode starts.
         uint32_t pn = 0u, pw = first_cand;
         const bool ok = owns0 ? true : ask(pn, pw);
@@ -790,10 +829,13 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             go = false;
         } else if (lastp) {
             run_piece = m_lo, run_cand = owns0 ? first_cand : pw, run_n = pn;
+            if (lastc && pw == entry)
+                replay_from_count();
         } else if (owns0 || pw == entry) { // the count stands: say it, then decode
             const uint32_t upto = pn + cnt1;
             tell(min(upto, R), upto >= R || dead1 || exit1 == ENDX ? ENDX : exit1);
             run_piece = m_lo, run_cand = owns0 ? first_cand : entry, run_n = pn;
+            replay_from_count();
         } else { // the chain enters this part's pieces elsewhere: decode from there, and say afterwards what comes out of it
             run_piece = m_lo, run_cand = pw, run_n = pn;
         }
@@ -822,13 +864,54 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         load_piece(nx, run_piece);
     store_bytes(nx);
     SIDE_STAMP(12); // first piece arrived
-    build_strides(nx, run_piece);
+    if (!rleft) // (a replayed piece needs no stride table)
+        build_strides(nx, run_piece);
     load_piece(nx, run_piece + 1u);
     load_piece(ny, run_piece + 2u);
+    // Replay (wave 0): the next unit's records out of the count's notes instead of a walk.  64 lanes x 8 entries are in
+    // registers, fetched one unit ahead (past the L1: other waves of this workgroup stored them); a unit ends in front of an
+    // entry that opens the next piece, like a walked one.
+    uint4 rq = make_uint4(0u, 0u, 0u, 0u);
+    auto rfetch = [&](uint32_t at) { rq = ld_b128_nt(rsp, 2u * (at + 8u * lane)); }; // (bounds-checked: zeros behind the part's entries)
+    auto replay = [&](uint32_t lst, uint32_t room) {
+        const uint32_t n = min(room, rleft);
+        const uint32_t w4[4] = {rq.x, rq.y, rq.z, rq.w};
+        uint32_t mine = 8u, ment = 0u; // my first entry (behind the unit's first) that opens a piece
+#pragma unroll
+        for (int i = 7; i >= 0; i--) {
+            const uint32_t idx = 8u * lane + static_cast<uint32_t>(i), e = (w4[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+            const bool hit = idx >= 1u && idx < n && (e & 0x8000u) != 0u;
+            mine = hit ? static_cast<uint32_t>(i) : mine;
+            ment = hit ? e : ment;
+        }
+        const unsigned long long m = __ballot(mine != 8u);
+        uint32_t take = n, pu = 0u, why = 1u;
+        if (m) {
+            const uint32_t fl = static_cast<uint32_t>(__builtin_ctzll(m));
+            take = 8u * fl + wave_lane(mine, fl);
+            pu = SIDE_HALF + (wave_lane(ment, fl) & 0x7fffu);
+            why = 2u;
+        } else if (n == rleft) { // the count's last records: what it found behind them
+            if (rdead)
+                why = 3u;
+            else if (rexit != ENDX)
+                why = 2u, pu = SIDE_HALF + rexit;
+        }
+        if (8u * lane < take)
+            *reinterpret_cast<uint4 *>(&s_L[lst][8u * lane]) = make_uint4(rq.x & 0x7fff7fffu, rq.y & 0x7fff7fffu, rq.z & 0x7fff7fffu, rq.w & 0x7fff7fffu);
+        if (lane == 0u)
+            *reinterpret_cast<uint4 *>(s_st[lst]) = make_uint4(pu, take, why, 0u);
+        rfetch(rnext + take);
+    };
     lds_barrier();
     SIDE_STAMP(13);
-    if (wave == 0u) // a short first unit: the decoders start early
-        walk(0u, run_cand, 0u, min(R - run_n, SIDE_LCAP / 4u), true);
+    if (wave == 0u) { // a short first unit: the decoders start early
+        if (rleft) {
+            rfetch(0u);
+            replay(0u, min(R - run_n, SIDE_LCAP / 4u));
+        } else
+            walk(0u, run_cand, 0u, min(R - run_n, SIDE_LCAP / 4u), true);
+    }
     SIDE_STAMP(14);
     while (true) {
         lds_barrier();
@@ -846,7 +929,11 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             n_first = n;
         if (npc > upc && npc == m_hi)
             exitc = pu - SIDE_HALF;
-        const bool moved = upc > bb, build = !last && npc > tb;
+        if (rleft) { // (that unit was replayed: all threads keep count of what is left)
+            rleft -= min(total, rleft);
+            rnext += total;
+        }
+        const bool moved = upc > bb, build = !last && npc > tb && rleft == 0u;
         if (moved) { // the decoders move on to piece bb + 1: every unit of piece bb has been decoded
             store_bytes(nx);
             bb = upc;
@@ -861,8 +948,12 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             lds_barrier();
         SIDE_STAMP(1);
         if (wave == 0u) {
-            if (!last)
-                walk(cur ^ 1u, npc > upc ? pu - SIDE_HALF : pu, SU, min(R - (n + total), SIDE_LCAP), npc > upc);
+            if (!last) {
+                if (rleft)
+                    replay(cur ^ 1u, min(R - (n + total), SIDE_LCAP));
+                else
+                    walk(cur ^ 1u, npc > upc ? pu - SIDE_HALF : pu, SU, min(R - (n + total), SIDE_LCAP), npc > upc);
+            }
             SIDE_STAMP(2);
             if (s == 0u && prev_total) // the unit the decoders finished before the last barrier
                 scan_unit(cur ^ 1u, prev_n, prev_total);
@@ -1278,14 +1369,18 @@ void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st, bool thin)
 {
     const uint32_t n7 = static_cast<uint32_t>(W.n7);
     switch (stage) {
-    case MCRAW_K7_SIDE:
+    case MCRAW_K7_SIDE: {
+        const dim3 sgrid(n7 * (W.nsplit[0] + W.nsplit[1]));
         if (thin)
-            hipLaunchKernelGGL((k7_side<MCRAW_THIN_T, MCRAW_THIN_LPT, MCRAW_THIN_LCAP, MCRAW_THIN_WARM>), dim3(n7 * (W.nsplit[0] + W.nsplit[1])),
-                               dim3(MCRAW_THIN_T), 0, st, W);
+            hipLaunchKernelGGL((k7_side<MCRAW_THIN_T, MCRAW_THIN_LPT, MCRAW_THIN_LCAP, MCRAW_THIN_WARM, true, false>), sgrid, dim3(MCRAW_THIN_T), 0, st, W);
+        else if (W.nsplit[0] + W.nsplit[1] > 2u && W.side_lastc)
+            hipLaunchKernelGGL((k7_side<MCRAW_SIDE_T, MCRAW_SIDE_LPT, MCRAW_SIDE_LCAP, MCRAW_SPEC_WARM, true, true>), sgrid, dim3(MCRAW_SIDE_T), 0, st, W);
+        else if (W.nsplit[0] + W.nsplit[1] > 2u)
+            hipLaunchKernelGGL((k7_side<MCRAW_SIDE_T, MCRAW_SIDE_LPT, MCRAW_SIDE_LCAP, MCRAW_SPEC_WARM, true, false>), sgrid, dim3(MCRAW_SIDE_T), 0, st, W);
         else
-            hipLaunchKernelGGL((k7_side<MCRAW_SIDE_T, MCRAW_SIDE_LPT, MCRAW_SIDE_LCAP, MCRAW_SPEC_WARM>), dim3(n7 * (W.nsplit[0] + W.nsplit[1])),
-                               dim3(MCRAW_SIDE_T), 0, st, W);
+            hipLaunchKernelGGL((k7_side<MCRAW_SIDE_T, MCRAW_SIDE_LPT, MCRAW_SIDE_LCAP, MCRAW_SPEC_WARM, false, false>), sgrid, dim3(MCRAW_SIDE_T), 0, st, W);
         break;
+    }
     case MCRAW_K7_TILES: {
 #ifdef MCRAW_DIAG // timing experiments of the same kernel (see item_decode); not in the product library
         static const int abl = []() {
