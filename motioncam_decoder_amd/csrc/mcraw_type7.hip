@@ -1296,6 +1296,15 @@ __global__ __launch_bounds__(256) void k7_tiles(const Work7 W, uint32_t total, u
     // span -> registers: 16-byte chunks lane, lane+64, ... (ITEM_SPAN + alignment head)
     constexpr uint32_t NV = (PAY_CHUNKS + 63u) / 64u;
     const __amdgpu_buffer_rsrc_t rs = frame_rsrc(I.in, I.len);
+#ifdef MCRAW_K7_LDSDMA
+    // The span from memory INTO the wave's LDS slice (buffer_load_dwordx4 ... lds: lane i's 16 bytes land at base + 16 i, which is
+    // the slice's own layout), no registers and no ds_write pass in between.  MEASURED, not shipped: docs/lab_notes.md, round 5.
+#pragma unroll
+    for (uint32_t c = 0; c < NV; c++)
+        if (ABL != 3 && lane + 64u * c < I.n16)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(s_pay[wave] + 1024u * c), 16,
+                                                     static_cast<int>(I.base16 + (lane + 64u * c) * 16u), 0, 0, 2);
+#else
     uint4 v[NV];
 #pragma unroll
     for (uint32_t c = 0; c < NV; c++) {
@@ -1303,6 +1312,7 @@ __global__ __launch_bounds__(256) void k7_tiles(const Work7 W, uint32_t total, u
         if (ABL != 3 && lane + 64u * c < I.n16)
             v[c] = ld_b128_nt(rs, I.base16 + (lane + 64u * c) * 16u);
     }
+#endif
     uint32_t b = 0, r = 0;
     if (I.valid && lane < ITEM_BLOCKS && I.g * ITEM_BLOCKS + lane < I.nblk) {
         b = W.bits[I.meta + lane];
@@ -1331,12 +1341,14 @@ __global__ __launch_bounds__(256) void k7_tiles(const Work7 W, uint32_t total, u
         s_blk[wave][lane] = (I.head + ex) | (cls7_of(b) << 16);
         s_ref[wave][lane] = static_cast<uint16_t>(r);
     }
+#ifndef MCRAW_K7_LDSDMA
     uint4 *pay4 = reinterpret_cast<uint4 *>(s_pay[wave]);
 #pragma unroll
     for (uint32_t c = 0; c < NV; c++)
         if (lane + 64u * c < I.n16)
             pay4[lane + 64u * c] = v[c];
-    __syncthreads();
+#endif
+    __syncthreads(); // (with loads that write the LDS in flight the compiler waits for them here: vmcnt(0) in front of the barrier)
 
 #pragma unroll
     for (uint32_t q = 0; q < ITEM_TILES / 4u; q++)

@@ -1,4 +1,4 @@
-"""GPU (-m gpu): k7_side with every side stream cut into parts (round 4).
+"""GPU (-m gpu): k7_side with every side stream cut into parts (round 4; round 5: the parts' decode replays their count).
 
 A long side stream of a small batch is resolved by several workgroups: each owns a range of the stream's 32 KiB pieces, counts
 the records of its pieces with the walker alone (from a speculative start, for the parts in the middle), is told by the part in
@@ -31,6 +31,13 @@ def _run(env):
 @pytest.mark.parametrize("parts", [2, 4])
 def test_all_type7_suites_with_every_side_stream_in_parts(parts):
     _run(dict(os.environ, MCRAW_SIDE_SPLIT=str(parts)))
+
+
+def test_parts_whose_last_one_does_not_count():
+    """Round 5: a part's decode replays the record positions its count left behind, and the LAST part of a stream counts too while
+    the chip has room for it (the library decides by the number of workgroups; the suites above run with it, their batches are
+    small).  Here the other instance of the kernel: the last part waits for the part in front and follows the chain itself."""
+    _run(dict(os.environ, MCRAW_SIDE_SPLIT="3,2", MCRAW_SIDE_LASTC="0"))
 
 
 def _build(tmp_path, flag):

@@ -43,7 +43,12 @@ def main():
         old = {k: os.environ.get(k) for k, _ in kv}
         for k, val in kv:
             os.environ[k] = val
+        lib = dict(kv).get("LIB")  # LIB=<name>: this variant's context comes from lib/libmcraw_hip_<name>.so (another build, same process)
+        if lib:
+            os.environ["MCRAW_LIB_PATH"] = os.path.join(ROOT, "motioncam_decoder_amd", "lib", "libmcraw_hip_%s.so" % lib)
+        M._lib = None  # (every variant binds its own handle: Context keeps the one it was created with)
         ctx = M.Context(0)
+        os.environ.pop("MCRAW_LIB_PATH", None)
         for k, _ in kv:
             if old[k] is None:
                 del os.environ[k]
