@@ -204,32 +204,34 @@ __device__ __forceinline__ void post_pack12_lean(const uint32_t p[4], uint32_t o
 }
 
 // The same for B = 10 or 14 bits per sample: 8 samples -> B bytes of an MSB-first B-bit stream (TIFF/DNG
-// BitsPerSample B, FillOrder 1), samples above 2^B - 1 saturate.  The stream is assembled in four big-endian
-// words (all shifts are compile-time constants) and byte-swapped into memory order.
-template <int B>
+// BitsPerSample B, FillOrder 1), samples above 2^B - 1 saturate unless the caller knows that none is (`CLAMP`).
+// Round 5: a sample PAIR (a, b) becomes a << B | b with one v_dot2_u32_u16, like the 12-bit form's; the four 2B-bit groups are
+// cut into big-endian words with v_lshl_or_b32 / v_or3_b32 and byte-swapped into memory order: 14 / 15 vector instructions where
+// the per-sample shifts of round 2 took 27 / 31.
+template <int B, bool CLAMP>
 __device__ __forceinline__ void post_pack_be(const uint32_t p[4], uint32_t o[4])
 {
+    static_assert(B == 10 || B == 14, "strip rows of 10 or 14 bits per sample");
     constexpr uint32_t MAXV = (1u << B) - 1u;
-    uint32_t s[8];
+    uint32_t g[4]; // a << B | b: 20 / 28 bits
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        const uint32_t c = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(mcraw_u16x2, p[i]),
-                                                                                  __builtin_bit_cast(mcraw_u16x2, MAXV | (MAXV << 16))));
-        s[2 * i] = c & 0xffffu;
-        s[2 * i + 1] = c >> 16;
+        uint32_t c = p[i];
+        if (CLAMP)
+            c = __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(mcraw_u16x2, c), __builtin_bit_cast(mcraw_u16x2, MAXV | (MAXV << 16))));
+        g[i] = __builtin_amdgcn_udot2(__builtin_bit_cast(mcraw_u16x2, c), __builtin_bit_cast(mcraw_u16x2, 0x00010000u | (1u << B)), 0u, false);
     }
-    uint32_t w[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int off = k * B, wi = off >> 5, sh = 32 - (off & 31) - B;
-        if (sh >= 0) {
-            w[wi] |= s[k] << sh;
-        } else {
-            w[wi] |= s[k] >> (-sh);
-            w[wi + 1] |= s[k] << (32 + sh);
-        }
+    uint32_t w[4];
+    if (B == 10) { // 80 bits: g0:20 g1:20 g2:20 g3:20
+        w[0] = (g[0] << 12) | (g[1] >> 8);
+        w[1] = (g[1] << 24) | (g[2] << 4) | (g[3] >> 16);
+        w[2] = g[3] << 16;
+        w[3] = 0u;
+    } else { // 112 bits: g0:28 g1:28 g2:28 g3:28
+        w[0] = (g[0] << 4) | (g[1] >> 24);
+        w[1] = (g[1] << 8) | (g[2] >> 20);
+        w[2] = (g[2] << 12) | (g[3] >> 16);
+        w[3] = g[3] << 16;
     }
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -286,18 +288,21 @@ __device__ __forceinline__ void post_store_bytes(uint8_t *dst, const uint32_t *o
 // form) / 16-byte friendly (16-bit form).
 // PB: bits per output sample, a compile-time property of the kernel instance (16, 12, 10 or 14) so that every
 // instance carries one packing only.
-// `lean` (12-bit strips only, wave-uniform): the samples need neither the black levels (they are off the references already)
+// `lean` (strip rows, wave-uniform): the samples need neither the black levels (they are off the references already)
 // nor the clamp.
 template <bool NT, int PB>
 __device__ __forceinline__ void post_store8(uint16_t *out, const Post &post, uint32_t width, uint32_t y, uint32_t x,
                                             uint32_t p[4], uint32_t n, bool quick, bool lean = false)
 {
-    if (!(PB == 12 && lean) && (post.mode & POST_BLACK))
+    if (!(PB != 16 && lean) && (post.mode & POST_BLACK))
         post_black(p, post, y);
     if (PB == 10 || PB == 14) { // 10 / 14 bytes per 8 samples; rows start on even bytes when width % 8 == 0
         constexpr uint32_t B = PB == 10 ? 10u : 14u;
         uint32_t o[4];
-        post_pack_be<(PB == 10 ? 10 : 14)>(p, o);
+        if (lean)
+            post_pack_be<(PB == 10 ? 10 : 14), false>(p, o);
+        else
+            post_pack_be<(PB == 10 ? 10 : 14), true>(p, o);
         uint8_t *dst = reinterpret_cast<uint8_t *>(out) + static_cast<size_t>(y) * post_row_bytes(width, post.mode) + (x >> 3) * B;
         if (quick && n == 8u) {
             typedef uint32_t u32x2_u __attribute__((ext_vector_type(2), aligned(2)));
@@ -366,6 +371,51 @@ __device__ __forceinline__ void post_store8(uint16_t *out, const Post &post, uin
             if (i < n)
                 gptr<uint16_t>(dst)[i] = static_cast<uint16_t>(p[i >> 1] >> (16u * (i & 1u)));
     }
+}
+
+// 10- and 14-bit strip rows, the interior of a frame (round 5).  A lane's 8 samples are 10 / 14 bytes; stored as 8 + 2 / 12 + 2
+// bytes, a wave's two store instructions touch every 64-byte line of the row piece twice (counters: 2.0 x the write requests
+// between L1 and L2 that the bytes need; the 14-bit kernel 1.20 ms where the plain one takes 0.98 for more bytes).  Instead every
+// lane stores ONE 16-byte piece: its own bytes and the first 6 / 2 bytes of the row's NEXT 8 samples, fetched from the lane that
+// holds them (`src`; ds_bpermute: the LDS crossbar, no memory) -- two lanes write those bytes, both write the same values, so no
+// order matters.  A lane whose next 8 samples are not decoded in this pass (`has_next` false: the last piece of the pass's last
+// tile, or of the frame's last tile column) stores the last 6 / 2 bytes of the PREVIOUS 8 samples in front of its own instead
+// (four lanes down in its group of eight: one DPP row shift).  One store instruction per row for the whole wave: a wave's
+// instruction that only a few lanes take costs the memory pipeline as much as a full one (the same exchange with the odd lanes
+// on the old 12 + 2 form: 1.38 ms).
+// All 64 lanes of the wave must be here (the caller checks), the row piece whole and inside the frame.
+template <int PB>
+__device__ __forceinline__ void post_store8_merged(uint16_t *out, const Post &post, uint32_t width, uint32_t y, uint32_t x, uint32_t p[4],
+                                                   bool lean, uint32_t src, bool has_next)
+{
+    static_assert(PB == 10 || PB == 14, "strip rows whose 8-sample pieces are no dword multiple");
+    constexpr uint32_t B = PB;
+    if (!lean && (post.mode & POST_BLACK))
+        post_black(p, post, y);
+    uint32_t o[4];
+    if (lean)
+        post_pack_be<PB, false>(p, o);
+    else
+        post_pack_be<PB, true>(p, o);
+    const auto next = [&](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>(src * 4u), static_cast<int>(v))); };
+    const auto prev = [&](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114, 0xf, 0xf, true)); }; // row_shr:4: lane - 4
+    uint8_t *dst = reinterpret_cast<uint8_t *>(out) + static_cast<size_t>(y) * post_row_bytes(width, post.mode) + (x >> 3) * B;
+    typedef uint32_t u32x4_u __attribute__((ext_vector_type(4), aligned(2)));
+    u32x4_u v;
+    if (PB == 10) {
+        const uint32_t n0 = next(o[0]), n1 = next(o[1]), m1 = prev(o[1]), m2 = prev(o[2]);
+        const u32x4_u fwd = {o[0], o[1], (o[2] & 0xffffu) | (n0 << 16), (n0 >> 16) | (n1 << 16)};                               // at dst
+        const u32x4_u back = {m1, (m2 & 0xffffu) | (o[0] << 16), (o[0] >> 16) | (o[1] << 16), (o[1] >> 16) | (o[2] << 16)};     // at dst - 6
+        v = has_next ? fwd : back;
+        dst -= has_next ? 0 : 6;
+    } else {
+        const uint32_t n0 = next(o[0]), m3 = prev(o[3]);
+        const u32x4_u fwd = {o[0], o[1], o[2], (o[3] & 0xffffu) | (n0 << 16)};                                                   // at dst
+        const u32x4_u back = {(m3 & 0xffffu) | (o[0] << 16), (o[0] >> 16) | (o[1] << 16), (o[1] >> 16) | (o[2] << 16), (o[2] >> 16) | (o[3] << 16)}; // at dst - 2
+        v = has_next ? fwd : back;
+        dst -= has_next ? 0 : 2;
+    }
+    *gptr<u32x4_u>(dst) = v;
 }
 
 } // namespace mcraw

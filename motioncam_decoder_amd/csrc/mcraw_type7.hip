@@ -1101,7 +1101,7 @@ struct ItemS {
     uint32_t len;
     uint16_t *out;
     size_t meta;         // index of the group's first entry in W.bits / W.refs
-    uint32_t lean;       // (12-bit strip rows) no sample of the item can reach 4096, black levels are off its references
+    uint32_t lean;       // (strip rows) no sample of the item can reach 2^bits, black levels are off its references
 };
 
 __device__ __forceinline__ ItemS item_scalars(const Work7 &W, uint32_t item, uint32_t first_frame, uint32_t class_groups)
@@ -1173,7 +1173,7 @@ __device__ __forceinline__ void store_px8(const ItemS &I, const Post &post, uint
     if (y >= static_cast<uint32_t>(I.rows) || x >= width)
         return;
     if (POST) { // black levels / 12-bit strip rows (mcraw_dev.h)
-        post_store8<NT, POST>(I.out, post, width, y, x, p, min(8u, width - x), I.fast != 0u, POST == 12 && I.lean != 0u);
+        post_store8<NT, POST>(I.out, post, width, y, x, p, min(8u, width - x), I.fast != 0u, POST != 16 && I.lean != 0u);
         return;
     }
     uint16_t *dst = I.out + static_cast<size_t>(y) * static_cast<size_t>(width) + x;
@@ -1217,6 +1217,7 @@ __device__ __forceinline__ void item_decode(const ItemS &I, const Post &post, ui
     const uint32_t tile = I.g * ITEM_TILES + tt;
     if (!I.valid || tile * 4u >= I.nblk) // uniform over the 16 lanes of a tile
         return;
+    const bool whole = __ballot(true) == ~0ull; // (10- / 14-bit strips: the whole wave is here, lanes can fetch from each other)
     const uint32_t ty = tile / I.tilesX, tx = tile - ty * I.tilesX;
 
     const uint32_t bi = 4u * tt + 2u * r;
@@ -1263,6 +1264,22 @@ __device__ __forceinline__ void item_decode(const ItemS &I, const Post &post, ui
     }
     const uint32_t x = 64u * tx + 8u * (2u * (k & 3u) + (k >> 2));
     const uint32_t y = 4u * ty + r;
+    if (POST == 14) { // (10-bit rows the same way -- 16-byte stores 10 bytes apart, six bytes written twice -- are 1.5 % SLOWER than 8 + 2)
+        // the interior of the frame: one 16-byte store per lane and row (post_store8_merged).  The row's next 8 samples: lane
+        // k + 4 for the first four lanes of a (tile, row pair) group, k - 3 for the next three, and the first lane of the next
+        // tile's group for the last one -- when that tile is the neighbour on the right and decoded in this pass (else the
+        // lane's store reaches back into the previous 8 samples instead: lane k - 4, the group's fourth).
+        const bool in = I.fast != 0u && y + 2u < static_cast<uint32_t>(I.rows) && x + 8u <= static_cast<uint32_t>(I.width);
+        if (whole && __ballot(!in) == 0ull) {
+            const uint32_t lane = threadIdx.x & 63u;
+            const bool has_next = k != 7u || ((tt & 3u) != 3u && tx + 1u < I.tilesX);
+            const uint32_t src = k < 4u ? lane + 4u : k < 7u ? lane - 3u : has_next ? lane + 9u : lane;
+            const uint32_t width = static_cast<uint32_t>(I.width);
+            post_store8_merged<14>(I.out, post, width, y, x, p0, I.lean != 0u, src, has_next);
+            post_store8_merged<14>(I.out, post, width, y + 2u, x, p1, I.lean != 0u, src, has_next);
+            return;
+        }
+    }
     store_px8<NT, POST>(I, post, y, x, p0);
     store_px8<NT, POST>(I, post, y + 2u, x, p1);
 }
@@ -1318,10 +1335,10 @@ __global__ __launch_bounds__(256) void k7_tiles(const Work7 W, uint32_t total, u
         b = W.bits[I.meta + lane];
         r = W.refs[I.meta + lane];
     }
-    if (POST == 12) {
-        // 12-bit strips (round 4): a block is one colour plane of its tile (block k of a tile: row parity k >> 1, column parity
+    if (POST == 12 || POST == 10 || POST == 14) {
+        // strip rows (round 4: 12 bits; round 5: 10 and 14 too): a block is one colour plane of its tile (block k of a tile: row parity k >> 1, column parity
         // k & 1, RawData.cpp:581-593), so its black level is ONE value and can come off its reference -- if the reference is not
-        // below it --, and no sample of the block can reach 4096 when reference - black + (2^storage width - 1) does not: then
+        // below it --, and no sample of the block can reach 2^POST when reference - black + (2^storage width - 1) does not: then
         // neither the saturating subtraction nor the clamp of the strip stage can change a sample, and the item's stores skip
         // both (16 of the stage's ~ 54 vector instructions per lane and call).  One ballot per item decides.
         const uint32_t bl2 = (W.post.mode & POST_BLACK) ? ((lane & 2u) ? W.post.black23 : W.post.black01) : 0u;
@@ -1329,7 +1346,7 @@ __global__ __launch_bounds__(256) void k7_tiles(const Work7 W, uint32_t total, u
         const uint32_t sw = b <= 6u ? b : b <= 8u ? 8u : 10u; // storage width of the block's residuals (RawData.cpp:424-458)
         const bool real = I.valid && lane < ITEM_BLOCKS && I.g * ITEM_BLOCKS + lane < I.nblk;
         // (r + 2^sw - 1 <= 65535: the reference add of the decode does not wrap either, RawData.cpp:581-593)
-        const bool fits = !real || (b <= 10u && r >= bl && r - bl + ((1u << sw) - 1u) <= 4095u && r + ((1u << sw) - 1u) <= 65535u);
+        const bool fits = !real || (b <= 10u && r >= bl && r - bl + ((1u << sw) - 1u) <= (1u << POST) - 1u && r + ((1u << sw) - 1u) <= 65535u);
         I.lean = __ballot(!fits) == 0ull ? 1u : 0u;
         if (I.lean)
             r -= bl;
