@@ -4,12 +4,12 @@
 # Per workload of the bench line: rocprofv3 --kernel-trace --stats; for nat, u and legacy also the HBM traffic counters
 # (FETCH_SIZE and WRITE_SIZE in separate passes, counters with --kernel-trace only) and one pass of SQ counters.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-for W in ${WORKLOADS:-nat u legacy mixed64 post12 config5}; do
+for W in ${WORKLOADS:-nat u legacy mixed64 post12 post10 post14 config5}; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$W/stats" -- python3 "$R/tools/prof_workload.py" $W 20 > "$OUT/$W.stats.log" 2>&1
 done
 for W in nat u legacy; do

@@ -45,7 +45,7 @@ def main():
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
     summary = {"tag": tag, "made_by": "tools/profile_round.sh (rocprofv3 ... -- python3 tools/prof_workload.py <workload> <launches>)", "workloads": {}}
-    for w in ("nat", "u", "legacy", "mixed64", "post12", "config5"):
+    for w in ("nat", "u", "legacy", "mixed64", "post12", "post10", "post14", "config5"):
         info = last_json(os.path.join(src, w + ".stats.log"))
         stats = sorted(glob.glob(os.path.join(src, w, "stats", "**", "*_kernel_stats.csv"), recursive=True), key=os.path.getmtime)
         entry = {"run": info}
