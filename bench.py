@@ -578,12 +578,14 @@ def post_stage(torch, ctx, M, L, wl, steps, bits=12):
             ok = ok and np.array_equal(got, L.oracle_post(wl.pairs[i % d][0], black, bits=bits))
         out_b = wl.frames * wl.h * rb
         ach = (wl.in_bytes + out_b) / (tile_ms / max(tile_n, 1) * 1e-3) / 1e9
-        bound = {12: "the memory pipeline's instruction rate: two stores per lane and call like the plain kernel, 12 instead of 16 bytes each "
-                     "(768 B per wave instruction); the stage's arithmetic is 14 vector instructions per lane and call for items "
-                     "that take the lean path (DESIGN 3)",
-                 10: "four stores per lane and call (8 + 2 bytes per row piece at 2-byte alignment) and the clamp / shift arithmetic of every "
-                     "sample (these 12-bit frames saturate at 1023 on the way, like the oracle's)",
-                 14: "four stores per lane and call (12 + 2 bytes per row piece at 2-byte alignment) and the shift arithmetic of every sample"}[bits]
+        bound = {12: "vector issue and the memory pipeline's instruction rate: two stores per lane and call like the plain kernel, 12 instead of 16 "
+                     "bytes each, every 64-byte line written once (L1->L2 write requests = bytes / 64, profiles/ and docs/lab_notes.md); the "
+                     "stage's arithmetic is 14 vector instructions per lane and call for items that take the lean path (DESIGN 3)",
+                 10: "four stores per lane and call (8 + 2 bytes per row piece at 2-byte alignment): every line of a row piece is touched by two "
+                     "instructions, 2.0 x the L1->L2 write requests its bytes need; the merged form (16-byte stores 10 bytes apart) writes six "
+                     "bytes twice and is slower still (these 12-bit frames saturate at 1023 on the way, like the oracle's)",
+                 14: "ONE 16-byte store per lane and row in the frame's interior (round 5: the next row piece's first two bytes are fetched "
+                     "across lanes and written by both lanes; 12 + 2 bytes per lane, round 4's form, touched every line twice: 1.24 -> 1.15 ms)"}[bits]
         return {"stage": "black levels %s subtracted, rows as %d-bit strips" % (black, bits), "ms_per_step": round(1e3 * el / steps, 4),
                 "mpix_s": round(wl.pixels * steps / el / 1e6, 1), "tiles_ms_per_launch": round(tile_ms / max(tile_n, 1), 4),
                 "algorithmic_bytes_per_launch": wl.in_bytes + out_b, "achieved_gbs": round(ach, 1),
@@ -638,7 +640,7 @@ def legacy_leg(torch, ctx, M, L, dev, n=32, w=4000, h=3000, nbits=12, sigma=12.0
     out["algorithmic_bytes_per_batch"] = byts
     if kms["k6_decode"] > 0:
         out["frac"] = round(byts / (kms["k6_decode"] * 1e-3) / 1e9 / 8000.0, 4)
-    for tag in ("r04", "r03", "r02"):
+    for tag in ("r05", "r04", "r03", "r02"):
         try:
             with open(os.path.join(ROOT, "profiles", tag + "_legacy_traffic.json")) as f:
                 tj = json.load(f)
