@@ -873,6 +873,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    import motioncam_decoder_amd as M
+    # The library's context BEFORE this process's first torch (or RCCL) operation on the GPU, as in a C++ host that has neither: HIP
+    # streams of one priority share four hardware queues, and which of the context's streams end up beside each other -- hence how
+    # well the three lanes of its host-memory pipeline overlap, pcie_inclusive below: 2 690 or 2 500 UHD frames/s -- depends on the
+    # queues that exist when it is created (tools/pcie_order.py, docs/lab_notes.md).  (Only where the library is built already.)
+    ctx = M.Context(local) if os.path.exists(M.lib_path()) else None
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched by torch.distributed.run
     if use_dist:
         if args.dist_backend == "nccl":
@@ -880,12 +886,7 @@ def main():
         else:
             dist_mod.init_process_group(args.dist_backend)
     comm = benchlib.Comm(dist_mod, dev if args.dist_backend == "nccl" else "cpu")
-    ranks_seen = int(round(comm.sum([1.0])[0]))  # every rank that takes part says so: the line's n_gpus is counted, not assumed
-    if ranks_seen != args.gpus:
-        print("bench.py: %d rank(s) took part, --gpus %d" % (ranks_seen, args.gpus), file=sys.stderr)
-        return 2
 
-    import motioncam_decoder_amd as M
     from motioncam_decoder_amd import build as B
     from motioncam_decoder_amd import shard
     if local == 0:
@@ -894,8 +895,13 @@ def main():
         B.build_synth()
     comm.barrier()
     L = synth_lib()
-    ctx = M.Context(local)
+    if ctx is None:
+        ctx = M.Context(local)
     ctx.profile(True)
+    ranks_seen = int(round(comm.sum([1.0])[0]))  # every rank that takes part says so: the line's n_gpus is counted, not assumed
+    if ranks_seen != args.gpus:
+        print("bench.py: %d rank(s) took part, --gpus %d" % (ranks_seen, args.gpus), file=sys.stderr)
+        return 2
 
     dists = [args.dist] + ([] if args.no_also else [("u" if args.dist == "nat" else "nat")])  # (at every N: a SCALE line is as complete as the N = 1 line)
     results = {}
