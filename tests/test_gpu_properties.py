@@ -58,7 +58,11 @@ def test_full_batch_order_and_repeat_invariance(gpu_ctx):
 def test_frame_checksums_do_not_depend_on_the_gpu_count(gpu_ctx):
     """BASELINE config 5: 7680x4320 frames sharded over 1, 2, 4, 8 ranks (frame i -> rank i mod world,
     motioncam_decoder_amd/shard.py); the per-frame checksums of the job must be the same for every world
-    size.  One GPU plays the ranks one after another."""
+    size.  One GPU plays the ranks one after another: what this proves is the PARTITION RULE (every frame decoded exactly
+    once, by the rank the rule names, to the same pixels whatever the world size) -- not that eight physical devices give the
+    same bytes; no test on a one-GPU box can.  `bench.py --gpus N` carries the check to real devices: its line holds a digest of
+    the job's per-frame checksums that must equal the N = 1 line's (`frame_checksums`; compared for two ranks on cuda:0 in
+    test_bench_multi_rank_path_on_one_gpu below)."""
     import torch
     import motioncam_decoder_amd as M
     from motioncam_decoder_amd import shard
