@@ -152,7 +152,7 @@ struct Decoder::Impl {
 
     // Pinned staging reused across loadFrames() calls.  Every slot has one slice per pool member (GPU),
     // allocated by that member's own thread: on the NUMA node of its GPU.
-    static constexpr int kOutSlots = 4; // decoded chunks whose copy-out may still be running
+    static constexpr int kOutSlots = 2; // decoded chunks whose copy-out may still be running (four until the output vectors got huge pages: the copy-out keeps up now)
     static constexpr int kInSlots = 3;  // (loadFramesInto) chunk being read, chunk queued, chunk finishing on the GPU
     struct Slice {
         uint8_t *p = nullptr;
