@@ -100,6 +100,16 @@ def make_frames(L, seeds, w, h, nbits, dist, sigma):
         return list(ex.map(one, seeds))
 
 
+def frame_seeds(gidx, distinct, frames, config):
+    """Seeds of the images a rank generates: global frame g holds image g mod `distinct` (seed 1000 * config + g mod distinct)
+    whatever the world size; the rank's local frame i is global frame gidx[i] = rank + i * world, and the images it needs repeat
+    with period d = distinct / gcd(world, distinct), so that seeds[i % d] is local frame i's."""
+    D = max(1, distinct)
+    stride_g = (gidx[1] - gidx[0]) if len(gidx) > 1 else 1
+    d = max(1, min(D // math.gcd(stride_g, D), frames))
+    return [1000 * config + (g % D) for g in gidx[:d]]
+
+
 class Workload:
     """A batch of `frames` type-7 frames resident in HBM (inputs at distinct addresses)."""
 
@@ -111,11 +121,8 @@ class Workload:
         # What a frame holds depends on its GLOBAL index alone -- frame g is image (g mod distinct) -- so that the per-frame
         # checksums of a job do not depend on how many ranks share it.  Local frame i is global frame rank + i * world; the
         # images a rank needs repeat with period d = distinct / gcd(world, distinct): pairs[i % d] is local frame i's.
-        D = max(1, args.distinct)
-        stride_g = (gidx[1] - gidx[0]) if len(gidx) > 1 else 1
-        d = max(1, min(D // math.gcd(stride_g, D), self.frames))
         self.gidx = list(gidx[: self.frames])
-        seeds = [1000 * args.config + (g % D) for g in gidx[:d]]
+        seeds = frame_seeds(gidx, args.distinct, self.frames, args.config)
         self.pairs = make_frames(L, seeds, self.w, self.h, args.nbits, dist, args.sigma)
         lens = [p[1].size for p in self.pairs]
         d = len(self.pairs)

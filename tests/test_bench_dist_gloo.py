@@ -94,3 +94,36 @@ def test_numa_helpers_do_not_need_a_gpu():
     finally:
         del os.environ["HIP_VISIBLE_DEVICES"]
     assert benchlib.bind_to_gpu_numa(63) is None
+
+
+def test_bench_frame_content_does_not_depend_on_the_world_size():
+    """bench.py: global frame g of the job holds image g mod 48 at every --gpus N (so that the digest of the per-frame checksums,
+    `frame_checksums`, is one value for the N = 1, 2, 4, 8 lines): every rank's local frame i must map to that image."""
+    import importlib.util
+    from motioncam_decoder_amd import shard
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    for distinct, frames in ((48, 240), (4, 24), (7, 30), (48, 5)):
+        for world in (1, 2, 3, 4, 8):
+            for rank in range(world):
+                gidx = shard.shard_frames(world * frames, rank, world)
+                seeds = b.frame_seeds(gidx, distinct, frames, 3)
+                d = len(seeds)
+                assert 1 <= d <= min(distinct, frames)
+                for i, g in enumerate(gidx[:frames]):
+                    assert seeds[i % d] == 3000 + g % distinct, (distinct, frames, world, rank, i)
+
+
+def test_bench_profile_helpers_read_the_committed_profiles():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    t, src = b.traffic_from_profile("3840x2160_12bit_240_nat", 6168487920)
+    assert t and 1.0 <= t / 6168487920 < 1.05 and "traffic.json" in src
+    t2, src2 = b.traffic_from_profile("7680x4320_12bit_120_nat", 12343588800)      # no --pmc pass of this geometry: the ratio
+    assert t2 and abs(t2 / 12343588800 - t / 6168487920) < 1e-9 and "ratio" in src2
+    assert b.traffic_from_profile("1x1_12bit_1_other", 100) == (None, None)
+    ms, path = b.profile_launch_ms("nat")
+    assert ms and 0.5 < ms < 2.0 and path.startswith("profiles/r")
