@@ -185,3 +185,24 @@ def test_post_stage_large_batch_under_load(gpu_ctx, typ, bits, bright):
                                          (typ, bits, rnd, i, bad.shape[0], bad[:4].tolist()))
     finally:
         gpu_ctx.set_post()
+
+
+def test_14_bit_rows_one_store_per_lane_every_neighbour_case(gpu_ctx):
+    """Round 5: in the interior of a frame a lane writes its 14 bytes of a 14-bit row AND the first two bytes of the row's next
+    8 samples (fetched across lanes), or -- when that piece is not decoded in the same pass: the last tile of a pass, the
+    frame's last tile column -- the last two bytes of the previous piece in front of its own.  Geometries that put every case
+    on every position: one to nine tile columns (a pass holds four tiles: rows wrap inside passes), heights that end
+    inside a tile row, widths off the 64 grid (their cropped tiles take the old path), natural content (lean items) and
+    noise with raw blocks (not lean), with and without black levels, dword-misaligned buffers."""
+    rng = np.random.default_rng(77)
+    items = []
+    for w in (64, 128, 192, 256, 320, 448, 576, 200, 1000):
+        for h in (4, 10, 36):
+            img = rng.integers(0, 1 << 14, size=(h, w), dtype=np.uint16) if (w // 64 + h) % 2 else L.natural_image_np(w, h, 12, 12.0, w + h)
+            items.append((7, w, h, L.encode7(img), img))
+    for black in (None, [256, 256, 256, 256], [60, 64, 68, 4000]):
+        for mis in (0, 2):
+            got = _run(gpu_ctx, items, black, False, misalign=mis, bits=14)
+            for (typ, w, h, buf, img), g in zip(items, got):
+                want = L.oracle_post(img, black, bits=14)
+                assert np.array_equal(g, want), (w, h, black, mis, np.argwhere(g != want)[:3])
