@@ -17,7 +17,11 @@
 #include <cerrno>
 #include <chrono>
 #include <cstdlib>
+#include <condition_variable>
+#include <functional>
 #include <future>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <cstring>
 #include <unistd.h>
@@ -126,6 +130,80 @@ bool loadAudioChunkAt(const FileReader &r, const Locator &o, AudioChunk &out)
 
 } // namespace
 
+// A few host threads that stay (per-frame callers: starting eight threads for every frame's copy-out cost more than the copy).
+// run(n, fn) calls fn(i) for i in [0, n) on the workers and the calling thread and returns when all are done; one run() at a time.
+class WorkerPool {
+public:
+    explicit WorkerPool(unsigned workers)
+    {
+        for (unsigned t = 0; t < workers; t++)
+            threads_.emplace_back([this]() { loop(); });
+    }
+    ~WorkerPool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        for (std::thread &t : threads_)
+            t.join();
+    }
+    void run(size_t n, const std::function<void(size_t)> &fn)
+    {
+        if (n == 0)
+            return;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            fn_ = &fn;
+            n_ = n;
+            next_.store(0);
+            busy_ = threads_.size();
+            gen_++;
+        }
+        cv_.notify_all();
+        for (size_t i = next_.fetch_add(1); i < n; i = next_.fetch_add(1))
+            fn(i);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_.wait(lk, [this]() { return busy_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    void loop()
+    {
+        unsigned long long seen = 0;
+        for (;;) {
+            const std::function<void(size_t)> *fn;
+            size_t n;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&]() { return quit_ || gen_ != seen; });
+                if (quit_)
+                    return;
+                seen = gen_;
+                fn = fn_;
+                n = n_;
+            }
+            for (size_t i = next_.fetch_add(1); i < n; i = next_.fetch_add(1))
+                (*fn)(i);
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (--busy_ == 0)
+                    done_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(size_t)> *fn_ = nullptr;
+    size_t n_ = 0, busy_ = 0;
+    std::atomic<size_t> next_{0};
+    unsigned long long gen_ = 0;
+    bool quit_ = false;
+};
+
 struct Decoder::Impl {
     explicit Impl(FILE *f) : reader(f) {}
 
@@ -159,11 +237,31 @@ struct Decoder::Impl {
         size_t cap = 0;
     };
     std::vector<Slice> pinIn[kInSlots], pinOut[kOutSlots]; // [slot][member]
+    // Read-ahead for per-frame callers (the reference's own loop, example.cpp:187-195 over lib/Decoder.cpp:184-235, asks for one
+    // frame after the other in timestamp order): while frame i is on the GPU and being copied out, the payload of the frame that
+    // follows it in the index is read into one of two pinned buffers of its own; the next loadFrame() decodes from there.
+    struct Ahead {
+        Slice buf[2];
+        int cur = 0;             // buffer the pending read goes to
+        bool armed = false;
+        Timestamp ts = 0;
+        int64_t payload = 0;
+        uint32_t size = 0;
+        std::future<bool> done;
+    } ahead;
+    std::unique_ptr<WorkerPool> workers; // copy-out of a lone frame, sliced over the threads; made on first use
     mcraw_pool *pool = nullptr; // the GPUs this decoder shards its batches over (frame i of a batch -> member i mod G)
     std::vector<int> devices;   // empty: MCRAW_DEVICES / MCRAW_DEVICE / the current device
 
     void releaseGpu()
     {
+        if (ahead.done.valid())
+            (void)ahead.done.get(); // (a read into a pinned buffer may still be under way)
+        ahead.armed = false;
+        for (Slice &b : ahead.buf) {
+            mcraw_host_free(b.p);
+            b = Slice{};
+        }
         for (auto &slot : pinIn)
             for (Slice &s : slot)
                 mcraw_host_free(s.p);
@@ -621,7 +719,9 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
                 dst.resize(bytes);
             const uint8_t *src = reinterpret_cast<const uint8_t *>(f.out);
             const size_t slice = (bytes + hostThreads - 1) / hostThreads;
-            parallelFor(hostThreads, hostThreads, [&](size_t t) {
+            if (!I.workers)
+                I.workers.reset(new WorkerPool(hostThreads - 1));
+            I.workers->run(hostThreads, [&](size_t t) {
                 const size_t lo = std::min(bytes, t * slice), hi = std::min(bytes, lo + slice);
                 std::memcpy(dst.data() + lo, src + lo, hi - lo);
             });
@@ -637,7 +737,47 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
     const auto tStart = now();
     std::vector<size_t> written(n);
     std::vector<int32_t> status(n);
-    std::future<void> reading = std::async(std::launch::async, readChunk, size_t(0));
+    // one frame asked for: was it read ahead?  (whatever the answer, the pending read is over before its buffer is looked at)
+    bool aheadHit = false;
+    if (I.ahead.done.valid()) {
+        const bool ok = I.ahead.done.get();
+        aheadHit = ok && I.ahead.armed && n == 1 && I.ahead.ts == timestamps[0] && I.ahead.payload == spans[0].payload &&
+                   I.ahead.size == frames[0].len;
+        I.ahead.armed = false;
+    }
+    if (aheadHit) {
+        frames[0].in = I.ahead.buf[I.ahead.cur].p;
+        I.ahead.cur ^= 1; // (the GPU reads that buffer now: the next read goes to the other one)
+    }
+    if (n == 1 && G >= 1) { // the frame behind this one in the index, on its way while this one is decoded
+        try {
+            auto it = I.frameOffsets.upper_bound(timestamps[0]);
+            if (it != I.frameOffsets.end()) {
+                const FrameSpan nx = I.locate(it->first);
+                Impl::Slice &b = I.ahead.buf[I.ahead.cur];
+                if (nx.payloadSize && nx.payloadSize <= (1u << 30)) {
+                    grow(b, 0, up(nx.payloadSize));
+                    I.ahead.ts = it->first;
+                    I.ahead.payload = nx.payload;
+                    I.ahead.size = nx.payloadSize;
+                    I.ahead.armed = true;
+                    uint8_t *dst = b.p;
+                    const FileReader *rd = &I.reader;
+                    I.ahead.done = std::async(std::launch::async, [rd, nx, dst]() {
+                        try {
+                            rd->readAt(nx.payload, dst, nx.payloadSize);
+                            return true;
+                        } catch (...) {
+                            return false;
+                        }
+                    });
+                }
+            }
+        } catch (...) { // (a frame that cannot be located is the next call's to report)
+            I.ahead.armed = false;
+        }
+    }
+    std::future<void> reading = aheadHit ? std::async(std::launch::deferred, []() {}) : std::async(std::launch::async, readChunk, size_t(0));
     std::vector<std::future<void>> copying(noutslots); // copy-out of the chunk that last used each output slot
     auto checkChunk = [&](size_t ci) {
         const Chunk &c = chunks[ci];

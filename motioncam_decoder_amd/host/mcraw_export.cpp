@@ -1,6 +1,6 @@
 // mcraw_export -- decode a .mcraw file on the GPU and dump what it holds.
 //
-//   mcraw_export <file.mcraw> [-n frames] [-o outdir] [--single] [--no-write] [--black] [--bits 10|12|14|auto] [--pinned]
+//   mcraw_export <file.mcraw> [-n frames] [-o outdir] [--single [--reuse]] [--no-write] [--black] [--bits 10|12|14|auto] [--pinned]
 //   mcraw_export <file.mcraw> --remux <out.mcraw> [-n frames] [--sorted-index] [--audio-inline] [--no-audio-index]
 //
 // --remux copies the first N frames (compressed as they are), their metadata and the audio into a new container
@@ -10,6 +10,8 @@
 // first N frames (by timestamp) and outdir/audio.s16 (interleaved PCM), and prints one line
 // per frame with its geometry and a CRC-32 of the pixels.  Frames are decoded as one GPU
 // batch (Decoder::loadFrames); --single uses the per-frame loadFrame() path instead.
+// --single --reuse is the reference example's loop as it stands (one `data` vector for every frame, example.cpp:182-188):
+// a timing mode, prints the rate and the last frame's checksum only.
 // --black subtracts the container's black levels, --bits N writes frame_%06d.pN (N-bit strip rows; auto: the
 // narrowest form that holds the container's whiteLevel) instead: both are done by the stage fused into the GPU
 // decode (Decoder::FrameOutput).
@@ -65,7 +67,7 @@ int main(int argc, char **argv)
     std::string input = argv[1], outdir = ".", remux;
     motioncam::Writer::Options wopt;
     long limit = -1;
-    bool single = false, nowrite = false, pinned = false;
+    bool single = false, nowrite = false, pinned = false, reuse = false;
     motioncam::Decoder::FrameOutput output;
     for (int i = 2; i < argc; i++) {
         if (!std::strcmp(argv[i], "-n") && i + 1 < argc)
@@ -82,6 +84,8 @@ int main(int argc, char **argv)
             wopt.audioIndex = false;
         else if (!std::strcmp(argv[i], "--single"))
             single = true;
+        else if (!std::strcmp(argv[i], "--reuse"))
+            reuse = true;
         else if (!std::strcmp(argv[i], "--no-write"))
             nowrite = true; // decode and checksum only (timing runs)
         else if (!std::strcmp(argv[i], "--pinned"))
@@ -142,7 +146,17 @@ int main(int argc, char **argv)
         std::vector<std::vector<uint8_t>> data;
         std::vector<nlohmann::json> meta;
         const auto t0 = std::chrono::steady_clock::now();
-        if (single) {
+        if (single && reuse) {
+            std::vector<uint8_t> one;
+            nlohmann::json m;
+            for (size_t i = 0; i < frames.size(); i++)
+                decoder.loadFrame(frames[i], one, m);
+            const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            std::cout << "decoded " << frames.size() << " frames in " << secs << " s (" << (secs > 0 ? frames.size() / secs : 0.0)
+                      << " frames/s, one vector for every frame)" << std::endl;
+            std::printf("last frame crc32 %08x\n", crc32(one.data(), one.size()));
+            return 0;
+        } else if (single) {
             data.resize(frames.size());
             meta.resize(frames.size());
             for (size_t i = 0; i < frames.size(); i++)
