@@ -131,7 +131,7 @@ bool loadAudioChunkAt(const FileReader &r, const Locator &o, AudioChunk &out)
 } // namespace
 
 // A few host threads that stay (per-frame callers: starting eight threads for every frame's copy-out cost more than the copy).
-// run(n, fn) calls fn(i) for i in [0, n) on the workers and the calling thread and returns when all are done; one run() at a time.
+// run(n, fn) calls fn(i) for i in [0, n) on the workers and the calling thread and returns when all are done; callers take turns.
 class WorkerPool {
 public:
     explicit WorkerPool(unsigned workers)
@@ -153,6 +153,7 @@ public:
     {
         if (n == 0)
             return;
+        std::lock_guard<std::mutex> one(run_); // (two chunks' copy-outs may be under way at once: they take turns)
         {
             std::lock_guard<std::mutex> lk(mu_);
             fn_ = &fn;
@@ -195,7 +196,7 @@ private:
         }
     }
     std::vector<std::thread> threads_;
-    std::mutex mu_;
+    std::mutex mu_, run_;
     std::condition_variable cv_, done_;
     const std::function<void(size_t)> *fn_ = nullptr;
     size_t n_ = 0, busy_ = 0;

@@ -186,3 +186,18 @@ def test_load_frame_in_any_order(container, order, tmp_path):
             line = "%s%d %d %08x" % ("b" if tok == "b" else "", i, img.nbytes, zlib.crc32(img.tobytes()) & 0xFFFFFFFF)
             want.append(line if tok == "b" else line + " %dx%d" % (img.shape[1], img.shape[0]))
     assert r.stdout.split("\n")[:-1] == want
+
+
+def test_export_tool_one_frame_per_chunk(container, tmp_path):
+    """MCRAW_SLOT_MB=1: every chunk of the loadFrames pipeline is one frame, so the copy-outs of neighbouring chunks (sliced over the
+    facade's worker threads, which take one caller at a time) are under way together; run a few times, every frame must be its own."""
+    d, path, images, audio = container
+    env = dict(os.environ, MCRAW_SLOT_MB="1")
+    order = sorted(images)
+    for rep in range(4):
+        r = subprocess.run([EXPORT, path, "-o", str(tmp_path), "--no-write"], cwd=str(tmp_path), capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stderr
+        lines = [l for l in r.stdout.splitlines() if l.startswith("frame ")]
+        assert len(lines) == len(order)
+        for i, ts in enumerate(order):
+            assert ("crc32 %08x" % (zlib.crc32(images[ts].tobytes()) & 0xFFFFFFFF)) in lines[i], (rep, i)

@@ -9,7 +9,7 @@ d = tempfile.mkdtemp(dir="/dev/shm")
 pairs = [L.encode7(L.synth_image(3840, 2160, 12, 1, 12.0, 3000 + i)) for i in range(8)]
 path = L.write_mcraw(os.path.join(d, "uhd.mcraw"), [(1000 + i, 7, 3840, 2160, pairs[i % 8]) for i in range(n)])
 exe = os.path.join(ROOT, "motioncam_decoder_amd", "lib", "mcraw_export")
-for mb in ("96", "192", "384", "768", "192", "384"):
+for mb in (os.environ.get("SLOTS") or "96 192 384 768 192 384").split():
     for rep in range(2):
         r = subprocess.run([exe, path, "-o", d, "--no-write"], capture_output=True, text=True, env=dict(os.environ, MCRAW_TRACE="1", MCRAW_SLOT_MB=mb))
         tr = [l for l in r.stderr.splitlines() if l.startswith("[mcraw]")]
