@@ -69,6 +69,7 @@ def build_host(force=False):
         return None
     hdrs = [os.path.join(HOST, "include", "motioncam", f) for f in ("Decoder.hpp", "Container.hpp", "RawData.hpp", "Writer.hpp",
                                                                      "mcraw_container.h")]
+    hdrs.append(os.path.join(HOST, "WorkerPool.hpp"))
     inc = ["-I" + os.path.join(HOST, "include"), "-I" + os.path.join(HOST, "thirdparty"), "-I" + os.path.join(ROOT, "include")]
     if force or _newer(out, srcs + hdrs):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall"] + inc + ["-o", out] + srcs +

@@ -8,6 +8,7 @@
 #include <motioncam/mcraw_container.h>
 
 #include "mcraw_hip.h"
+#include "WorkerPool.hpp"
 
 #include <algorithm>
 #if defined(__linux__)
@@ -130,81 +131,6 @@ bool loadAudioChunkAt(const FileReader &r, const Locator &o, AudioChunk &out)
 
 } // namespace
 
-// A few host threads that stay (per-frame callers: starting eight threads for every frame's copy-out cost more than the copy).
-// run(n, fn) calls fn(i) for i in [0, n) on the workers and the calling thread and returns when all are done; callers take turns.
-class WorkerPool {
-public:
-    explicit WorkerPool(unsigned workers)
-    {
-        for (unsigned t = 0; t < workers; t++)
-            threads_.emplace_back([this]() { loop(); });
-    }
-    ~WorkerPool()
-    {
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            quit_ = true;
-        }
-        cv_.notify_all();
-        for (std::thread &t : threads_)
-            t.join();
-    }
-    void run(size_t n, const std::function<void(size_t)> &fn)
-    {
-        if (n == 0)
-            return;
-        std::lock_guard<std::mutex> one(run_); // (two chunks' copy-outs may be under way at once: they take turns)
-        {
-            std::lock_guard<std::mutex> lk(mu_);
-            fn_ = &fn;
-            n_ = n;
-            next_.store(0);
-            busy_ = threads_.size();
-            gen_++;
-        }
-        cv_.notify_all();
-        for (size_t i = next_.fetch_add(1); i < n; i = next_.fetch_add(1))
-            fn(i);
-        std::unique_lock<std::mutex> lk(mu_);
-        done_.wait(lk, [this]() { return busy_ == 0; });
-        fn_ = nullptr;
-    }
-
-private:
-    void loop()
-    {
-        unsigned long long seen = 0;
-        for (;;) {
-            const std::function<void(size_t)> *fn;
-            size_t n;
-            {
-                std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&]() { return quit_ || gen_ != seen; });
-                if (quit_)
-                    return;
-                seen = gen_;
-                fn = fn_;
-                n = n_;
-            }
-            for (size_t i = next_.fetch_add(1); i < n; i = next_.fetch_add(1))
-                (*fn)(i);
-            {
-                std::lock_guard<std::mutex> lk(mu_);
-                if (--busy_ == 0)
-                    done_.notify_all();
-            }
-        }
-    }
-    std::vector<std::thread> threads_;
-    std::mutex mu_, run_;
-    std::condition_variable cv_, done_;
-    const std::function<void(size_t)> *fn_ = nullptr;
-    size_t n_ = 0, busy_ = 0;
-    std::atomic<size_t> next_{0};
-    unsigned long long gen_ = 0;
-    bool quit_ = false;
-};
-
 struct Decoder::Impl {
     explicit Impl(FILE *f) : reader(f) {}
 
@@ -250,7 +176,7 @@ struct Decoder::Impl {
         uint32_t size = 0;
         std::future<bool> done;
     } ahead;
-    std::unique_ptr<WorkerPool> workers; // copy-out of a lone frame, sliced over the threads; made on first use
+    std::unique_ptr<detail::WorkerPool> workers; // copy-out of a lone frame, sliced over the threads; made on first use
     mcraw_pool *pool = nullptr; // the GPUs this decoder shards its batches over (frame i of a batch -> member i mod G)
     std::vector<int> devices;   // empty: MCRAW_DEVICES / MCRAW_DEVICE / the current device
 
@@ -721,7 +647,7 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
             const uint8_t *src = reinterpret_cast<const uint8_t *>(f.out);
             const size_t slice = (bytes + hostThreads - 1) / hostThreads;
             if (!I.workers)
-                I.workers.reset(new WorkerPool(hostThreads - 1));
+                I.workers.reset(new detail::WorkerPool(hostThreads - 1));
             I.workers->run(hostThreads, [&](size_t t) {
                 const size_t lo = std::min(bytes, t * slice), hi = std::min(bytes, lo + slice);
                 std::memcpy(dst.data() + lo, src + lo, hi - lo);

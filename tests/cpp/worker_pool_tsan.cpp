@@ -1,0 +1,38 @@
+// worker_pool_tsan -- the facade's copy-out workers under ThreadSanitizer: several callers at once (two chunks' copy-outs overlap
+// in Decoder::loadFrames), runs of every size around the worker count, pools made and destroyed while idle and right after work.
+#include "WorkerPool.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+
+int main()
+{
+    using motioncam::detail::WorkerPool;
+    long bad = 0;
+    for (int round = 0; round < 20; round++) {
+        WorkerPool pool(3 + round % 5);
+        std::vector<std::thread> callers;
+        std::atomic<long> wrong{0};
+        for (int c = 0; c < 3; c++)
+            callers.emplace_back([&, c]() {
+                for (size_t n = 0; n < 24; n++) {
+                    std::vector<unsigned char> src(4096 * (n + 1), static_cast<unsigned char>(c + n)), dst(src.size(), 0);
+                    const size_t slice = (src.size() + n) / (n + 1);
+                    pool.run(n + 1, [&](size_t t) {
+                        const size_t lo = std::min(src.size(), t * slice), hi = std::min(src.size(), lo + slice);
+                        std::memcpy(dst.data() + lo, src.data() + lo, hi - lo);
+                    });
+                    if (dst != src)
+                        wrong++;
+                }
+                pool.run(0, [&](size_t) { wrong++; });
+            });
+        for (std::thread &t : callers)
+            t.join();
+        bad += wrong.load();
+    }
+    { WorkerPool idle(4); }
+    std::printf("wrong %ld\n", bad);
+    return bad ? 1 : 0;
+}

@@ -120,3 +120,15 @@ def test_reference_container_vocabulary_compiles_and_reads_a_file(tmp_path):
     r = subprocess.run([exe, path], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stderr)
     assert r.stdout.strip() == "frames 3 audio 2 first_ts 1000"
+
+
+def test_copy_out_workers_under_thread_sanitizer(tmp_path):
+    """The threads Decoder::loadFrame's copy-out keeps (host/WorkerPool.hpp) take one caller at a time; two chunks' copy-outs call
+    them together.  tests/cpp/worker_pool_tsan.cpp: three callers, every run size around the worker count, under -fsanitize=thread."""
+    exe = str(tmp_path / "worker_pool_tsan")
+    host = os.path.join(ROOT, "motioncam_decoder_amd", "host")
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Werror", "-fsanitize=thread", "-I" + host, "-o", exe,
+                    os.path.join(ROOT, "tests", "cpp", "worker_pool_tsan.cpp"), "-lpthread"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, (r.stdout, r.stderr[-2000:])
+    assert r.stdout.strip() == "wrong 0"
