@@ -164,31 +164,67 @@ struct Decoder::Impl {
         size_t cap = 0;
     };
     std::vector<Slice> pinIn[kInSlots], pinOut[kOutSlots]; // [slot][member]
-    // Read-ahead for per-frame callers (the reference's own loop, example.cpp:187-195 over lib/Decoder.cpp:184-235, asks for one
-    // frame after the other in timestamp order): while frame i is on the GPU and being copied out, the payload of the frame that
-    // follows it in the index is read into one of two pinned buffers of its own; the next loadFrame() decodes from there.
+    // Per-frame callers (the reference's own loop, example.cpp:182-188 over lib/Decoder.cpp:184-235, asks for one frame after the
+    // other in index order) are served ahead of their calls, two frames deep: while frame i is copied out to the caller, frame
+    // i + 1 -- its payload read during the call before -- is being decoded (a ticket of the pool: pinned in -> GPU -> pinned out),
+    // and the payload of frame i + 2 is on its way from the file into the other pinned input buffer.  A call that asks for
+    // anything else, or with other output options, or whose frame failed ahead of time, takes the ordinary path and reports
+    // what that path reports.
     struct Ahead {
-        Slice buf[2];
-        int cur = 0;             // buffer the pending read goes to
-        bool armed = false;
-        Timestamp ts = 0;
-        int64_t payload = 0;
-        uint32_t size = 0;
-        std::future<bool> done;
+        Slice in[2], out[2];
+        struct Read { // a payload on its way into in[buf] (or there already: `done` not valid any more)
+            bool armed = false;
+            Timestamp ts = 0;
+            int64_t payload = 0;
+            uint32_t size = 0;
+            int buf = 0;
+            std::future<bool> done;
+        } rd;
+        struct Decode { // a frame on the GPU: in[inbuf] -> out[outbuf]
+            bool armed = false;
+            Timestamp ts = 0;
+            int64_t payload = 0;
+            int inbuf = 0, outbuf = 0;
+            int bits = 16;
+            bool black = false;
+            size_t outBytes = 0;
+            mcraw_frame f{}; // (the ticket's descriptor: lives as long as the ticket)
+            mcraw_pool_ticket *ticket = nullptr;
+        } dc;
     } ahead;
+    // Both over: was the read good, did the frame decode?  (Whatever the answers, nothing is under way afterwards.)
+    void settleAhead(bool &rdOk, bool &dcOk)
+    {
+        bool ok = true;
+        if (ahead.rd.done.valid())
+            ok = ahead.rd.done.get();
+        rdOk = ahead.rd.armed && ok;
+        ahead.rd.armed = rdOk;
+        dcOk = false;
+        if (ahead.dc.ticket) {
+            size_t w = 0;
+            int32_t st = 0;
+            const int rc = mcraw_pool_ticket_wait(ahead.dc.ticket, &w, &st);
+            ahead.dc.ticket = nullptr;
+            dcOk = ahead.dc.armed && rc == 0 && st == 0 && w != 0;
+        }
+        ahead.dc.armed = dcOk;
+    }
     std::unique_ptr<detail::WorkerPool> workers; // copy-out of a lone frame, sliced over the threads; made on first use
+    std::unique_ptr<detail::WorkerPool> readers; // a frame's payload read ahead, in slices; made on first use
     mcraw_pool *pool = nullptr; // the GPUs this decoder shards its batches over (frame i of a batch -> member i mod G)
     std::vector<int> devices;   // empty: MCRAW_DEVICES / MCRAW_DEVICE / the current device
 
     void releaseGpu()
     {
-        if (ahead.done.valid())
-            (void)ahead.done.get(); // (a read into a pinned buffer may still be under way)
-        ahead.armed = false;
-        for (Slice &b : ahead.buf) {
-            mcraw_host_free(b.p);
-            b = Slice{};
-        }
+        bool rdOk, dcOk; // (a read into a pinned buffer, a frame on the GPU may still be under way)
+        settleAhead(rdOk, dcOk);
+        ahead.rd.armed = ahead.dc.armed = false;
+        for (Slice *set : {ahead.in, ahead.out})
+            for (int i = 0; i < 2; i++) {
+                mcraw_host_free(set[i].p);
+                set[i] = Slice{};
+            }
         for (auto &slot : pinIn)
             for (Slice &s : slot)
                 mcraw_host_free(s.p);
@@ -530,6 +566,178 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
                                                                    : "Failed to uncompress legacy frame") +
                           " (" + mcraw_pool_last_error() + ")");
     const size_t G = static_cast<size_t>(mcraw_pool_size(I.pool)); // frame k of a chunk is decoded by member k mod G
+    auto grow = [&](Impl::Slice &sl, size_t member, size_t want) {
+        if (want <= sl.cap)
+            return;
+        mcraw_host_free(sl.p);
+        sl.p = static_cast<uint8_t *>(mcraw_pool_host_alloc(I.pool, static_cast<int>(member), want));
+        sl.cap = sl.p ? want : 0;
+        if (!sl.p)
+            throw IOException("Failed to allocate pinned staging");
+    };
+    const unsigned hostThreads = std::max(2u, std::min(8u, std::thread::hardware_concurrency() / 2));
+    // A fresh vector of a frame's size is fresh memory: its first touch faults in 4 000 pages of 4 KiB per UHD frame, which is what
+    // the copy-out spends its time on.  Where the kernel hands out transparent huge pages on request (THP mode "madvise"), asking
+    // for them before the first touch makes that eight faults of 2 MiB.  (Linux only; a no-op elsewhere and for vectors that own
+    // enough memory already.)
+    auto reserveHuge = [](std::vector<uint8_t> &v, size_t bytes) {
+        if (v.capacity() >= bytes)
+            return;
+        std::vector<uint8_t>().swap(v);
+        v.reserve(bytes);
+#if defined(__linux__) && defined(MADV_HUGEPAGE)
+        const uintptr_t a = (reinterpret_cast<uintptr_t>(v.data()) + 4095u) & ~static_cast<uintptr_t>(4095u);
+        const uintptr_t e = (reinterpret_cast<uintptr_t>(v.data()) + bytes) & ~static_cast<uintptr_t>(4095u);
+        if (e > a && bytes >= (4u << 20))
+            (void)madvise(reinterpret_cast<void *>(a), e - a, MADV_HUGEPAGE);
+#endif
+    };
+    auto copyFrame = [&](std::vector<uint8_t> &dst, const uint8_t *src, size_t bytes) { // one frame, sliced over the threads that stay
+        reserveHuge(dst, bytes);
+        if (dst.size() != bytes)
+            dst.resize(bytes);
+        const size_t slice = (bytes + hostThreads - 1) / hostThreads;
+        if (!I.workers)
+            I.workers.reset(new detail::WorkerPool(hostThreads - 1));
+        I.workers->run(hostThreads, [&](size_t t) {
+            const size_t lo = std::min(bytes, t * slice), hi = std::min(bytes, lo + slice);
+            std::memcpy(dst.data() + lo, src + lo, hi - lo);
+        });
+    };
+    static const bool trace = std::getenv("MCRAW_TRACE") != nullptr;
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+
+    // ---- one frame asked for: was it decoded, or at least read, ahead of this call?  (Impl::Ahead)
+    Impl::Ahead &A = I.ahead;
+    bool rdOk = false, dcOk = false;
+    const auto tSettle0 = now();
+    I.settleAhead(rdOk, dcOk); // (whatever this call is: nothing is under way behind this line)
+    const auto tSettle1 = now();
+    const bool single = n == 1 && !direct;
+    // the payload of the frame behind `after` in the index, on its way into in[buf]
+    auto startRead = [&](Timestamp after, int buf) {
+        A.rd.armed = false;
+        try {
+            const auto it = I.frameOffsets.upper_bound(after);
+            if (it == I.frameOffsets.end())
+                return;
+            const FrameSpan nx = I.locate(it->first);
+            if (!nx.payloadSize || nx.payloadSize > (1u << 30))
+                return;
+            grow(A.in[buf], 0, up(nx.payloadSize));
+            A.rd.ts = it->first;
+            A.rd.payload = nx.payload;
+            A.rd.size = nx.payloadSize;
+            A.rd.buf = buf;
+            uint8_t *dst = A.in[buf].p;
+            const FileReader *rd = &I.reader;
+            if (!I.readers)
+                I.readers.reset(new detail::WorkerPool(3));
+            detail::WorkerPool *pool = I.readers.get();
+            // (one thread moves a UHD frame's 9 MB out of the page cache in 0.9 ms, which would be the loop's period: four slices)
+            A.rd.done = std::async(std::launch::async, [rd, nx, dst, pool]() {
+                std::atomic<bool> good{true};
+                const size_t slice = ((static_cast<size_t>(nx.payloadSize) + 3) / 4 + 4095) & ~static_cast<size_t>(4095);
+                pool->run(4, [&](size_t t) {
+                    const size_t lo = std::min<size_t>(nx.payloadSize, t * slice), hi = std::min<size_t>(nx.payloadSize, lo + slice);
+                    try {
+                        if (hi > lo)
+                            rd->readAt(nx.payload + static_cast<int64_t>(lo), dst + lo, hi - lo);
+                    } catch (...) {
+                        good = false;
+                    }
+                });
+                return good.load();
+            });
+            A.rd.armed = true;
+        } catch (...) { // (a frame that cannot be located is the next call's to report)
+            A.rd.armed = false;
+        }
+    };
+    // the frame whose payload has been read (A.rd, settled and good) onto the GPU, with this call's output options; false: not
+    // queued (its own call will say why)
+    auto submitAhead = [&](int outbuf) {
+        A.dc.armed = false;
+        try {
+            const FrameSpan sp = I.locate(A.rd.ts);
+            if (sp.payload != A.rd.payload || sp.payloadSize != A.rd.size)
+                return false;
+            nlohmann::json m = readJson(I.reader, sp.json, sp.jsonSize);
+            const int width = m["width"], height = m["height"], type = m["compressionType"];
+            if ((type != kTypeBlock && type != kTypeLegacy) || width <= 0 || height <= 0)
+                return false;
+            const uint64_t px = static_cast<uint64_t>(width) * static_cast<uint64_t>(height);
+            if (px >= (1ull << 31) || sp.payloadSize < (type == kTypeBlock ? px / 1024 : px / 8))
+                return false;
+            const size_t bytes = frameBytes(width, height, output);
+            grow(A.out[outbuf], 0, up(bytes + 2));
+            mcraw_frame &f = A.dc.f;
+            f = mcraw_frame{};
+            f.in = A.in[A.rd.buf].p;
+            f.out = reinterpret_cast<uint16_t *>(A.out[outbuf].p);
+            f.len = sp.payloadSize;
+            f.width = width;
+            f.height = height;
+            f.type = type;
+            f.out_capacity = (bytes + 1) / 2;
+            int rc = post.flags ? mcraw_pool_set_post(I.pool, &post) : 0;
+            if (rc == 0)
+                rc = mcraw_pool_decode_batch_async(I.pool, &f, 1, &A.dc.ticket);
+            if (post.flags)
+                (void)mcraw_pool_set_post(I.pool, nullptr);
+            if (rc != 0) {
+                A.dc.ticket = nullptr;
+                return false;
+            }
+            A.dc.ts = A.rd.ts;
+            A.dc.payload = A.rd.payload;
+            A.dc.inbuf = A.rd.buf;
+            A.dc.outbuf = outbuf;
+            A.dc.bits = output.bitsPerSample;
+            A.dc.black = output.subtractBlackLevel;
+            A.dc.outBytes = bytes;
+            A.dc.armed = true;
+            A.rd.armed = false; // (its buffer is the decode's now)
+            return true;
+        } catch (...) {
+            return false;
+        }
+    };
+    bool hitRd = false;
+    if (!single) {
+        A.rd.armed = A.dc.armed = false;
+    } else {
+        const mcraw_frame &f0 = frames[0];
+        const bool hitDc = dcOk && A.dc.ts == timestamps[0] && A.dc.payload == spans[0].payload && A.dc.f.len == f0.len &&
+                           A.dc.f.width == f0.width && A.dc.f.height == f0.height && A.dc.f.type == f0.type &&
+                           A.dc.bits == output.bitsPerSample && A.dc.black == output.subtractBlackLevel && A.dc.outBytes == outBytes[0];
+        A.dc.armed = false;
+        if (hitDc) {
+            const int ob = A.dc.outbuf, freeIn = A.dc.inbuf;
+            // the frame behind this one: read already?  Onto the GPU now, and the one behind THAT on its way from the file --
+            // both while this frame is copied out and the caller works on it
+            const auto nxt = I.frameOffsets.upper_bound(timestamps[0]);
+            const bool nextRead = rdOk && nxt != I.frameOffsets.end() && A.rd.ts == nxt->first;
+            if (nextRead) {
+                const Timestamp t = A.rd.ts;
+                if (submitAhead(ob ^ 1))
+                    startRead(t, freeIn);
+                // (not queued: its payload stays where it is, the next call decodes it from there)
+            } else {
+                startRead(timestamps[0], freeIn);
+            }
+            const auto t1 = now();
+            copyFrame(outData[0], A.out[ob].p, outBytes[0]);
+            if (trace)
+                std::fprintf(stderr, "[mcraw] loadFrames n=1 decoded ahead: pipeline %.2f ms: wait-read 0.00, gpu batch %.2f, wait-copy 0.00, tail copy %.2f (index + JSON %.2f, queue the next %.2f)\n",
+                             ms(tEnter, now()), ms(tSettle0, tSettle1), ms(t1, now()), ms(tEnter, tSettle0), ms(tSettle1, t1));
+            return;
+        }
+        hitRd = rdOk && A.rd.ts == timestamps[0] && A.rd.payload == spans[0].payload && A.rd.size == f0.len;
+    }
 
     // chunks: as many frames as fit the staging budget of one slot (at least one frame)
     // (MCRAW_SLOT_MB: 240 UHD frames run through the pipeline in 142 / 124 / 116 ms with slots of 192 / 384 / 768 MB -- and the pinned
@@ -555,15 +763,6 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
         }
         chunks.push_back(c);
     }
-    auto grow = [&](Impl::Slice &sl, size_t member, size_t want) {
-        if (want <= sl.cap)
-            return;
-        mcraw_host_free(sl.p);
-        sl.p = static_cast<uint8_t *>(mcraw_pool_host_alloc(I.pool, static_cast<int>(member), want));
-        sl.cap = sl.p ? want : 0;
-        if (!sl.p)
-            throw IOException("Failed to allocate pinned staging");
-    };
     // staging bytes a chunk needs from every member's slice
     std::vector<size_t> maxIn(G, 0), maxOut(G, 0);
     for (const Chunk &c : chunks) {
@@ -592,8 +791,6 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
         for (size_t m = 0; m < G; m++)
             grow(I.pinOut[sl][m], m, maxOut[m]);
     }
-    const unsigned hostThreads = std::max(2u, std::min(8u, std::thread::hardware_concurrency() / 2));
-
     auto readChunk = [&](size_t ci) { // file -> pinned input slot
         const Chunk &c = chunks[ci];
         std::vector<Impl::Slice> &slot = I.pinIn[ci % nslots];
@@ -610,22 +807,6 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
             f.in = dst;
         });
     };
-    // A fresh vector of a frame's size is fresh memory: its first touch faults in 4 000 pages of 4 KiB per UHD frame, which is what
-    // the copy-out spends its time on.  Where the kernel hands out transparent huge pages on request (THP mode "madvise"), asking
-    // for them before the first touch makes that eight faults of 2 MiB.  (Linux only; a no-op elsewhere and for vectors that own
-    // enough memory already.)
-    auto reserveHuge = [](std::vector<uint8_t> &v, size_t bytes) {
-        if (v.capacity() >= bytes)
-            return;
-        std::vector<uint8_t>().swap(v);
-        v.reserve(bytes);
-#if defined(__linux__) && defined(MADV_HUGEPAGE)
-        const uintptr_t a = (reinterpret_cast<uintptr_t>(v.data()) + 4095u) & ~static_cast<uintptr_t>(4095u);
-        const uintptr_t e = (reinterpret_cast<uintptr_t>(v.data()) + bytes) & ~static_cast<uintptr_t>(4095u);
-        if (e > a && bytes >= (4u << 20))
-            (void)madvise(reinterpret_cast<void *>(a), e - a, MADV_HUGEPAGE);
-#endif
-    };
     auto copyOut = [&](size_t ci) { // pinned output slot -> the caller's vectors
         const Chunk &c = chunks[ci];
         if (c.count >= 3) { // one frame per task
@@ -637,74 +818,22 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
             });
             return;
         }
-        for (size_t k = 0; k < c.count; k++) { // few frames: slice every frame over the threads
-            const mcraw_frame &f = frames[c.first + k];
-            const size_t bytes = outBytes[c.first + k];
-            std::vector<uint8_t> &dst = outData[c.first + k];
-            reserveHuge(dst, bytes);
-            if (dst.size() != bytes)
-                dst.resize(bytes);
-            const uint8_t *src = reinterpret_cast<const uint8_t *>(f.out);
-            const size_t slice = (bytes + hostThreads - 1) / hostThreads;
-            if (!I.workers)
-                I.workers.reset(new detail::WorkerPool(hostThreads - 1));
-            I.workers->run(hostThreads, [&](size_t t) {
-                const size_t lo = std::min(bytes, t * slice), hi = std::min(bytes, lo + slice);
-                std::memcpy(dst.data() + lo, src + lo, hi - lo);
-            });
-        }
+        for (size_t k = 0; k < c.count; k++) // few frames: slice every frame over the threads
+            copyFrame(outData[c.first + k], reinterpret_cast<const uint8_t *>(frames[c.first + k].out), outBytes[c.first + k]);
     };
 
-    static const bool trace = std::getenv("MCRAW_TRACE") != nullptr;
-    auto now = []() { return std::chrono::steady_clock::now(); };
-    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
-        return std::chrono::duration<double, std::milli>(b - a).count();
-    };
     double tWaitRead = 0, tDecode = 0, tWaitCopy = 0;
     const auto tStart = now();
     std::vector<size_t> written(n);
     std::vector<int32_t> status(n);
-    // one frame asked for: was it read ahead?  (whatever the answer, the pending read is over before its buffer is looked at)
-    bool aheadHit = false;
-    if (I.ahead.done.valid()) {
-        const bool ok = I.ahead.done.get();
-        aheadHit = ok && I.ahead.armed && n == 1 && I.ahead.ts == timestamps[0] && I.ahead.payload == spans[0].payload &&
-                   I.ahead.size == frames[0].len;
-        I.ahead.armed = false;
+    if (hitRd) { // read ahead: decoded from where it is, while the frame behind it is read into the other buffer
+        const int b = A.rd.buf;
+        frames[0].in = A.in[b].p;
+        startRead(timestamps[0], b ^ 1);
+    } else if (single) {
+        startRead(timestamps[0], 0);
     }
-    if (aheadHit) {
-        frames[0].in = I.ahead.buf[I.ahead.cur].p;
-        I.ahead.cur ^= 1; // (the GPU reads that buffer now: the next read goes to the other one)
-    }
-    if (n == 1 && G >= 1) { // the frame behind this one in the index, on its way while this one is decoded
-        try {
-            auto it = I.frameOffsets.upper_bound(timestamps[0]);
-            if (it != I.frameOffsets.end()) {
-                const FrameSpan nx = I.locate(it->first);
-                Impl::Slice &b = I.ahead.buf[I.ahead.cur];
-                if (nx.payloadSize && nx.payloadSize <= (1u << 30)) {
-                    grow(b, 0, up(nx.payloadSize));
-                    I.ahead.ts = it->first;
-                    I.ahead.payload = nx.payload;
-                    I.ahead.size = nx.payloadSize;
-                    I.ahead.armed = true;
-                    uint8_t *dst = b.p;
-                    const FileReader *rd = &I.reader;
-                    I.ahead.done = std::async(std::launch::async, [rd, nx, dst]() {
-                        try {
-                            rd->readAt(nx.payload, dst, nx.payloadSize);
-                            return true;
-                        } catch (...) {
-                            return false;
-                        }
-                    });
-                }
-            }
-        } catch (...) { // (a frame that cannot be located is the next call's to report)
-            I.ahead.armed = false;
-        }
-    }
-    std::future<void> reading = aheadHit ? std::async(std::launch::deferred, []() {}) : std::async(std::launch::async, readChunk, size_t(0));
+    std::future<void> reading = hitRd ? std::async(std::launch::deferred, []() {}) : std::async(std::launch::async, readChunk, size_t(0));
     std::vector<std::future<void>> copying(noutslots); // copy-out of the chunk that last used each output slot
     auto checkChunk = [&](size_t ci) {
         const Chunk &c = chunks[ci];
@@ -788,6 +917,18 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
         std::future<void> &f = copying[(chunks.size() + k) % copying.size()];
         if (f.valid())
             f.get();
+    }
+    if (single && A.rd.armed && A.rd.done.valid() && A.rd.done.wait_for(std::chrono::seconds(0)) == std::future_status::ready) {
+        // the next frame's payload is here already: onto the GPU behind this call (the caller works on this frame meanwhile),
+        // and the payload of the one behind it on its way into the buffer this call's frame came from
+        if (A.rd.done.get()) {
+            const Timestamp t = A.rd.ts;
+            const int b = A.rd.buf;
+            if (submitAhead(0))
+                startRead(t, b ^ 1);
+        } else {
+            A.rd.armed = false;
+        }
     }
     if (trace)
         std::fprintf(stderr, "[mcraw] loadFrames n=%zu chunks=%zu setup %.2f ms (index, JSON, context, pinned staging), pipeline %.2f ms: wait-read %.2f, gpu batch %.2f, wait-copy %.2f, tail copy %.2f\n",

@@ -1,4 +1,4 @@
-// frame_order <file.mcraw> <i|b> ... -- loadFrame() calls in the order the arguments give (each a position in the sorted
+// frame_order <file.mcraw> <i|b|oN> ... -- loadFrame() calls in the order the arguments give (each a position in the sorted
 // frame list), every one into the SAME vector as the reference's example does; "b" runs a loadFrames() batch of every frame
 // in between.  Prints "<position> <bytes> <crc32>" per call: whatever the order, a call's bytes must be its frame's
 // (the facade reads the index-next frame ahead of the call that may never come).
@@ -33,6 +33,7 @@ int main(int argc, char **argv)
         const std::vector<motioncam::Timestamp> frames = d.getFrames();
         std::vector<uint8_t> data;
         nlohmann::json meta;
+        motioncam::Decoder::FrameOutput output;
         for (int a = 2; a < argc; a++) {
             if (!std::strcmp(argv[a], "b")) {
                 std::vector<std::vector<uint8_t>> all;
@@ -42,10 +43,22 @@ int main(int argc, char **argv)
                     std::printf("b%zu %zu %08x\n", i, all[i].size(), crc32(all[i].data(), all[i].size()));
                 continue;
             }
+            if (argv[a][0] == 'o') { // "o12": the calls behind it ask for 12-bit strip rows (a one-frame loadFrames); "o16": plain again
+                output.bitsPerSample = std::atoi(argv[a] + 1);
+                continue;
+            }
             const size_t i = static_cast<size_t>(std::atol(argv[a]));
             if (i >= frames.size())
                 return 2;
-            d.loadFrame(frames[i], data, meta);
+            if (output.bitsPerSample == 16) {
+                d.loadFrame(frames[i], data, meta);
+            } else {
+                std::vector<std::vector<uint8_t>> one;
+                std::vector<nlohmann::json> metas;
+                d.loadFrames({frames[i]}, one, metas, output);
+                data = one[0];
+                meta = metas[0];
+            }
             const int w = meta["width"], h = meta["height"];
             std::printf("%zu %zu %08x %dx%d\n", i, data.size(), crc32(data.data(), data.size()), w, h);
         }

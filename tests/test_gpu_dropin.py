@@ -162,12 +162,14 @@ def test_export_tool_strip_width_from_white_level(container, tmp_path):
         assert np.array_equal(got.reshape(img.shape[0], -1), L.oracle_post(img, None, bits=10)), (i, ts)
 
 
-@pytest.mark.parametrize("order", ["0 1 2 3 4", "4 3 2 1 0", "0 0 1 1 4 4", "0 2 4 1 3 0", "1 b 2 3 b 4 0", "3", "4 4 4"])
+@pytest.mark.parametrize("order", ["0 1 2 3 4", "4 3 2 1 0", "0 0 1 1 4 4", "0 2 4 1 3 0", "1 b 2 3 b 4 0", "3", "4 4 4",
+                                   "0 1 2 o12 3 4 o16 0 1 2 o10 3 o14 4", "0 1 2 3 4 0 1 2 3 4 4 3 3 4"])
 def test_load_frame_in_any_order(container, order, tmp_path):
-    """The facade reads the frame that FOLLOWS a loadFrame() call in the index ahead into pinned memory (the reference's loop,
-    example.cpp:182-188, asks for the frames one by one in that order).  A call gets its own frame whatever was read ahead:
-    backwards, repeats, skips, batches in between, the last frame (nothing to read ahead), a lone call that leaves a read
-    pending when the decoder goes away."""
+    """The facade reads the frame that FOLLOWS a loadFrame() call in the index ahead into pinned memory and decodes the one
+    behind the previous call ahead of time (the reference's loop, example.cpp:182-188, asks for the frames one by one in that
+    order).  A call gets its own frame, in the form IT asks for, whatever was read or decoded ahead: backwards, repeats, skips,
+    batches in between, other output options from one call to the next, the last frame (nothing to read ahead), a lone call
+    that leaves a read or a decode pending when the decoder goes away."""
     d, path, images, audio = container
     inc = os.path.join(ROOT, "motioncam_decoder_amd", "host")
     lib = os.path.join(ROOT, "motioncam_decoder_amd", "lib")
@@ -179,11 +181,15 @@ def test_load_frame_in_any_order(container, order, tmp_path):
     r = _run([exe, path] + order.split(), str(tmp_path))
     assert r.returncode == 0, r.stdout + r.stderr
     ts = sorted(images)
-    want = []
+    want, bits = [], 16
     for tok in order.split():
+        if tok[0] == "o":
+            bits = int(tok[1:])
+            continue
         for i in (range(len(ts)) if tok == "b" else [int(tok)]):
             img = images[ts[i]]
-            line = "%s%d %d %08x" % ("b" if tok == "b" else "", i, img.nbytes, zlib.crc32(img.tobytes()) & 0xFFFFFFFF)
+            data = img.tobytes() if bits == 16 or tok == "b" else L.oracle_post(img, None, bits=bits).tobytes()
+            line = "%s%d %d %08x" % ("b" if tok == "b" else "", i, len(data), zlib.crc32(data) & 0xFFFFFFFF)
             want.append(line if tok == "b" else line + " %dx%d" % (img.shape[1], img.shape[0]))
     assert r.stdout.split("\n")[:-1] == want
 

@@ -130,5 +130,7 @@ def test_copy_out_workers_under_thread_sanitizer(tmp_path):
     subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Werror", "-fsanitize=thread", "-I" + host, "-o", exe,
                     os.path.join(ROOT, "tests", "cpp", "worker_pool_tsan.cpp"), "-lpthread"], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    if "FATAL: ThreadSanitizer" in r.stderr:  # (a kernel whose address-space layout this sanitizer runtime cannot map: not a finding)
+        pytest.skip("ThreadSanitizer does not start here: " + r.stderr.strip().splitlines()[0])
     assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, (r.stdout, r.stderr[-2000:])
     assert r.stdout.strip() == "wrong 0"
