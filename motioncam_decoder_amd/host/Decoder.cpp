@@ -605,6 +605,7 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
         });
     };
     static const bool trace = std::getenv("MCRAW_TRACE") != nullptr;
+    static const bool trace2 = trace && std::atoi(std::getenv("MCRAW_TRACE")) >= 2; // a line per chunk
     auto now = []() { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double, std::milli>(b - a).count();
@@ -891,6 +892,7 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
         }
         if (post.flags)
             (void)mcraw_pool_set_post(I.pool, nullptr);
+        const auto tSub = now();
         if (rc != 0)
             throw IOException(std::string("GPU decode failed: ") + mcraw_pool_last_error());
         if (direct) {
@@ -904,6 +906,8 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
             copying[ci % noutslots] = std::async(std::launch::async, copyOut, ci);
         }
         tDecode += ms(t0, now());
+        if (trace2)
+            std::fprintf(stderr, "[mcraw2] chunk %zu (%zu frames) at %.2f ms: batch call %.2f, behind it %.2f\n", ci, c.count, ms(tStart, t0), ms(t0, tSub), ms(tSub, now()));
     }
     {
         const auto t0 = now();
