@@ -207,3 +207,53 @@ def test_export_tool_one_frame_per_chunk(container, tmp_path):
         assert len(lines) == len(order)
         for i, ts in enumerate(order):
             assert ("crc32 %08x" % (zlib.crc32(images[ts].tobytes()) & 0xFFFFFFFF)) in lines[i], (rep, i)
+
+
+def test_load_frame_random_walk(container, tmp_path):
+    """A few hundred loadFrame calls in a seeded random order -- runs of consecutive frames (where the facade decodes ahead), jumps,
+    repeats, output options that change in the middle of a run, a batch now and then: every call's bytes are its frame's in the
+    form it asked for.  (MCRAW_WALK=<n> for a longer walk.)"""
+    import random
+    d, path, images, audio = container
+    test_load_frame_in_any_order(container, "0", tmp_path)  # (builds the program)
+    exe = str(d / "frame_order")
+    rng = random.Random(20261003)
+    ts = sorted(images)
+    toks, i, bits = [], 0, 16
+    for step in range(int(os.environ.get("MCRAW_WALK", "300"))):
+        r = rng.random()
+        if r < 0.60:
+            i = (i + 1) % len(ts)  # the reference's loop: the next frame (wrapping at the end)
+        elif r < 0.75:
+            i = rng.randrange(len(ts))
+        elif r < 0.80:
+            pass  # the same frame again
+        elif r < 0.90:
+            bits = rng.choice([16, 16, 12, 10, 14])
+            toks.append("o%d" % bits)
+            continue
+        else:
+            toks.append("b")
+            continue
+        toks.append(str(i))
+    crc = {}
+    want, bits = [], 16
+    for tok in toks:
+        if tok[0] == "o":
+            bits = int(tok[1:])
+            continue
+        for k in (range(len(ts)) if tok == "b" else [int(tok)]):
+            key = (k, 16 if tok == "b" else bits)
+            if key not in crc:
+                img = images[ts[k]]
+                data = img.tobytes() if key[1] == 16 else L.oracle_post(img, None, bits=key[1]).tobytes()
+                crc[key] = (len(data), zlib.crc32(data) & 0xFFFFFFFF)
+            img = images[ts[k]]
+            line = "%s%d %d %08x" % ("b" if tok == "b" else "", k, crc[key][0], crc[key][1])
+            want.append(line if tok == "b" else line + " %dx%d" % (img.shape[1], img.shape[0]))
+    r = _run([exe, path] + toks, str(tmp_path))
+    assert r.returncode == 0, r.stdout[-500:] + r.stderr[-500:]
+    got = r.stdout.split("\n")[:-1]
+    assert len(got) == len(want)
+    bad = [(n, g, w) for n, (g, w) in enumerate(zip(got, want)) if g != w]
+    assert not bad, bad[:3]
