@@ -50,14 +50,19 @@ int main(int argc, char **argv)
             const size_t i = static_cast<size_t>(std::atol(argv[a]));
             if (i >= frames.size())
                 return 2;
-            if (output.bitsPerSample == 16) {
-                d.loadFrame(frames[i], data, meta);
-            } else {
-                std::vector<std::vector<uint8_t>> one;
-                std::vector<nlohmann::json> metas;
-                d.loadFrames({frames[i]}, one, metas, output);
-                data = one[0];
-                meta = metas[0];
+            try {
+                if (output.bitsPerSample == 16) {
+                    d.loadFrame(frames[i], data, meta);
+                } else {
+                    std::vector<std::vector<uint8_t>> one;
+                    std::vector<nlohmann::json> metas;
+                    d.loadFrames({frames[i]}, one, metas, output);
+                    data = one[0];
+                    meta = metas[0];
+                }
+            } catch (const motioncam::IOException &e) { // (a frame that does not decode: said, and the walk goes on)
+                std::printf("%zu failed: %s\n", i, e.what());
+                continue;
             }
             const int w = meta["width"], h = meta["height"];
             std::printf("%zu %zu %08x %dx%d\n", i, data.size(), crc32(data.data(), data.size()), w, h);

@@ -257,3 +257,31 @@ def test_load_frame_random_walk(container, tmp_path):
     assert len(got) == len(want)
     bad = [(n, g, w) for n, (g, w) in enumerate(zip(got, want)) if g != w]
     assert not bad, bad[:3]
+
+
+def test_load_frame_walks_past_a_frame_that_does_not_decode(container, tmp_path):
+    """Frame 2 of 5 is damaged (its side streams cut off).  Decoded ahead of its call it fails quietly; the call FOR it then
+    takes the ordinary path and throws what the reference throws, the calls around it get their frames -- forwards (where the
+    damaged frame is decoded ahead), backwards, and asked for twice."""
+    d, path, images, audio = container
+    test_load_frame_in_any_order(container, "0", tmp_path)  # (builds the program)
+    exe = str(d / "frame_order")
+    ts = sorted(images)
+    specs = []
+    for n, t in enumerate(ts):
+        img = images[t]
+        buf = L.encode7(img)
+        if n == 2:
+            buf = buf[:len(buf) // 2].copy()  # (the bits / refs streams lie behind the payload: gone)
+        specs.append((t, 7, img.shape[1], img.shape[0], buf))
+    bad = L.write_mcraw(str(tmp_path / "damaged.mcraw"), specs)
+    r = _run([exe, bad] + "0 1 2 3 4 3 2 2 1 0 1 2 3".split(), str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = r.stdout.split("\n")[:-1]
+    for line, i in zip(got, [0, 1, 2, 3, 4, 3, 2, 2, 1, 0, 1, 2, 3]):
+        if i == 2:
+            assert line == "2 failed: Failed to uncompress frame", line
+        else:
+            img = images[ts[i]]
+            assert line == "%d %d %08x %dx%d" % (i, img.nbytes, zlib.crc32(img.tobytes()) & 0xFFFFFFFF, img.shape[1], img.shape[0]), line
+    assert len(got) == 13
