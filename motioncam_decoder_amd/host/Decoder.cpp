@@ -922,9 +922,11 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
         if (f.valid())
             f.get();
     }
-    if (single && A.rd.armed && A.rd.done.valid() && A.rd.done.wait_for(std::chrono::seconds(0)) == std::future_status::ready) {
-        // the next frame's payload is here already: onto the GPU behind this call (the caller works on this frame meanwhile),
-        // and the payload of the one behind it on its way into the buffer this call's frame came from
+    if (single && hitRd && A.rd.armed && A.rd.done.valid() && A.rd.done.wait_for(std::chrono::seconds(0)) == std::future_status::ready) {
+        // the caller walks the index (this frame had been read ahead) and the next frame's payload is here already: onto the GPU
+        // behind this call (the caller works on this frame meanwhile), and the payload of the one behind it on its way into the
+        // buffer this call's frame came from.  (A caller that jumps about never gets here: its next call would have to wait
+        // for a frame it does not want.)
         if (A.rd.done.get()) {
             const Timestamp t = A.rd.ts;
             const int b = A.rd.buf;
