@@ -8,10 +8,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -81,9 +83,15 @@ struct Slot {
     ::mcraw_ticket *owner = nullptr; // host-memory batch whose statuses still sit in this slot's arena
     int owner_part = -1;
     hipEvent_t uploaded = nullptr; // host-memory pipeline: inputs of the sub-batch are in HBM
+#ifdef MCRAW_TIMELINE
+    hipEvent_t tl_begin = nullptr; // in front of the sub-batch's uploads
+    double tl_host = 0.0;          // host clock when the sub-batch was queued (ms since the context's first)
+#endif
     hipEvent_t decoded = nullptr;  // ... its kernels have run
     hipStream_t stream = nullptr; // the slot's own stream (host-memory pipeline: the kernels of a sub-batch)
     bool busy = false;
+    uint64_t seq = 0;    // host-memory pipeline: the order the sub-batches were queued in
+    bool landed = false; // ... this one's downloads are known to be over (its statuses may still wait for their ticket)
     // A device-memory batch submitted without a status request: what is needed to plan frames again
     // whose header asks for more workspace than they were given (mcraw_ctx_synchronize, or the
     // next use of the slot, does that before the batch is forgotten).
@@ -99,6 +107,7 @@ struct Part {
     int slot, first, count;
     size_t status_off;
     bool drained;
+    bool sent; // its status words went home behind its kernels (send_status): nothing to fetch when it is drained
 };
 
 struct KStat {
@@ -118,9 +127,22 @@ struct mcraw_ticket {
     std::vector<Part> parts;
     std::vector<int> skipped; // frames that no sub-batch holds (no device memory for their workspace): failed on their own
     Post post{0, 0, 0}; // post stage the batch was submitted with
+    bool small = false; // a few sub-batches only: takes the short way home (host_submit)
+    // A large batch queued with mcraw_decode_batch_async is dealt out as a row of short ones (deal_host): this ticket then holds
+    // the ones still under way (oldest first, with the index of their first frame) and the results of those that have landed.
+    bool composite = false;
+    std::vector<std::unique_ptr<mcraw_ticket>> pieces;
+    std::vector<int> piece_first;
+    std::vector<size_t> got_written;
+    std::vector<int32_t> got_status;
 };
 
 struct mcraw_ctx {
+    uint64_t part_seq = 0;
+#ifdef MCRAW_TIMELINE
+    hipEvent_t tl0 = nullptr; // the timeline's zero: recorded on the upload stream in front of the first sub-batch
+    std::chrono::steady_clock::time_point tl_host0;
+#endif
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t h2d = nullptr, d2h = nullptr; // host-memory pipeline: one stream per copy direction
@@ -813,7 +835,7 @@ int submit(mcraw_ctx *c, Slot &s, const mcraw_frame *frames, int n, const std::v
     return 0;
 }
 
-int fetch_status(mcraw_ctx *c, Slot &s, size_t status_off, int n, hipStream_t st, int32_t *status, uint32_t *encH = nullptr);
+int fetch_status(mcraw_ctx *c, Slot &s, size_t status_off, int n, hipStream_t st, int32_t *status, uint32_t *encH = nullptr, bool sent = false);
 
 // Bring the statuses of one sub-batch home (they live in its slot's arena) and wait for its downloads:
 // the slot is free afterwards.
@@ -823,9 +845,27 @@ int drain_part(mcraw_ticket *t, int idx)
     if (p.drained)
         return 0;
     Slot &s = t->c->slots[p.slot];
-    if (int rc = fetch_status(t->c, s, p.status_off, p.count, s.stream, t->status.data() + p.first, t->encH.data() + p.first))
-        return rc;
-    HIP_TRY(hipEventSynchronize(s.done)); // its downloads, queued on the download stream
+    if (p.sent) {
+        HIP_TRY(hipEventSynchronize(s.done)); // its downloads, queued on the download stream behind its kernels and its status words
+        if (int rc = fetch_status(t->c, s, p.status_off, p.count, s.stream, t->status.data() + p.first, t->encH.data() + p.first, true))
+            return rc;
+    } else {
+        if (int rc = fetch_status(t->c, s, p.status_off, p.count, s.stream, t->status.data() + p.first, t->encH.data() + p.first))
+            return rc;
+        HIP_TRY(hipEventSynchronize(s.done)); // its downloads, queued on the download stream
+    }
+#ifdef MCRAW_TIMELINE
+    {
+        float b = 0, u = 0, d = 0, e = 0;
+        (void)hipEventElapsedTime(&b, t->c->tl0, s.tl_begin);
+        (void)hipEventElapsedTime(&u, t->c->tl0, s.uploaded);
+        (void)hipEventElapsedTime(&d, t->c->tl0, s.decoded);
+        (void)hipEventElapsedTime(&e, t->c->tl0, s.done);
+        const double now = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t->c->tl_host0).count();
+        std::fprintf(stderr, "[tl] slot %2d frames %3d+%d  queued (host) %8.3f | upload from %8.3f to %8.3f, decoded %8.3f, downloaded %8.3f | drained (host) %8.3f\n",
+                     p.slot, p.first, p.count, s.tl_host, b, u, d, e, now);
+    }
+#endif
     s.busy = false;
     s.owner = nullptr;
     p.drained = true;
@@ -892,17 +932,20 @@ int acquire_slot(mcraw_ctx *c, Slot **out, bool device_batch = false)
 
 // Fetch statuses of a finished-or-running batch (synchronises on the stream); `encH`: the coded
 // height of every type-7 frame, from its header (rows written = min(height, encH), RawData.cpp:571, :611).
-int fetch_status(mcraw_ctx *c, Slot &s, size_t status_off, int n, hipStream_t st, int32_t *status, uint32_t *encH)
+// `sent`: the words are in s.status_host already (send_status below, and the caller has waited for what was queued behind it).
+int fetch_status(mcraw_ctx *c, Slot &s, size_t status_off, int n, hipStream_t st, int32_t *status, uint32_t *encH, bool sent)
 {
     const int ndev = static_cast<int>(s.order.size()), n7 = s.n7, n6 = ndev - n7, w7 = s.wpf;
     const size_t nstatus = static_cast<size_t>(w7) * n7 + n6 + 1;
     const size_t words = nstatus + n7; // statuses (w7 per type-7 frame, one per legacy frame, one spare), coded heights
-    if (int rc = ensure(s.status_host, sizeof(int32_t) * words, true))
-        return rc;
-    if (ndev)
-        HIP_TRY(hipMemcpyAsync(s.status_host.p, static_cast<uint8_t *>(s.arena.p) + status_off, sizeof(int32_t) * words,
-                               hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    if (!sent) {
+        if (int rc = ensure(s.status_host, sizeof(int32_t) * words, true))
+            return rc;
+        if (ndev)
+            HIP_TRY(hipMemcpyAsync(s.status_host.p, static_cast<uint8_t *>(s.arena.p) + status_off, sizeof(int32_t) * words,
+                                   hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     const int32_t *dev = static_cast<const int32_t *>(s.status_host.p);
     for (int i = 0; i < n && i < static_cast<int>(s.host_status.size()); i++)
         status[i] = s.host_status[i];
@@ -921,6 +964,32 @@ int fetch_status(mcraw_ctx *c, Slot &s, size_t status_off, int n, hipStream_t st
             if (s.order[j] < n)
                 encH[s.order[j]] = static_cast<uint32_t>(dev[nstatus + j]);
     (void)c;
+    return 0;
+}
+
+// Host-memory pipeline: the sub-batch's status words go home behind its kernels, on the same stream, written into pinned host
+// memory by a kernel of one workgroup.  (Fetched with a copy only when the batch is waited for, they are queued on the copy engine
+// behind whatever the NEXT batch has put there, and the wait for batch A ends when batch B's downloads do: tools/timeline_host.sh;
+// a stream of ticketed batches then runs no faster than synchronous calls.  Sent with a copy of their own at submit time -- on the
+// slot's stream or on the download lane -- they take the engine the frames' download would have had, and with a few batches
+// queued every other download or so runs on one that moves 13 GB/s.)
+__global__ void k_words_home(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint32_t n)
+{
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x)
+        __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+int send_status(Slot &s, size_t status_off, hipStream_t st)
+{
+    const int ndev = static_cast<int>(s.order.size()), n7 = s.n7, n6 = ndev - n7, w7 = s.wpf;
+    const size_t words = static_cast<size_t>(w7) * n7 + n6 + 1 + n7;
+    if (int rc = ensure(s.status_host, sizeof(int32_t) * words, true))
+        return rc;
+    if (ndev) {
+        hipLaunchKernelGGL(k_words_home, dim3(1), dim3(256), 0, st, static_cast<uint32_t *>(s.status_host.p),
+                           reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(s.arena.p) + status_off), static_cast<uint32_t>(words));
+        HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 
@@ -1152,6 +1221,15 @@ int host_submit_part(mcraw_ticket *t, int first, int count)
         din[i] = in_off[i] != SIZE_MAX ? static_cast<uint8_t *>(s.dev_in.p) + in_off[i] : nullptr;
         dout[i] = out_off[i] != SIZE_MAX ? reinterpret_cast<uint16_t *>(static_cast<uint8_t *>(s.dev_out.p) + out_off[i]) : nullptr;
     }
+#ifdef MCRAW_TIMELINE
+    if (!c->tl0) {
+        HIP_TRY(hipEventCreate(&c->tl0));
+        HIP_TRY(hipEventRecord(c->tl0, c->h2d));
+        c->tl_host0 = std::chrono::steady_clock::now();
+    }
+    HIP_TRY(hipEventRecord(s.tl_begin, c->h2d));
+    s.tl_host = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c->tl_host0).count();
+#endif
     for (const Run &r : rin) {
         hipError_t e = hipMemcpyAsync(static_cast<uint8_t *>(s.dev_in.p) + r.dev, reinterpret_cast<const void *>(r.host), r.bytes,
                                       hipMemcpyHostToDevice, c->h2d);
@@ -1171,6 +1249,9 @@ int host_submit_part(mcraw_ticket *t, int first, int count)
     size_t status_off = 0;
     if (int rc = submit(c, s, frames + first, count, &geom, din.data(), dout.data(), st, &status_off))
         return rc;
+    if (t->small)
+        if (int rc = send_status(s, status_off, st))
+            return rc;
     HIP_TRY(hipEventRecord(s.decoded, st));
     HIP_TRY(hipStreamWaitEvent(c->d2h, s.decoded, 0));
     // downloads: only frames the host has not rejected (a rejected frame's buffer stays untouched; the
@@ -1199,12 +1280,14 @@ int host_submit_part(mcraw_ticket *t, int first, int count)
     }
     HIP_TRY(hipEventRecord(s.done, c->d2h));
     s.busy = true;
+    s.landed = false;
+    s.seq = ++c->part_seq;
     // the slot keeps this sub-batch's statuses until they are drained into the ticket: by
     // mcraw_ticket_wait, or earlier by acquire_slot when the ring comes round (more sub-batches in
     // flight than slots)
     s.owner = t;
     s.owner_part = static_cast<int>(t->parts.size());
-    t->parts.push_back({static_cast<int>(sp - c->slots), first, count, status_off, false});
+    t->parts.push_back({static_cast<int>(sp - c->slots), first, count, status_off, false, t->small});
     return 0;
 }
 
@@ -1231,8 +1314,8 @@ int host_submit(mcraw_ticket *t)
         return static_cast<size_t>((encW * encH / 64u + GROUP_BLOCKS - 1u) / GROUP_BLOCKS);
     };
     constexpr size_t WS_PER_GROUP = 64u * 3u + 4u * ITEM_SPLIT; // bits (u8) + refs (u16) per block, one offset per item
-    int first = 0;
-    while (first < n) {
+    // the sub-batch that starts at frame `first`
+    auto cut = [&](int first) {
         size_t bytes = 0, gmax = 0;
         int count = 0, n7 = 0;
         while (first + count < n) {
@@ -1247,6 +1330,45 @@ int host_submit(mcraw_ticket *t)
             n7 += g ? 1 : 0;
             count++;
         }
+        return count;
+    };
+    // A batch of a few sub-batches -- a caller that streams tickets, the facade's chunks -- goes the short way: its status
+    // words come home behind its kernels (send_status), so waiting for it is waiting for ITS downloads, and the next ticket's
+    // uploads run beside them (7-frame UHD tickets, two in flight: 2 560 -> 2 990 frames/s; tools/bench_tickets.py).  That
+    // way works while little is queued: with four tickets in flight, or more sub-batches than the ring has slots, the
+    // downloads fall to a quarter of their rate (13 GB/s; the runtime's choice of copy engine is the suspect), where the long
+    // way -- statuses fetched when the batch is waited for, which queues that fetch behind everything submitted since and so
+    // lets the ring run empty now and then -- keeps 2 700-2 900.  So: the short way for batches of up to SHORT_PARTS
+    // sub-batches, and such a batch is queued only when at most ONE other batch still has downloads under way.
+    constexpr int SHORT_PARTS = 6;
+    {
+        int parts = 0;
+        for (int f = 0; f < n && parts <= SHORT_PARTS; parts++)
+            f += cut(f);
+        t->small = parts <= SHORT_PARTS;
+    }
+    while (t->small) {
+        int others = 0;
+        Slot *oldest = nullptr;
+        const ::mcraw_ticket *seen[NSLOT];
+        for (Slot &x : c->slots)
+            if (x.busy && !x.landed && x.owner && x.owner != t) {
+                bool dup = false;
+                for (int k = 0; k < others; k++)
+                    dup = dup || seen[k] == x.owner;
+                if (!dup)
+                    seen[others++] = x.owner;
+                if (!oldest || x.seq < oldest->seq)
+                    oldest = &x;
+            }
+        if (others <= 1)
+            break;
+        HIP_TRY(hipEventSynchronize(oldest->done));
+        oldest->landed = true;
+    }
+    int first = 0;
+    while (first < n) {
+        int count = cut(first);
         int rc = host_submit_part(t, first, count);
         // out of device memory: halve the sub-batch; a single frame that cannot get its workspace fails alone
         // (the failed attempt may have queued uploads from the caller's buffers into a slot that no part of the ticket owns:
@@ -1312,17 +1434,67 @@ void forget_ticket(mcraw_ticket *t)
         }
 }
 
+// A host-memory batch dealt out as a row of short batches (host_submit: up to SHORT_PARTS sub-batches each), two of them under
+// way at a time -- the regime in which the copy lanes never drain and never crowd: 240 UHD frames in one call 2 750 -> 3 000
+// frames/s host to host.  `finish`: wait for all of them (the synchronous call); else the last ones stay in `pieces` for
+// land_pieces.  Results go to written / status_out (either may be null) at the frames' positions in the batch.
+int land_piece(std::vector<std::unique_ptr<mcraw_ticket>> &pieces, std::vector<int> &piece_first, size_t *written, int32_t *status_out)
+{
+    mcraw_ticket *p = pieces.front().get(); // the oldest piece: wait, file its results
+    const int first = piece_first.front();
+    const int r = host_finish(p, written ? written + first : nullptr, status_out ? status_out + first : nullptr);
+    forget_ticket(p);
+    pieces.erase(pieces.begin());
+    piece_first.erase(piece_first.begin());
+    return r;
+}
+
+int deal_host(mcraw_ctx *c, const mcraw_frame *frames, int n, size_t *written, int32_t *status_out,
+              std::vector<std::unique_ptr<mcraw_ticket>> &pieces, std::vector<int> &piece_first, bool finish)
+{
+    // (a piece is cut by bytes here and into sub-batches of up to 96 MB by host_submit, which ends one in front of the frame that
+    // would not fit: four sub-batches' worth of bytes are five or six sub-batches, short by host_submit's count)
+    constexpr size_t PIECE_BYTES = 4 * (96ull << 20);
+    int rc = 0, first = 0;
+    while (first < n && rc == 0) {
+        size_t bytes = 0;
+        int count = 0;
+        while (first + count < n) {
+            const mcraw_frame &f = frames[first + count];
+            const size_t fb = static_cast<size_t>(f.len) + (f.width > 0 && f.height > 0 ? static_cast<size_t>(f.width) * f.height * 2 : 0);
+            if (count > 0 && bytes + fb > PIECE_BYTES)
+                break;
+            bytes += fb;
+            count++;
+        }
+        std::unique_ptr<mcraw_ticket> p(new mcraw_ticket());
+        p->c = c;
+        p->frames.assign(frames + first, frames + first + count);
+        rc = host_submit(p.get());
+        if (rc != 0) { // (host_submit has waited for whatever it had queued of this piece)
+            forget_ticket(p.get());
+            break;
+        }
+        pieces.push_back(std::move(p));
+        piece_first.push_back(first);
+        first += count;
+        if (pieces.size() >= 2 && (finish || first < n))
+            rc = land_piece(pieces, piece_first, written, status_out);
+    }
+    while (!pieces.empty() && (finish || rc != 0)) { // (behind a failure too: nothing of the batch may still be moving then)
+        const int r = land_piece(pieces, piece_first, written, status_out);
+        if (rc == 0)
+            rc = r;
+    }
+    return rc;
+}
+
 // Synchronous host-memory batch.
 int decode_host(mcraw_ctx *c, const mcraw_frame *frames, int n, size_t *written, int32_t *status_out)
 {
-    mcraw_ticket t;
-    t.c = c;
-    t.frames.assign(frames, frames + n);
-    int rc = host_submit(&t);
-    if (rc == 0)
-        rc = host_finish(&t, written, status_out);
-    forget_ticket(&t);
-    return rc;
+    std::vector<std::unique_ptr<mcraw_ticket>> pieces;
+    std::vector<int> piece_first;
+    return deal_host(c, frames, n, written, status_out, pieces, piece_first, true);
 }
 
 mcraw_ctx *g_default = nullptr;
@@ -1465,9 +1637,16 @@ int mcraw_ctx_create(int device, mcraw_ctx **out)
     for (Slot &s : c->slots) {
         HIP_TRY(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
+#ifdef MCRAW_TIMELINE // (tools/timeline_host.sh: when did every sub-batch's upload, kernels and download end on the GPU's clock?)
+        HIP_TRY(hipEventCreate(&s.done));
+        HIP_TRY(hipEventCreate(&s.uploaded));
+        HIP_TRY(hipEventCreate(&s.decoded));
+        HIP_TRY(hipEventCreate(&s.tl_begin));
+#else
         HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s.uploaded, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&s.decoded, hipEventDisableTiming));
+#endif
         HIP_TRY(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
     }
     for (Slot &s : c->dslots) {
@@ -1575,10 +1754,12 @@ int mcraw_decode_batch_async(mcraw_ctx *c, const mcraw_frame *frames, int nframe
     HIP_TRY(hipSetDevice(c->device));
     mcraw_ticket *t = new mcraw_ticket();
     t->c = c;
-    if (nframes)
-        t->frames.assign(frames, frames + nframes);
-    if (int rc = host_submit(t)) {
-        forget_ticket(t);
+    // (queued as a row of short batches: the call returns when the last of them is queued, as it did when the ring of slots was
+    // shorter than the batch; what has landed by then is kept in the ticket)
+    t->composite = true;
+    t->got_written.assign(static_cast<size_t>(nframes), 0);
+    t->got_status.assign(static_cast<size_t>(nframes), 0);
+    if (int rc = deal_host(c, frames, nframes, t->got_written.data(), t->got_status.data(), t->pieces, t->piece_first, false)) {
         delete t;
         return rc;
     }
@@ -1594,8 +1775,19 @@ int mcraw_ticket_wait(mcraw_ticket *t, size_t *written, int32_t *status)
     int rc;
     {
         std::lock_guard<std::mutex> lk(c->mu);
-        rc = hipSetDevice(c->device) == hipSuccess ? host_finish(t, written, status) : -static_cast<int>(hipErrorInvalidDevice);
-        forget_ticket(t);
+        rc = hipSetDevice(c->device) == hipSuccess ? 0 : -static_cast<int>(hipErrorInvalidDevice);
+        while (!t->pieces.empty()) { // (whatever happens: every piece is waited for, the first failure is the one reported)
+            const int r = land_piece(t->pieces, t->piece_first, t->got_written.data(), t->got_status.data());
+            if (rc == 0)
+                rc = r;
+        }
+        const size_t n = t->got_status.size();
+        for (size_t i = 0; i < n; i++) {
+            if (written)
+                written[i] = t->got_written[i];
+            if (status)
+                status[i] = t->got_status[i];
+        }
     }
     delete t;
     return rc;

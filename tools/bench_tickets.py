@@ -48,13 +48,17 @@ def free_sets(sets):
 
 for per in [int(x) for x in os.environ.get("PERS", "3 7 16 40").split()]:
     row = {"frames_per_batch": per, "pool": bool(os.environ.get("POOL")), "separate_outputs": SEPOUT}
-    for depth in (1, 2, 3, 4):
+    for depth in [int(x) for x in os.environ.get("DEPTHS", "1 2 3 4").split()]:
         sets = make_sets(per, depth + 1)
         nb = max(4, total // per)
         for rep in range(2):  # (the first pass warms the slots)
             q = []
             t0 = time.perf_counter()
             for b in range(nb):
+                if os.environ.get("SYNC") and depth == 1:  # the synchronous entry point (a large batch is dealt out inside)
+                    wr, st = ctx.decode_batch(sets[b % (depth + 1)][0]) if os.environ.get("POOL") else ctx.decode_batch(sets[b % (depth + 1)][0], mem=M.MEM_HOST)
+                    assert all(s == 0 for s in st)
+                    continue
                 q.append(ctx.decode_batch_async(sets[b % (depth + 1)][0]))
                 if len(q) >= depth:
                     wr, st = ctx.wait(q.pop(0))
