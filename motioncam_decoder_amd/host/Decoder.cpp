@@ -157,8 +157,8 @@ struct Decoder::Impl {
 
     // Pinned staging reused across loadFrames() calls.  Every slot has one slice per pool member (GPU),
     // allocated by that member's own thread: on the NUMA node of its GPU.
-    static constexpr int kOutSlots = 2; // decoded chunks whose copy-out may still be running (four until the output vectors got huge pages: the copy-out keeps up now)
-    static constexpr int kInSlots = 3;  // (loadFramesInto) chunk being read, chunk queued, chunk finishing on the GPU
+    static constexpr int kOutSlots = 3; // chunk queued, chunk finishing on the GPU, chunk being copied out
+    static constexpr int kInSlots = 3;  // chunk being read, chunk queued, chunk finishing on the GPU
     struct Slice {
         uint8_t *p = nullptr;
         size_t cap = 0;
@@ -742,11 +742,11 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
     }
 
     // chunks: as many frames as fit the staging budget of one slot (at least one frame)
-    // (MCRAW_SLOT_MB: 240 UHD frames run through the pipeline in 142 / 124 / 116 ms with slots of 192 / 384 / 768 MB -- and the pinned
-    // staging of the first call costs 0.2 ms per MB: 330 / 420 / 530 ms of set-up.  192 MB is the faster choice up to a thousand frames.)
+    // (MCRAW_SLOT_MB: 240 UHD frames run through the pipeline in 140 / 117 / 120 / 108 ms with slots of 96 / 128 / 192 / 384 MB -- three
+    // for the inputs, three for the outputs -- and the pinned staging of the first call costs 0.2 ms per MB.)
     static const size_t kSlotBudget = []() {
         const char *e = std::getenv("MCRAW_SLOT_MB");
-        return (e && std::atoi(e) > 0 ? static_cast<size_t>(std::atoi(e)) : size_t(192)) << 20;
+        return (e && std::atoi(e) > 0 ? static_cast<size_t>(std::atoi(e)) : size_t(128)) << 20;
     }();
     struct Chunk {
         size_t first, count, inBytes, outBytes;
@@ -778,10 +778,9 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
             maxOut[m] = std::max(maxOut[m], out[m]);
         }
     }
-    // with the caller's buffers as destination the GPU stage is asynchronous (below): one more input slot
-    const int nslots = static_cast<int>(std::min<size_t>(direct ? Impl::kInSlots : 2, chunks.size()));
-    // a copy-out is one thread per frame (vector::assign faults its pages in as it copies), so several
-    // chunks' copy-outs have to be in flight to keep up with the GPU: one output slot each
+    // the GPU stage runs on tickets (below: chunk ci is queued behind chunk ci - 1 before that one is waited for, so the PCIe
+    // lanes never drain between chunks): three input slots, and three output slots where the frames go through pinned staging
+    const int nslots = static_cast<int>(std::min<size_t>(Impl::kInSlots, chunks.size()));
     const int noutslots = static_cast<int>(std::min<size_t>(Impl::kOutSlots, chunks.size()));
     for (int sl = 0; sl < nslots; sl++) {
         I.pinIn[sl].resize(G);
@@ -851,7 +850,7 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
                 throw IOException(frames[k].type == kTypeBlock ? "Failed to uncompress frame"
                                                                : "Failed to uncompress legacy frame");
     };
-    struct Queued { // loadFramesInto: the chunk whose ticket is still open
+    struct Queued { // the chunk whose ticket is still open
         mcraw_pool_ticket *ticket = nullptr;
         size_t ci = 0;
         ~Queued()
@@ -891,27 +890,21 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
         // the post stage is a property of this call, not of the contexts: set for the batch, cleared behind it
         int rc = post.flags ? mcraw_pool_set_post(I.pool, &post) : 0;
         mcraw_pool_ticket *ticket = nullptr;
-        if (rc == 0) {
-            if (direct) // queued BEHIND chunk ci-1, which is waited for below: the PCIe lanes never drain
-                rc = mcraw_pool_decode_batch_async(I.pool, frames.data() + c.first, static_cast<int>(c.count), &ticket);
-            else
-                rc = mcraw_pool_decode_batch(I.pool, frames.data() + c.first, static_cast<int>(c.count),
-                                             written.data() + c.first, status.data() + c.first);
-        }
+        if (rc == 0) // queued BEHIND chunk ci-1, which is waited for below: the PCIe lanes never drain
+            rc = mcraw_pool_decode_batch_async(I.pool, frames.data() + c.first, static_cast<int>(c.count), &ticket);
         if (post.flags)
             (void)mcraw_pool_set_post(I.pool, nullptr);
         const auto tSub = now();
         if (rc != 0)
             throw IOException(std::string("GPU decode failed: ") + mcraw_pool_last_error());
-        if (direct) {
+        {
             mcraw_pool_ticket *prev = queued.ticket;
             const size_t prevCi = queued.ci;
             queued.ticket = ticket; // owned from here on, whatever chunk ci-1 turns out to be
             queued.ci = ci;
             finishTicket(prev, prevCi);
-        } else {
-            checkChunk(ci);
-            copying[ci % noutslots] = std::async(std::launch::async, copyOut, ci);
+            if (prev && !direct)
+                copying[prevCi % noutslots] = std::async(std::launch::async, copyOut, prevCi);
         }
         tDecode += ms(t0, now());
         if (trace2)
@@ -925,6 +918,8 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
         tDecode += ms(t0, now());
     }
     const auto t1 = now();
+    if (!direct)
+        copyOut(queued.ci); // (the last chunk: on this thread)
     for (size_t k = 0; k < copying.size(); k++) { // oldest first
         std::future<void> &f = copying[(chunks.size() + k) % copying.size()];
         if (f.valid())
