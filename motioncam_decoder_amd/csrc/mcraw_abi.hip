@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -137,8 +138,13 @@ struct mcraw_ticket {
     std::vector<int32_t> got_status;
 };
 
+// Contexts of this process per device.  The short way of the host-memory pipeline (host_submit) is tuned for ONE stream of batches
+// on a GPU's copy engines: two contexts on one device (the bench's pool of two members on one GPU) take the long way, as before.
+std::atomic<int> g_ctx_on_device[64];
+
 struct mcraw_ctx {
     uint64_t part_seq = 0;
+    bool counted = false; // in g_ctx_on_device
 #ifdef MCRAW_TIMELINE
     hipEvent_t tl0 = nullptr; // the timeline's zero: recorded on the upload stream in front of the first sub-batch
     std::chrono::steady_clock::time_point tl_host0;
@@ -1291,6 +1297,8 @@ int host_submit_part(mcraw_ticket *t, int first, int count)
     return 0;
 }
 
+inline bool alone_on_device(const mcraw_ctx *c) { return !c->counted || g_ctx_on_device[c->device].load() <= 1; }
+
 // Queue a host-memory batch (ticket->frames): returns when the last sub-batch is submitted.
 int host_submit(mcraw_ticket *t)
 {
@@ -1345,7 +1353,7 @@ int host_submit(mcraw_ticket *t)
         int parts = 0;
         for (int f = 0; f < n && parts <= SHORT_PARTS; parts++)
             f += cut(f);
-        t->small = parts <= SHORT_PARTS;
+        t->small = parts <= SHORT_PARTS && alone_on_device(c);
     }
     while (t->small) {
         int others = 0;
@@ -1454,7 +1462,7 @@ int deal_host(mcraw_ctx *c, const mcraw_frame *frames, int n, size_t *written, i
 {
     // (a piece is cut by bytes here and into sub-batches of up to 96 MB by host_submit, which ends one in front of the frame that
     // would not fit: four sub-batches' worth of bytes are five or six sub-batches, short by host_submit's count)
-    constexpr size_t PIECE_BYTES = 4 * (96ull << 20);
+    const size_t PIECE_BYTES = alone_on_device(c) ? 4 * (96ull << 20) : SIZE_MAX;
     int rc = 0, first = 0;
     while (first < n && rc == 0) {
         size_t bytes = 0;
@@ -1656,6 +1664,10 @@ int mcraw_ctx_create(int device, mcraw_ctx **out)
         HIP_TRY(hipEventCreateWithFlags(&s.join, hipEventDisableTiming));
     }
     guard.c = nullptr;
+    if (c->device >= 0 && c->device < 64) {
+        g_ctx_on_device[c->device]++;
+        c->counted = true;
+    }
     *out = c;
     return 0;
 }
@@ -1664,6 +1676,8 @@ void mcraw_ctx_destroy(mcraw_ctx *c)
 {
     if (!c)
         return;
+    if (c->counted)
+        g_ctx_on_device[c->device]--;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     auto release = [](Slot &s) {
