@@ -180,3 +180,49 @@ def test_xcd_mapping_is_decided_for_a_caller_that_never_reuses_an_output_buffer(
         for i in (0, n - 1):
             assert np.array_equal(t[i * w * h * 2:(i + 1) * w * h * 2].cpu().numpy().view(np.uint16).reshape(h, w), imgs[i % 4])
     ctx.close()
+
+
+@pytest.mark.parametrize("entry", ["sync", "ticket"])
+def test_large_host_batch_is_dealt_out_in_pieces(gpu_ctx, entry):
+    """A host-memory batch of more than 384 MB is dealt out as a row of short batches inside the call (two under way): every
+    frame's result lands at ITS place in the caller's arrays -- frames that fail (cut in half) in the first, a middle and the last
+    piece, a legacy frame among them, an output buffer that is too small -- and nothing but the failing frames is touched."""
+    w, h = 4032, 3024
+    imgs = [L.synth_image(w, h, 12, 1, 12.0, 8100 + i) for i in range(3)]
+    bufs7 = [L.encode7(im) for im in imgs]
+    trunc = bufs7[1][: bufs7[1].size // 2].copy()
+    small = L.natural_image_np(800, 600, 12, 12.0, 11)
+    buf6 = L.encode6(small)
+    n = 34  # 34 x 38 MB: four pieces
+    items = []
+    for i in range(n):
+        if i in (2, 16, n - 1):
+            items.append((7, w, h, trunc, None, w * h))
+        elif i == 9:
+            items.append((6, 800, 600, buf6, small, 800 * 600))
+        elif i == 21:
+            items.append((7, w, h, bufs7[i % 3], None, w * h - 1))  # capacity one sample short
+        else:
+            items.append((7, w, h, bufs7[i % 3], imgs[i % 3], w * h))
+    outs, descs = [], []
+    for typ, ww, hh, buf, img, cap in items:
+        out = np.full((hh, ww), 0xA5A5, np.uint16)
+        outs.append(out)
+        descs.append((buf.ctypes.data, buf.size, ww, hh, typ, out.ctypes.data, cap))
+    fr = M.Context.make_frames(descs)
+    if entry == "sync":
+        written, status = gpu_ctx.decode_batch(fr, mem=M.MEM_HOST)
+    else:
+        other = np.zeros((600, 800), np.uint16)
+        t = gpu_ctx.decode_batch_async(fr)
+        t2 = gpu_ctx.decode_batch_async(M.Context.make_frames([(buf6.ctypes.data, buf6.size, 800, 600, 6, other.ctypes.data, 800 * 600)]))
+        assert gpu_ctx.wait(t2) == ([800 * 600], [0]) and np.array_equal(other, small)  # (a short ticket queued behind it, waited for first)
+        written, status = gpu_ctx.wait(t)
+    for i, (typ, ww, hh, buf, img, cap) in enumerate(items):
+        if img is None:
+            assert status[i] != 0 and written[i] == 0, (i, status[i])
+            if cap < ww * hh:
+                assert (outs[i] == 0xA5A5).all(), i  # rejected on the host: never written
+        else:
+            assert status[i] == 0 and written[i] == ww * hh, (i, status[i])
+            assert np.array_equal(outs[i], img), i
