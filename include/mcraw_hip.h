@@ -95,7 +95,12 @@ int mcraw_decode_batch(mcraw_ctx *ctx, const mcraw_frame *frames, int nframes, i
  * sequence of synchronous mcraw_decode_batch calls cannot do.  `frames` is copied; the in / out buffers
  * must stay valid until mcraw_ticket_wait has returned for the ticket.  mcraw_ticket_wait blocks for that
  * batch only, fills `written` / `status` (either may be NULL) and releases the ticket.  Wait for every
- * ticket before mcraw_ctx_destroy.  Returns 0 or a negative value. */
+ * ticket before mcraw_ctx_destroy.  Returns 0 or a negative value.
+ * Scheduling: the copy lanes run best with two batches of a few hundred MB under way (about 3 000 UHD frames/s
+ * host to host).  The library keeps to that by itself -- a third ticket's submission waits for the oldest one's
+ * downloads (not for its mcraw_ticket_wait), and a batch of more than 384 MB is dealt out in such pieces inside the
+ * call, which then returns when the last piece is queued -- so neither the size of a batch nor the number of tickets
+ * a caller keeps in flight (two is enough) has to be tuned. */
 typedef struct mcraw_ticket mcraw_ticket;
 int mcraw_decode_batch_async(mcraw_ctx *ctx, const mcraw_frame *frames, int nframes, mcraw_ticket **ticket);
 int mcraw_ticket_wait(mcraw_ticket *ticket, size_t *written, int32_t *status);
