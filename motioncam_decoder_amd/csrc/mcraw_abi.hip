@@ -128,7 +128,14 @@ struct mcraw_ticket {
     std::vector<Part> parts;
     std::vector<int> skipped; // frames that no sub-batch holds (no device memory for their workspace): failed on their own
     Post post{0, 0, 0}; // post stage the batch was submitted with
-    bool small = false; // a few sub-batches only: takes the short way home (host_submit)
+    bool small = false; // a few sub-batches only: scheduled the short way (host_submit)
+    bool send = false;  // ... and its status words go home behind their kernels (send_status)
+    int want_send = -1; // (deal_host: what this piece is to do; -1: what the context has decided)
+    int trial_way = -1; // a ticket of the context's trial rows (mcraw_decode_batch_async): which row
+    size_t trial_bytes = 0;
+    bool big_trial = false; // a large batch whose way is being compared (big_way)
+    int way = 0;
+    std::chrono::steady_clock::time_point t_queued;
     // A large batch queued with mcraw_decode_batch_async is dealt out as a row of short ones (deal_host): this ticket then holds
     // the ones still under way (oldest first, with the index of their first frame) and the results of those that have landed.
     bool composite = false;
@@ -145,6 +152,19 @@ std::atomic<int> g_ctx_on_device[64];
 struct mcraw_ctx {
     uint64_t part_seq = 0;
     bool counted = false; // in g_ctx_on_device
+    // Host-memory pipeline: do the status words go home behind their kernels (1) or are they fetched when the batch is waited for
+    // (0)?  Decided by measurement on the first large batch (deal_host), or by MCRAW_SHORT_WAY=0|1; until then: fetched.
+    int send_home = -1;         // ... a large batch in one synchronous call
+    int send_home_tickets = -1; // ... a stream of tickets
+    double trial_rate[2] = {0.0, 0.0}; // bytes per second of the two trial batches (fetched, sent)
+    // ... and for a caller that streams short tickets instead (the facade's chunks): TRIAL_TICKETS in a row fetch, the next
+    // TRIAL_TICKETS send, the rate between the first and the last landing of each row is compared
+    struct TicketTrial {
+        int way = 0, queued = 0, landed = 0;
+        size_t bytes = 0;
+        std::chrono::steady_clock::time_point t_first;
+        double rate[2] = {0.0, 0.0};
+    } tt;
 #ifdef MCRAW_TIMELINE
     hipEvent_t tl0 = nullptr; // the timeline's zero: recorded on the upload stream in front of the first sub-batch
     std::chrono::steady_clock::time_point tl_host0;
@@ -1255,7 +1275,7 @@ int host_submit_part(mcraw_ticket *t, int first, int count)
     size_t status_off = 0;
     if (int rc = submit(c, s, frames + first, count, &geom, din.data(), dout.data(), st, &status_off))
         return rc;
-    if (t->small)
+    if (t->send)
         if (int rc = send_status(s, status_off, st))
             return rc;
     HIP_TRY(hipEventRecord(s.decoded, st));
@@ -1293,10 +1313,11 @@ int host_submit_part(mcraw_ticket *t, int first, int count)
     // flight than slots)
     s.owner = t;
     s.owner_part = static_cast<int>(t->parts.size());
-    t->parts.push_back({static_cast<int>(sp - c->slots), first, count, status_off, false, t->small});
+    t->parts.push_back({static_cast<int>(sp - c->slots), first, count, status_off, false, t->send});
     return 0;
 }
 
+// Is this context the only one of the process on its device?  (Else: the long way for every batch.)
 inline bool alone_on_device(const mcraw_ctx *c) { return !c->counted || g_ctx_on_device[c->device].load() <= 1; }
 
 // Queue a host-memory batch (ticket->frames): returns when the last sub-batch is submitted.
@@ -1354,6 +1375,7 @@ int host_submit(mcraw_ticket *t)
         for (int f = 0; f < n && parts <= SHORT_PARTS; parts++)
             f += cut(f);
         t->small = parts <= SHORT_PARTS && alone_on_device(c);
+        t->send = t->small && t->want_send == 1;
     }
     while (t->small) {
         int others = 0;
@@ -1457,12 +1479,60 @@ int land_piece(std::vector<std::unique_ptr<mcraw_ticket>> &pieces, std::vector<i
     return r;
 }
 
+// Status words home behind their kernels (1), or fetched at the wait (0)?  In a process whose first GPU work was this context
+// sending is 10 % faster for a large batch (2 960 against 2 680 UHD frames/s); behind one torch operation -- HIP hands a process four
+// hardware queues per stream priority, and which of the context's streams share one depends on what existed before -- the small
+// kernel that writes home makes sub-batch k + 1's upload wait for sub-batch k's download there (1 600 against 2 570).  Neither a
+// probe on dummy buffers nor the first pieces of a batch show that (it sets in later), so whole batches are compared: the first
+// one of ten pieces or more fetches, the second sends, the faster way is the context's for large batches from then on (until
+// then: fetched).  Streams of short tickets decide for themselves (mcraw_decode_batch_async: sending won wherever it was
+// measured).  MCRAW_SHORT_WAY=0|1 decides both beforehand.
+constexpr size_t PIECE_BYTES = 4 * (96ull << 20);
+
+size_t host_bytes(const mcraw_frame *frames, int n)
+{
+    size_t total = 0;
+    for (int i = 0; i < n; i++)
+        total += static_cast<size_t>(frames[i].len) + (frames[i].width > 0 && frames[i].height > 0 ? static_cast<size_t>(frames[i].width) * frames[i].height * 2 : 0);
+    return total;
+}
+
+void way_from_env(mcraw_ctx *c)
+{
+    static const char *e = std::getenv("MCRAW_SHORT_WAY");
+    if (e && (e[0] == '0' || e[0] == '1') && c->send_home < 0)
+        c->send_home = c->send_home_tickets = e[0] - '0';
+}
+
+// The way of a batch of more than one piece; *trial: it is one of the two that are compared (big_way_result when it is over).
+int big_way(mcraw_ctx *c, size_t total, bool *trial)
+{
+    way_from_env(c);
+    *trial = c->send_home < 0 && alone_on_device(c) && total / PIECE_BYTES >= 10;
+    if (c->send_home >= 0)
+        return c->send_home;
+    return *trial && c->trial_rate[0] != 0.0 ? 1 : 0;
+}
+
+void big_way_result(mcraw_ctx *c, int way, size_t total, double seconds)
+{
+    if (c->send_home >= 0 || seconds <= 0)
+        return;
+    c->trial_rate[way] = total / seconds;
+    if (way == 1) {
+        c->send_home = c->trial_rate[1] > c->trial_rate[0] * 1.03 ? 1 : 0;
+        if (std::getenv("MCRAW_TRACE"))
+            std::fprintf(stderr, "[mcraw] host-memory pipeline: status words fetched %.1f GB/s, sent home %.1f GB/s: %s from here on\n",
+                         c->trial_rate[0] / 1e9, c->trial_rate[1] / 1e9, c->send_home ? "sent" : "fetched");
+    }
+}
+
 int deal_host(mcraw_ctx *c, const mcraw_frame *frames, int n, size_t *written, int32_t *status_out,
-              std::vector<std::unique_ptr<mcraw_ticket>> &pieces, std::vector<int> &piece_first, bool finish)
+              std::vector<std::unique_ptr<mcraw_ticket>> &pieces, std::vector<int> &piece_first, bool finish, int way)
 {
     // (a piece is cut by bytes here and into sub-batches of up to 96 MB by host_submit, which ends one in front of the frame that
     // would not fit: four sub-batches' worth of bytes are five or six sub-batches, short by host_submit's count)
-    const size_t PIECE_BYTES = alone_on_device(c) ? 4 * (96ull << 20) : SIZE_MAX;
+    const size_t piece = alone_on_device(c) ? PIECE_BYTES : SIZE_MAX;
     int rc = 0, first = 0;
     while (first < n && rc == 0) {
         size_t bytes = 0;
@@ -1470,7 +1540,7 @@ int deal_host(mcraw_ctx *c, const mcraw_frame *frames, int n, size_t *written, i
         while (first + count < n) {
             const mcraw_frame &f = frames[first + count];
             const size_t fb = static_cast<size_t>(f.len) + (f.width > 0 && f.height > 0 ? static_cast<size_t>(f.width) * f.height * 2 : 0);
-            if (count > 0 && bytes + fb > PIECE_BYTES)
+            if (count > 0 && bytes + fb > piece)
                 break;
             bytes += fb;
             count++;
@@ -1478,6 +1548,7 @@ int deal_host(mcraw_ctx *c, const mcraw_frame *frames, int n, size_t *written, i
         std::unique_ptr<mcraw_ticket> p(new mcraw_ticket());
         p->c = c;
         p->frames.assign(frames + first, frames + first + count);
+        p->want_send = way;
         rc = host_submit(p.get());
         if (rc != 0) { // (host_submit has waited for whatever it had queued of this piece)
             forget_ticket(p.get());
@@ -1486,8 +1557,9 @@ int deal_host(mcraw_ctx *c, const mcraw_frame *frames, int n, size_t *written, i
         pieces.push_back(std::move(p));
         piece_first.push_back(first);
         first += count;
-        if (pieces.size() >= 2 && (finish || first < n))
+        if (pieces.size() >= 2 && (finish || first < n)) {
             rc = land_piece(pieces, piece_first, written, status_out);
+        }
     }
     while (!pieces.empty() && (finish || rc != 0)) { // (behind a failure too: nothing of the batch may still be moving then)
         const int r = land_piece(pieces, piece_first, written, status_out);
@@ -1502,7 +1574,15 @@ int decode_host(mcraw_ctx *c, const mcraw_frame *frames, int n, size_t *written,
 {
     std::vector<std::unique_ptr<mcraw_ticket>> pieces;
     std::vector<int> piece_first;
-    return deal_host(c, frames, n, written, status_out, pieces, piece_first, true);
+    const size_t total = host_bytes(frames, n);
+    bool trial = false;
+    way_from_env(c);
+    const int way = total > PIECE_BYTES ? big_way(c, total, &trial) : std::max(0, c->send_home_tickets);
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = deal_host(c, frames, n, written, status_out, pieces, piece_first, true, way);
+    if (trial && rc == 0)
+        big_way_result(c, way, total, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    return rc;
 }
 
 mcraw_ctx *g_default = nullptr;
@@ -1773,7 +1853,25 @@ int mcraw_decode_batch_async(mcraw_ctx *c, const mcraw_frame *frames, int nframe
     t->composite = true;
     t->got_written.assign(static_cast<size_t>(nframes), 0);
     t->got_status.assign(static_cast<size_t>(nframes), 0);
-    if (int rc = deal_host(c, frames, nframes, t->got_written.data(), t->got_status.data(), t->pieces, t->piece_first, false)) {
+    constexpr int TRIAL_TICKETS = 12;
+    way_from_env(c);
+    const size_t total = host_bytes(frames, nframes);
+    int way;
+    if (total > PIECE_BYTES) { // a large batch as a ticket: compared like the synchronous ones, its time runs until it is waited for
+        way = big_way(c, total, &t->big_trial);
+        t->trial_bytes = total;
+        t->t_queued = std::chrono::steady_clock::now();
+    } else if (c->send_home_tickets >= 0) {
+        way = c->send_home_tickets;
+    } else if (nframes > 0 && alone_on_device(c) && c->tt.queued < TRIAL_TICKETS) {
+        way = t->trial_way = c->tt.way; // (undecided: this ticket belongs to the row under way)
+        t->trial_bytes = total;
+        c->tt.queued++;
+    } else {
+        way = 0;
+    }
+    t->way = way;
+    if (int rc = deal_host(c, frames, nframes, t->got_written.data(), t->got_status.data(), t->pieces, t->piece_first, false, way)) {
         delete t;
         return rc;
     }
@@ -1794,6 +1892,28 @@ int mcraw_ticket_wait(mcraw_ticket *t, size_t *written, int32_t *status)
             const int r = land_piece(t->pieces, t->piece_first, t->got_written.data(), t->got_status.data());
             if (rc == 0)
                 rc = r;
+        }
+        if (t->big_trial && rc == 0)
+            big_way_result(c, t->way, t->trial_bytes, std::chrono::duration<double>(std::chrono::steady_clock::now() - t->t_queued).count());
+        if (t->trial_way >= 0 && c->send_home_tickets < 0 && t->trial_way == c->tt.way) { // a ticket of the trial row under way has landed
+            constexpr int TRIAL_TICKETS = 12;
+            mcraw_ctx::TicketTrial &tt = c->tt;
+            const auto now = std::chrono::steady_clock::now();
+            if (tt.landed++ == 0)
+                tt.t_first = now; // (the row's clock starts with its first landing; that ticket's bytes are not counted)
+            else
+                tt.bytes += t->trial_bytes;
+            if (tt.landed == TRIAL_TICKETS) {
+                tt.rate[tt.way] = tt.bytes / std::max(1e-9, std::chrono::duration<double>(now - tt.t_first).count());
+                if (tt.way == 0) {
+                    tt = mcraw_ctx::TicketTrial{1, 0, 0, 0, now, {tt.rate[0], 0.0}};
+                } else {
+                    c->send_home_tickets = tt.rate[1] > tt.rate[0] * 1.03 ? 1 : 0;
+                    if (std::getenv("MCRAW_TRACE"))
+                        std::fprintf(stderr, "[mcraw] host-memory pipeline (tickets): status words fetched %.1f GB/s, sent home %.1f GB/s: %s from here on\n",
+                                     tt.rate[0] / 1e9, tt.rate[1] / 1e9, c->send_home_tickets ? "sent" : "fetched");
+                }
+            }
         }
         const size_t n = t->got_status.size();
         for (size_t i = 0; i < n; i++) {

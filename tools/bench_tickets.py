@@ -15,6 +15,9 @@ import _libs as L
 import motioncam_decoder_amd as M
 
 w, h, total = 3840, 2160, int(os.environ.get("TOTAL", "240"))
+if os.environ.get("TORCH_FIRST"):  # a torch operation on the GPU BEFORE the context exists (the hardware-queue lottery: tools/pcie_order.py)
+    import torch
+    torch.ones(4, device="cuda:0").sum().item()
 lib = M.load()
 # POOL=1: through the pool of one member (what the facade calls); SEPOUT=1: every output buffer an allocation of its own
 ctx = M.Pool([0]) if os.environ.get("POOL") else M.Context(0)
