@@ -100,7 +100,10 @@ int mcraw_decode_batch(mcraw_ctx *ctx, const mcraw_frame *frames, int nframes, i
  * host to host).  The library keeps to that by itself -- a third ticket's submission waits for the oldest one's
  * downloads (not for its mcraw_ticket_wait), and a batch of more than 384 MB is dealt out in such pieces inside the
  * call, which then returns when the last piece is queued -- so neither the size of a batch nor the number of tickets
- * a caller keeps in flight (two is enough) has to be tuned. */
+ * a caller keeps in flight (two is enough) has to be tuned.  How the per-frame statuses travel (written home behind the
+ * kernels, or fetched at the wait) is measured by every context on its first batches, because the better way depends on
+ * what the process did with the GPU before the context existed; MCRAW_SHORT_WAY=0|1 in the environment decides it
+ * beforehand (1: written home), MCRAW_TRACE=1 prints what was measured. */
 typedef struct mcraw_ticket mcraw_ticket;
 int mcraw_decode_batch_async(mcraw_ctx *ctx, const mcraw_frame *frames, int nframes, mcraw_ticket **ticket);
 int mcraw_ticket_wait(mcraw_ticket *ticket, size_t *written, int32_t *status);
