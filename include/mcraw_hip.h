@@ -250,6 +250,8 @@ int mcraw_ctx_set_post(mcraw_ctx *ctx, const mcraw_post *post);
  *   MCRAW_XCD_CHUNK=n                          pins the tile kernel's workgroup-to-XCD mapping (mcraw_ctx_xcd_runs)
  *   MCRAW_SIDE_SPLIT=b[,r]                     pins the workgroups per bits / refs side stream (mcraw_ctx_side_parts)
  *   MCRAW_SIDE_LASTC=0|1                       the last part of a split side stream counts its pieces too (default: by batch size)
+ *   MCRAW_SHORT_WAY=0|1                        host-memory pipeline: status words fetched at the wait / written home behind the
+ *                                              kernels (default: every context measures which is faster in its process)
  * Experiments that are measured in docs/lab_notes.md and OFF by default (tests keep them correct):
  *   MCRAW_SIDE_CUS=-1|r                        k7_side of a batch on a side stream beside the previous batch's tile kernel:
  *                                              -1 = a stream of the lowest priority, r = r CUs of every XCD (CU-masked streams);

@@ -2,6 +2,7 @@
 signature and return convention as motioncam::raw::Decode / DecodeLegacy,
 RawData.hpp:25-37) and the host-memory batch with overlapped copies."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -226,3 +227,18 @@ def test_large_host_batch_is_dealt_out_in_pieces(gpu_ctx, entry):
         else:
             assert status[i] == 0 and written[i] == ww * hh, (i, status[i])
             assert np.array_equal(outs[i], img), i
+
+
+@pytest.mark.parametrize("way", ["0", "1"])
+def test_host_pipeline_both_ways_home(way):
+    """The host-memory pipeline brings its status words home in one of two ways (written behind the kernels, or fetched at the
+    wait) and picks one per context by measurement; MCRAW_SHORT_WAY pins it.  This file's host-memory tests (sub-batches, tickets
+    out of order with failing frames, large batches in pieces) pass with either pinned."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MCRAW_SHORT_WAY=way)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", os.path.abspath(__file__), "-k",
+                        "many_sub_batches or async_tickets or survives_context or dealt_out or concurrent_host"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    tail = "\n".join(r.stdout.splitlines()[-10:])
+    assert r.returncode == 0 and " passed" in tail and "failed" not in tail, tail + r.stderr[-1500:]
