@@ -52,6 +52,19 @@ def build_hip(force=False):
     return out
 
 
+def build_timeline(force=False):
+    """The diagnostic build of the host-memory pipeline (tools/timeline_host.sh): events with timing, one line per sub-batch when
+    it is drained.  Not the product: lib/timeline/libmcraw_hip.so, picked up through LD_LIBRARY_PATH or MCRAW_LIB_PATH."""
+    d = os.path.join(LIB, "timeline")
+    os.makedirs(d, exist_ok=True)
+    out = os.path.join(d, "libmcraw_hip.so")
+    srcs = [os.path.join(CSRC, f) for f in ("mcraw_abi.hip", "mcraw_pool.hip", "mcraw_type7.hip", "mcraw_type6.hip")]
+    if force or _newer(out, srcs + [os.path.join(CSRC, f) for f in ("mcraw_plan.h", "mcraw_dev.h")]):
+        _run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+              "-DMCRAW_TIMELINE", "-o", out] + srcs + ["-lpthread"])
+    return out
+
+
 def build_synth(force=False):
     out = os.path.join(SYNTH, "libmcraw_synth.so")
     src = os.path.join(SYNTH, "mcraw_synth.c")

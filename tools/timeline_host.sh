@@ -1,8 +1,8 @@
 #!/bin/bash
 # The host-memory pipeline on the GPU's own clock, without a profiler: a library built with -DMCRAW_TIMELINE (events with
 # timing; one line per sub-batch when it is drained: queued / upload from-to / decoded / downloaded, ms since the first) under
-# mcraw_export.  Build here first:
-#   hipcc ... -DMCRAW_TIMELINE -o motioncam_decoder_amd/lib/timeline/libmcraw_hip.so csrc/*.hip   (see DESIGN / lab notes)
+# mcraw_export.  Build here first (the built library travels to the GPU box with the snapshot):
+#   python3 -c "from motioncam_decoder_amd import build; build.build_timeline()"
 #   gpurun -- 'ARGS="--pinned" bash tools/timeline_host.sh'
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R && python3 - <<'PY'
