@@ -504,7 +504,10 @@ def pool_leg(torch, M, L, wl, devices, link=None, nframes=240, reps=2):
         in_b = sum(wl.pairs[i % d][1].size for i in range(n))
         res = {"devices": pool.devices(), "numa_cpus": pool.numa_cpus(),
                "host_buffers": {"frames": n, "frames_per_s": round(n / t, 1), "mpix_s": round(n * wl.w * wl.h / t / 1e6, 1),
-                                "h2d_GBs": round(in_b / t / 1e9, 2), "d2h_GBs": round(n * out_bytes / t / 1e9, 2), "bit_exact": bool(ok)}}
+                                "h2d_GBs": round(in_b / t / 1e9, 2), "d2h_GBs": round(n * out_bytes / t / 1e9, 2), "bit_exact": bool(ok),
+                                "note": "the pool's contexts share their GPU with this process's own context (and with each other where a device "
+                                        "is named twice): the host-memory pipeline then takes its long way (status words fetched at the wait, no "
+                                        "pieces), as before round 5's change; pcie_inclusive is the leg of a context that has its device to itself"}}
         if link:
             per = max(in_b, n * out_bytes) / G / (link["each_way_when_both_GBs"] * 1e9)  # every member has a link of its own
             res["host_buffers"]["link_frac"] = round(per / t, 3)
