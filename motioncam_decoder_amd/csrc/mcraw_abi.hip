@@ -1367,8 +1367,10 @@ int host_submit(mcraw_ticket *t)
     // way works while little is queued: with four tickets in flight, or more sub-batches than the ring has slots, the
     // downloads fall to a quarter of their rate (13 GB/s; the runtime's choice of copy engine is the suspect), where the long
     // way -- statuses fetched when the batch is waited for, which queues that fetch behind everything submitted since and so
-    // lets the ring run empty now and then -- keeps 2 700-2 900.  So: the short way for batches of up to SHORT_PARTS
-    // sub-batches, and such a batch is queued only when at most ONE other batch still has downloads under way.
+    // lets the ring run empty now and then -- keeps 2 700-2 900.  So: batches of up to SHORT_PARTS sub-batches are scheduled the
+    // short way (queued only when at most ONE other batch still has downloads under way; larger batches are dealt out as such
+    // by deal_host), and whether their status words are sent home is the caller's word (`want_send`: big_way / the ticket rows
+    // of mcraw_decode_batch_async measure what is faster in this process).
     constexpr int SHORT_PARTS = 6;
     {
         int parts = 0;
