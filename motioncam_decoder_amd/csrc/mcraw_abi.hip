@@ -157,6 +157,8 @@ struct mcraw_ctx {
     int send_home = -1;         // ... a large batch in one synchronous call
     int send_home_tickets = -1; // ... a stream of tickets
     double trial_rate[2] = {0.0, 0.0}; // bytes per second of the two trial batches (fetched, sent)
+    int big_seen = 0;                  // large batches so far (the first one is not compared)
+    int sent_trials = 0;               // ... that sent (the first of them is not compared either)
     // ... and for a caller that streams short tickets instead (the facade's chunks): TRIAL_TICKETS in a row fetch, the next
     // TRIAL_TICKETS send, the rate between the first and the last landing of each row is compared
     struct TicketTrial {
@@ -1485,9 +1487,10 @@ int land_piece(std::vector<std::unique_ptr<mcraw_ticket>> &pieces, std::vector<i
 // sending is 10 % faster for a large batch (2 960 against 2 680 UHD frames/s); behind one torch operation -- HIP hands a process four
 // hardware queues per stream priority, and which of the context's streams share one depends on what existed before -- the small
 // kernel that writes home makes sub-batch k + 1's upload wait for sub-batch k's download there (1 600 against 2 570).  Neither a
-// probe on dummy buffers nor the first pieces of a batch show that (it sets in later), so whole batches are compared: the first
-// one of ten pieces or more fetches, the second sends, the faster way is the context's for large batches from then on (until
-// then: fetched).  Streams of short tickets decide for themselves (mcraw_decode_batch_async: sending won wherever it was
+// probe on dummy buffers nor the first pieces of a batch show that (it sets in later), so whole batches are compared: of the
+// batches of ten pieces or more the first one fetches and only warms the slots up, the second fetches, the third and the fourth
+// send (the fourth is the one compared), and the faster way is the context's for large batches from then on (until then:
+// fetched).  Streams of short tickets decide for themselves (mcraw_decode_batch_async: sending won wherever it was
 // measured).  MCRAW_SHORT_WAY=0|1 decides both beforehand.
 constexpr size_t PIECE_BYTES = 4 * (96ull << 20);
 
@@ -1513,6 +1516,20 @@ int big_way(mcraw_ctx *c, size_t total, bool *trial)
     *trial = c->send_home < 0 && alone_on_device(c) && total / PIECE_BYTES >= 10;
     if (c->send_home >= 0)
         return c->send_home;
+    if (*trial && c->big_seen++ == 0) {
+        *trial = false; // (the context's first large batch pays for the slots' buffers: fetched, and not compared)
+        // ... and what the other way needs is made now, so that its trial batch does not pay for it: the slots' pinned status
+        // buffers, the first launch of the kernel that writes into them
+        for (Slot &x : c->slots)
+            if (ensure(x.status_host, 4096, true) != 0)
+                break;
+        if (c->slots[0].status_host.p) {
+            hipLaunchKernelGGL(k_words_home, dim3(1), dim3(64), 0, c->slots[0].stream, static_cast<uint32_t *>(c->slots[0].status_host.p),
+                               static_cast<const uint32_t *>(c->slots[0].status_host.p), 0u);
+            (void)hipStreamSynchronize(c->slots[0].stream);
+        }
+        (void)hipGetLastError();
+    }
     return *trial && c->trial_rate[0] != 0.0 ? 1 : 0;
 }
 
@@ -1520,6 +1537,8 @@ void big_way_result(mcraw_ctx *c, int way, size_t total, double seconds)
 {
     if (c->send_home >= 0 || seconds <= 0)
         return;
+    if (way == 1 && c->sent_trials++ == 0)
+        return; // (the first batch that sends is its way's warm-up, as the context's first batch was the other's)
     c->trial_rate[way] = total / seconds;
     if (way == 1) {
         c->send_home = c->trial_rate[1] > c->trial_rate[0] * 1.03 ? 1 : 0;
