@@ -61,6 +61,22 @@ def cases():
     nrec = (256 // 32) * 2 * 16
     out.append(("t6_forced_mix_256x16", 6, L.natural_image_np(256, 16, 12, 12.0, 45),
                 rng.integers(0, 16, nrec).astype(np.uint8), 1))
+
+    # ---- streams long enough for the GPU path's hand-offs (round 6; the npz is compressed, so these are built from few
+    # distinct values): legacy streams of more than three 16 KiB segments (look-back between workgroups), one of them with
+    # a padded width and a trailer; a type-7 frame whose bits AND refs streams are longer than one 32 KiB piece
+    rng2 = np.random.default_rng(20261003)
+    out.append(("t6_segments_640x128", 6, L.natural_image_np(640, 128, 12, 12.0, 46), None, 0))
+    w, h = 600, 100
+    nrec = ((w + 31) // 32) * 2 * h
+    out.append(("t6_segments_forced_600x100", 6, L.natural_image_np(w, h, 10, 4.0, 47),
+                rng2.integers(0, 16, nrec).astype(np.uint8), 1))
+    w, h = 2048, 1600  # 51 200 blocks = 800 records per side stream
+    tiles = rng2.integers(0, 1 << 16, size=(h // 4, w // 64, 4), dtype=np.uint16)  # one value per block: refs of 16 bits
+    yy, xx = np.arange(h)[:, None], np.arange(w)[None, :]
+    img = tiles[yy // 4, xx // 64, (yy & 1) * 2 + (xx & 1)]
+    out.append(("t7_long_side_streams_2048x1600", 7, np.ascontiguousarray(img),
+                rng2.integers(0, 17, (w // 64) * (h // 4) * 4).astype(np.uint8), 0))
     return out
 
 

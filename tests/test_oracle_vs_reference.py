@@ -40,12 +40,32 @@ def test_type6_random(w, h):
         assert np.array_equal(oo, img)
 
 
-def test_full_size_configs():
-    # BASELINE configs 1 and 2 at full size, both distributions
-    for (w, h, nb, dist, sig) in [(1920, 1080, 10, 0, 0), (1920, 1080, 10, 1, 4), (4032, 3024, 12, 1, 12)]:
-        img = L.synth_image(w, h, nb, dist, sig, 1000 + dist)
-        buf = L.encode7(img)
-        ro, oo = L.oracle_decode7(buf, w, h)
-        rr, orr = L.ref_decode7(buf, w, h)
-        assert ro == rr == w * h
-        assert np.array_equal(oo, orr[:h]) and np.array_equal(oo, img)
+@pytest.mark.parametrize("w,h,nb,dist,sig", [
+    (1920, 1080, 10, 0, 0), (1920, 1080, 10, 1, 4),          # BASELINE config 1, both distributions
+    (4032, 3024, 12, 1, 12), (4032, 3024, 12, 0, 0),         # config 2: Nat and U
+    (3840, 2160, 12, 1, 12), (3840, 2160, 12, 0, 0),         # config 3's frame (the bench line's): Nat and U
+    (4032, 3024, 14, 0, 0),                                  # config 4's 14-bit frames
+    (7680, 4320, 12, 1, 12),                                 # config 5's frame
+])
+def test_full_size_type7(w, h, nb, dist, sig):
+    img = L.synth_image(w, h, nb, dist, sig, 1000 + dist)
+    buf = L.encode7(img)
+    ro, oo = L.oracle_decode7(buf, w, h)
+    rr, orr = L.ref_decode7(buf, w, h)
+    assert ro == rr == w * h
+    assert np.array_equal(oo, orr[:h]) and np.array_equal(oo, img)
+
+
+@pytest.mark.parametrize("w,h,nb,dist,sig,flags", [
+    (4000, 3000, 12, 1, 12, 0),                              # the bench's legacy leg; width % 32 == 0
+    (4000, 3000, 14, 0, 0, 1),                               # config 4's 14-bit legacy frames, with a trailer
+    (1920, 1080, 10, 1, 4, 0), (1920, 1080, 10, 0, 0, 1),    # config 1's frame as legacy
+    (4032 - 5, 3024 // 4, 12, 1, 12, 1),                     # a padded width at full row length
+])
+def test_full_size_legacy(w, h, nb, dist, sig, flags):
+    img = L.synth_image(w, h, nb, dist, sig, 2000 + dist)
+    buf = L.encode6(img, None, flags)
+    ro, oo = L.oracle_decode6(buf, w, h)
+    rr, orr = L.ref_decode6(buf, w, h)
+    assert ro == rr == w * h
+    assert np.array_equal(oo, orr) and np.array_equal(oo, img)
