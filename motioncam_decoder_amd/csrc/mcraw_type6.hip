@@ -419,6 +419,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         // the second half's 17 walks map the first half's exits to arrivals); and, while the arrivals are not yet one chain,
         // on to the next quarter's start
         if (wave == RESOLVER - 1u) {
+            __builtin_amdgcn_s_setprio(3);
             uint32_t fr = 0u; // boundary (quarters into the segment) << 8 | phase of THE chain there; segment 0 starts with a record at byte 0 (RawData_Legacy.cpp:476)
             if (seg) {
                 const bool w17 = lane < PHASES6, w34 = lane < 2u * PHASES6;
@@ -455,6 +456,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
             }
             if (lane == 0u)
                 s_front = fr;
+            __builtin_amdgcn_s_setprio(0);
         }
 
         if (wave != RESOLVER) {
@@ -462,6 +464,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
             K6_STAMP(2, 0);
         } else {
             // ---- speculative walkers
+            __builtin_amdgcn_s_setprio(3);
             const bool inq = uj < cnt; // (quarters behind the stream's last chunk: nothing to walk)
             {
                 const uint32_t s0 = seg ? 0u : FRONT6; // (segment 0: the stream starts with a record at byte 0, RawData_Legacy.cpp:476)
@@ -894,6 +897,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
             }
         }
         K6_STAMP(13, RESOLVER * 64u);
+        __builtin_amdgcn_s_setprio(0);
     }
     __syncthreads();
     K6_STAMP(3, 0);
