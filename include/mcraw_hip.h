@@ -245,19 +245,14 @@ typedef struct mcraw_post {
 int mcraw_ctx_set_post(mcraw_ctx *ctx, const mcraw_post *post);
 
 /* ---- environment ------------------------------------------------------------------------------
- * Read when a context (or pool) is created, or once per process:
+ * Read when a context (or pool) is created, never afterwards:
  *   MCRAW_DEVICE=n, MCRAW_DEVICES=all|0,1,5   default device of the five-argument entry points / members of a default pool
  *   MCRAW_XCD_CHUNK=n                          pins the tile kernel's workgroup-to-XCD mapping (mcraw_ctx_xcd_runs)
  *   MCRAW_SIDE_SPLIT=b[,r]                     pins the workgroups per bits / refs side stream (mcraw_ctx_side_parts)
  *   MCRAW_SIDE_LASTC=0|1                       the last part of a split side stream counts its pieces too (default: by batch size)
  *   MCRAW_SHORT_WAY=0|1                        host-memory pipeline: status words fetched at the wait / written home behind the
  *                                              kernels (default: every context measures which is faster in its process)
- * Experiments that are measured in docs/lab_notes.md and OFF by default (tests keep them correct):
- *   MCRAW_SIDE_CUS=-1|r                        k7_side of a batch on a side stream beside the previous batch's tile kernel:
- *                                              -1 = a stream of the lowest priority, r = r CUs of every XCD (CU-masked streams);
- *                                              with MCRAW_SIDE_FAT (fat workgroups there), MCRAW_SIDE_PRIO=s,t (stream priorities)
- *   MCRAW_SIDE_THIN=1                          every k7_side launch as thin workgroups (256 threads, 23 KB of LDS)
- *   MCRAW_NO_FORK=1, MCRAW_PLAN_UPLOAD=1       one stream for batches of both encodings; type-7 plans through HBM
+ *   MCRAW_TRACE=1                              the verdicts of the contexts' own measurements on stderr
  * Of the HIP runtime (docs/lab_notes.md): GPU_MAX_HW_QUEUES (hardware queues per process and priority). */
 
 /* Pinned host memory for MCRAW_MEM_HOST batches (hipHostMalloc / hipHostFree). */

@@ -2,6 +2,7 @@
 
     python -m motioncam_decoder_amd.build            # everything
     python -m motioncam_decoder_amd.build hip synth  # selected targets
+    python -m motioncam_decoder_amd.build variant /tmp/libx.so -DMCRAW_DIAG   # another build of the HIP sources (tests, tools)
 
 Targets
   hip    motioncam_decoder_amd/lib/libmcraw_hip.so      gfx950 kernels + C ABI (hipcc)
@@ -39,29 +40,78 @@ def _run(cmd):
     subprocess.run(cmd, check=True)
 
 
+# The gfx950 library: kernels (mcraw_type7 / mcraw_type6), the host side of the C ABI in its units (csrc/mcraw_host.h) and the device pool.
+HIP_SOURCES = ("mcraw_abi.hip", "mcraw_submit.hip", "mcraw_tune.hip", "mcraw_device.hip", "mcraw_hostmem.hip", "mcraw_pool.hip",
+               "mcraw_type7.hip", "mcraw_type6.hip")
+HIP_HEADERS = ("mcraw_plan.h", "mcraw_dev.h", "mcraw_host.h")
+HIP_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
+
+
+def hip_sources():
+    return [os.path.join(CSRC, f) for f in HIP_SOURCES]
+
+
+def _objects(flags=(), tag="", force=False, only=None):
+    """One object per source under lib/obj/ (rebuilt when the source or a header is newer), compiled side by side."""
+    obj = os.path.join(LIB, "obj")
+    os.makedirs(obj, exist_ok=True)
+    hdrs = [os.path.join(CSRC, f) for f in HIP_HEADERS] + [os.path.join(ROOT, "include", "mcraw_hip.h")]
+    objs, jobs = [], []
+    for src in hip_sources():
+        if only is not None and src not in only:
+            continue
+        o = os.path.join(obj, os.path.basename(src)[:-4] + tag + ".o")
+        objs.append(o)
+        if force or _newer(o, [src] + hdrs):
+            cmd = [HIPCC] + HIP_FLAGS + ["-Wall", "-Wno-unused-function"] + list(flags) + ["-c", "-o", o, src]
+            print("+", " ".join(cmd), flush=True)
+            jobs.append((subprocess.Popen(cmd), cmd))
+    for pr, cmd in jobs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    return objs, bool(jobs)
+
+
+def _link(out, objs):
+    _run([HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fno-gpu-rdc", "-o", out] + objs + ["-lpthread"])
+
+
+def build_variant(out, flags=()):
+    """Another build of the same sources (tests and tools: fault injection, forced paths, diagnostics).  Only the sources that a
+    flag can reach are compiled again -- those that mention a -D name themselves, all of them when a header does or when a flag
+    is no -D --; the others' objects are the product library's."""
+    import hashlib
+    import re
+    os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
+    names = [re.sub(r"^-D([A-Za-z0-9_]+).*$", r"\1", f) for f in flags if f.startswith("-D")]
+    everything = len(names) != len(flags) or any(n in open(os.path.join(CSRC, h)).read() for n in names for h in HIP_HEADERS)
+    touched = [s for s in hip_sources() if everything or any(n in open(s).read() for n in names)]
+    tag = ".v" + hashlib.sha1(" ".join(flags).encode()).hexdigest()[:10]
+    plain, _ = _objects(only=[s for s in hip_sources() if s not in touched])
+    special, _ = _objects(flags, tag, only=touched)
+    _link(out, plain + special)
+    return out
+
+
 def build_hip(force=False):
+    """lib/libmcraw_hip.so: one object per source (lib/obj/), then the link."""
     os.makedirs(LIB, exist_ok=True)
     out = os.path.join(LIB, "libmcraw_hip.so")
-    srcs = [os.path.join(CSRC, f) for f in ("mcraw_abi.hip", "mcraw_pool.hip", "mcraw_type7.hip", "mcraw_type6.hip")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("mcraw_plan.h", "mcraw_dev.h")] + [
-        os.path.join(ROOT, "include", "mcraw_hip.h")]
-    if force or _newer(out, deps):
-        diag = ["-DMCRAW_DIAG"] if os.environ.get("MCRAW_DIAG") else []  # timing-experiment kernels (tools/abl7.sh)
-        _run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc",
-              "-Wall", "-Wno-unused-function"] + diag + ["-o", out] + srcs + ["-lpthread"])
+    if os.environ.get("MCRAW_DIAG"):  # timing-experiment kernels (tools/abl7.sh) in place of the product library
+        objs, built = _objects(["-DMCRAW_DIAG"], ".diag", force)
+    else:
+        objs, built = _objects(force=force)
+    if force or built or _newer(out, objs):
+        _link(out, objs)
     return out
 
 
 def build_timeline(force=False):
     """The diagnostic build of the host-memory pipeline (tools/timeline_host.sh): events with timing, one line per sub-batch when
     it is drained.  Not the product: lib/timeline/libmcraw_hip.so, picked up through LD_LIBRARY_PATH or MCRAW_LIB_PATH."""
-    d = os.path.join(LIB, "timeline")
-    os.makedirs(d, exist_ok=True)
-    out = os.path.join(d, "libmcraw_hip.so")
-    srcs = [os.path.join(CSRC, f) for f in ("mcraw_abi.hip", "mcraw_pool.hip", "mcraw_type7.hip", "mcraw_type6.hip")]
-    if force or _newer(out, srcs + [os.path.join(CSRC, f) for f in ("mcraw_plan.h", "mcraw_dev.h")]):
-        _run([HIPCC, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
-              "-DMCRAW_TIMELINE", "-o", out] + srcs + ["-lpthread"])
+    out = os.path.join(LIB, "timeline", "libmcraw_hip.so")
+    if force or _newer(out, hip_sources() + [os.path.join(CSRC, f) for f in HIP_HEADERS]):
+        build_variant(out, ["-Wall", "-Wno-unused-function", "-DMCRAW_TIMELINE"])
     return out
 
 
@@ -107,5 +157,8 @@ def build_all(force=False, targets=("hip", "synth", "host")):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "variant":  # python -m motioncam_decoder_amd.build variant <out.so> [compiler flags ...]
+        build_variant(sys.argv[2], sys.argv[3:])
+        sys.exit(0)
     args = [a for a in sys.argv[1:] if not a.startswith("-")]
     build_all(force="--force" in sys.argv, targets=tuple(args) or ("hip", "synth", "host"))

@@ -135,10 +135,7 @@ struct Plan6 {
 constexpr int CHUNK6 = 1024; // bytes of legacy stream per transition-map chunk
 constexpr int TICKET_STRIDE6 = 64; // uint32 words between the segment ticket counters of two legacy frames (256 bytes)
 constexpr int ROWS_CH = 4;   // chunks per unpacking wave of k6_decode
-#ifndef MCRAW_K6_WAVES
-#define MCRAW_K6_WAVES 4
-#endif
-constexpr int SEG_WAVES6 = MCRAW_K6_WAVES == 5 ? 4 : MCRAW_K6_WAVES; // unpacking waves per workgroup of k6_decode
+constexpr int SEG_WAVES6 = 4;                                        // waves per workgroup of k6_decode
 constexpr int SEG_CHUNKS6 = SEG_WAVES6 * ROWS_CH;                    // chunks per workgroup = per SEGMENT
 constexpr int PHASES6 = 17;  // entry offsets 0,2,..,32 (record stride <= 34, all even)
 

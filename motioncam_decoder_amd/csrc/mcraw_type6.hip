@@ -115,15 +115,14 @@ static_assert(ROWS_CAP <= 1024u && ROWS_CAP % 2u == 0u, "the division-free row a
 #endif
 
 // ------------------------------------------------------------------ k6_decode
-constexpr uint32_t TAIL6 = 128;           // (five-wave form) tasks (8 pixels each) of every unpacking wave's list that the fifth wave takes over
 constexpr uint32_t UNPACK_W = SEG_WAVES6;         // unpacking waves per workgroup
 constexpr uint32_t DEC_CH = UNPACK_W * ROWS_CH;   // chunks per workgroup
-// Waves per workgroup.  Four: the last wave resolves the chain, then unpacks its chunks like the others (seven workgroups fit a CU:
-// the kernel is a chain of latencies -- load, walk, look-back, lists, unpack --, and what hides them is the number of
-// segments in flight).  Five (rounds 2 and 3): a wave of its own resolves and then takes a share of every list.
-constexpr uint32_t DEC_T = 64 * MCRAW_K6_WAVES;
-constexpr bool FIFTH6 = DEC_T == 320;
-static_assert(DEC_T == 128 || DEC_T == 256 || DEC_T == 320, "two or four unpacking waves; the resolving wave is the last one");
+// Four waves per workgroup: the last wave resolves the chain (the one in front of it the sure entry beside it), then all four unpack
+// their chunks.  Seven workgroups fit a CU: the kernel is a chain of latencies -- load, walk, look-back, lists, unpack --, and what
+// hides them is the number of segments in flight.  (Rounds 2-5 also built two-, five- and eight-wave workgroups and a form that
+// stages the stream by LDS-DMA, all slower: docs/lab_notes.md.)
+constexpr uint32_t DEC_T = 64 * UNPACK_W;
+static_assert(DEC_T == 256, "four waves: the resolving wave is the last one");
 constexpr uint32_t FRONT6 = CHUNK6;       // bytes staged in front of the segment: the chains that cross into them have become one by the segment's start
 #ifndef MCRAW_WARM6
 #define MCRAW_WARM6 512
@@ -132,7 +131,7 @@ constexpr uint32_t WARM6 = MCRAW_WARM6;   // bytes in front of its quarter chunk
 constexpr uint32_t QUART6 = CHUNK6 / 4;   // bytes of stream per walker
 constexpr uint32_t NQ6 = 4 * DEC_CH;      // walkers = quarter chunks per segment
 constexpr uint32_t NOFRONT = 255;         // s_front's boundary: the chains never became one inside this segment
-static_assert(NQ6 == 64 || NQ6 == 32, "one walker per lane of the resolving wave (the lanes behind them take no part)");
+static_assert(NQ6 == 64, "one walker per lane of the resolving wave");
 static_assert(WARM6 <= FRONT6 && WARM6 % 2u == 0u && WARM6 >= 64u, "the walkers of the first quarter start inside the staged front");
 
 // Bytes from a record's header to the next record's (RawData_Legacy.cpp:13-32,377-442); `b` = the header's first byte.
@@ -304,28 +303,6 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     if (tid == 0)
         s_ticket = K6_ABL >= 8 ? 0u : atomicAdd(tickets + f * TICKET_STRIDE6, 1u);
     uint32_t seg = (all_in ? 0u : wg_tab[nframes + 1u + stage]) + wrel / inplay;
-#ifdef MCRAW_K6_LDSDMA
-    // The stream goes from memory INTO the LDS (gfx950: buffer_load_dwordx4 ... lds, 16 bytes per lane, a wave's 64 lanes to 1 KiB
-    // in a row; the same bounds-checked descriptor: bytes past `len` arrive as zeros): no registers hold the stage on its way, no
-    // ds_write pass behind the loads.  MEASURED AND NOT SHIPPED (docs/lab_notes.md, round 5: 0.360 against 0.353 ms -- the barrier
-    // behind the ticket now waits for every wave's loads, the eight-record bit map needs the bytes read back; a workgroup's later
-    // stages get shorter by as much as its first ones get longer); tests/test_gpu_k6_waves.py keeps the build parity-green.
-    auto fetch = [&]() {
-#pragma unroll
-        for (uint32_t r = 0; r < NROUND; r++) {
-            const uint32_t i = tid + r * DEC_T;
-            const uint32_t off = seg * OWN - FRONT6 + i * 16u;
-            uint8_t *dst = s_stage + (r * DEC_T + wave * 64u) * 16u; // wave-uniform; the hardware adds lane * 16
-            if (i < NPIECE) {
-                if (seg || i >= FRONT6 / 16u)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(dst), 16,
-                                                             static_cast<int>(off), 0, 0, 0);
-                else // (segment 0 has nothing in front of it)
-                    *reinterpret_cast<uint4 *>(s_stage + i * 16u) = make_uint4(0u, 0u, 0u, 0u);
-            } // (the lines behind the stage touched by a dword load each, as the plain form's last round fetches them: 0.377 against 0.361 ms)
-        }
-    };
-#else
     uint4 v[NROUND];
     auto fetch = [&]() { // piece i at stream offset (seg * DEC_CH - 1) * CHUNK6 + 16 i; past `len`: reads 0
 #pragma unroll
@@ -343,23 +320,18 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                 v[r] = ld_b128(rs, off);
         }
     };
-#endif
     fetch();
     __syncthreads();
     K6_STAMP(0, 0);
     K6_STAMP(8, RESOLVER * 64u);
     if (K6_ABL < 8 && s_ticket != seg) {
         seg = s_ticket;
-#ifdef MCRAW_K6_LDSDMA
-        __syncthreads(); // (nobody may still be reading s_ticket / the first stage when the second one lands)
-#endif
         fetch();
     }
 
     // ---- what the resolving wave finds out (lane = quarter chunk: chunk uj, quarter ur)
     const uint32_t uj = lane >> 2, ur = lane & 3u;
-    const bool walker6 = lane < NQ6; // (two-wave workgroups: 32 quarters, the resolving wave's upper lanes stand behind every bound)
-    const uint32_t qb = walker6 ? FRONT6 + lane * QUART6 : 0u, qe = walker6 ? qb + QUART6 : 0u;
+    const uint32_t qb = FRONT6 + lane * QUART6, qe = qb + QUART6;
     constexpr uint32_t NOTES6 = 32;
     uint32_t nb[NOTES6 / 4u] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u}; // where my quarter's records start (half positions, a byte each)
     uint32_t a = DEAD, x = DEAD, qn = 0u; // phases at which the chain enters and leaves my quarter; records it starts there
@@ -367,9 +339,6 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     uint32_t spins = 0;
     const uint32_t cfirst = seg * DEC_CH;
     if (cfirst >= nchunks) {
-#ifdef MCRAW_K6_LDSDMA
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (no load may still be on its way into LDS that the next workgroup gets)
-#endif
         return; // whole workgroup
     }
     const uint32_t cnt = min(static_cast<uint32_t>(DEC_CH), nchunks - cfirst);
@@ -381,20 +350,13 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
 
         // ---- stage the stream; note which pieces are eight 2-byte records in a row (a flat or clipped image region would
         // otherwise cost a step per record, 128 per quarter)
-#ifdef MCRAW_K6_LDSDMA
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (my own pieces have landed: a wave reads back what it loaded)
-#endif
 #pragma unroll
         for (uint32_t r = 0; r < NROUND; r++) {
             const uint32_t i = tid + r * DEC_T;
             bool ones = false;
             if (i < NPIECE && (seg || i >= FRONT6 / 16u)) {
-#ifdef MCRAW_K6_LDSDMA
-                const uint4 vr = *reinterpret_cast<const uint4 *>(s_stage + i * 16u);
-#else
                 const uint4 vr = v[r];
                 *reinterpret_cast<uint4 *>(s_stage + i * 16u) = vr;
-#endif
                 // every even byte has a zero high nibble: a walk that arrives on the piece's first byte passes eight records of
                 // two bytes; none of them may be the chain's end (RawData_Legacy.cpp:387-388: the last one ends at 16 i + 16)
                 ones = ((vr.x | vr.y | vr.z | vr.w) & 0x00F000F0u) == 0u && i * 16u + 16u < limP;
@@ -770,8 +732,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         const uint32_t ent4v = qp | (qi << 8);
         const uint32_t entv = inq && !lost ? (cph | (qi << 8)) : DEAD;                 // (lanes with ur == 0: chunk uj's)
         const uint32_t ent16 = full && !lost ? (aph | (endn << 8)) : DEAD;             // ... and of the chunk behind a full segment
-        if (walker6)
-            s_ent4[lane] = ent4v;
+        s_ent4[lane] = ent4v;
         if (ur == 0u)
             s_ent[uj] = entv;
         if (lane == 0)
@@ -789,14 +750,14 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         // also wait for the look-back words' way to memory -- stores count on the same counter)
         const uint32_t uw = lane / (4u * ROWS_CH), j = (lane >> 2) & (ROWS_CH - 1u), r = lane & 3u;
         static_assert(ROWS_CH == 4, "an unpacking wave's chunks are sixteen lanes of this wave");
-        const uint32_t ew0 = wave_lane(entv, 0u), ew1 = wave_lane(entv, 16u), ew2 = wave_lane(entv, 32u % NQ6), ew3 = wave_lane(entv, 48u % NQ6);
+        const uint32_t ew0 = wave_lane(entv, 0u), ew1 = wave_lane(entv, 16u), ew2 = wave_lane(entv, 32u), ew3 = wave_lane(entv, 48u);
         auto ent_reg = [&](uint32_t w) { // entry of chunk w * ROWS_CH, as ent_of() will read it
             const uint32_t v = w >= UNPACK_W ? ent16 : w == 0u ? ew0 : w == 1u ? ew1 : w == 2u ? ew2 : ew3;
             return cfirst + w * ROWS_CH < nchunks ? v : DEAD;
         };
         const uint32_t enext_reg = ent_reg(uw + 1u);
         const Range6 rg = range_from(uw, ent_reg(uw), enext_reg);
-        const bool coop = __ballot(walker6 && !rg.lean) == 0ull;
+        const bool coop = __ballot(!rg.lean) == 0ull;
         if (lane == 0)
             s_coop = coop ? 1u : 0u;
         // The common case (no jumps over runs of 2-byte records in this segment, at most NOTES6 records per quarter, every
@@ -806,10 +767,8 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         // (every quarter starts at least seven: a record has at most 34 bytes), taken from the lane behind it: what a lane
         // stores beyond its own records is then exactly what that lane stores there itself, and it does not matter which
         // of the two stores comes last.
-        const bool noted = coop && notes_ok && __ballot(walker6 && (rg.pairmode || rg.N + NOTES6 > ROWS_CAP / 2u)) == 0ull;
-        if (!walker6) {
-            // (the upper lanes of a two-wave workgroup's resolving wave list nothing)
-        } else if (K6_ABL != 3 && noted) {
+        const bool noted = coop && notes_ok && __ballot(rg.pairmode || rg.N + NOTES6 > ROWS_CAP / 2u) == 0ull;
+        if (K6_ABL != 3 && noted) {
             const int32_t slot0 = static_cast<int32_t>(qi - rg.R0); // -1: an odd first record belongs to the previous wave's
             uint16_t *lp = s_pos[uw] + slot0;                        // last pair, never listed
             const uint32_t boff = j * CHUNK6 + r * (CHUNK6 / 4u);
@@ -904,17 +863,12 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     const bool coop = s_coop != 0u;
     if (K6_ABL == 2)
         return;
-    if (FIFTH6 && wave >= 4u && !coop) {
-        K6_END();
-        return; // (a fifth wave has no chunks of its own; on the lean path it takes a share of every wave's pairs)
-    }
-
-    const Range6 mine = range_of(wave & 3u);
+    const Range6 mine = range_of(wave);
     const uint32_t c0 = cfirst + wave * ROWS_CH, cs0 = c0 * CHUNK6;
     const uint32_t R0 = mine.R0, R1 = mine.R1, N = mine.N;
     const bool live = mine.live, pairmode = mine.pairmode;
     // entries of my chunks (lane j) and of the chunk after them (lane ROWS_CH): the general path walks from them
-    const uint32_t e = lane <= ROWS_CH ? ent_of((wave & 3u) * ROWS_CH + lane) : DEAD;
+    const uint32_t e = lane <= ROWS_CH ? ent_of(wave * ROWS_CH + lane) : DEAD;
 
     // (the walk tables are dead: from here on their LDS holds the record lists)
     const uint32_t width = static_cast<uint32_t>(P->width);
@@ -1029,23 +983,8 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     };
 
     if (coop) {
-        // The wave that resolved the entries has no chunks of its own: it takes the last TAIL6 tasks of each of the four
-        // lists (whole passes of 64 lanes: a wave's 580 tasks were nine passes and a tenth of 8 lanes; now seven or eight,
-        // and eight for the fifth wave).
         K6_STAMP(4, 0);
-        auto tail_of = [&](uint32_t ntask) { return ntask >= 3u * TAIL6 ? ntask - TAIL6 : ntask; }; // first task of the fifth wave's share
-        if (!FIFTH6) {
-            unpack_round(wave, R0, R1, pairmode, 0u, 2u * (R1 - R0));
-        } else if (wave < 4u) {
-            unpack_round(wave, R0, R1, pairmode, 0u, tail_of(2u * (R1 - R0)));
-        } else {
-#pragma unroll 1
-            for (uint32_t uw = 0; uw < 4u; uw++) {
-                const Range6 rg = range_of(uw);
-                const uint32_t ntask = 2u * (rg.R1 - rg.R0);
-                unpack_round(uw, rg.R0, rg.R1, rg.pairmode, tail_of(ntask), ntask);
-            }
-        }
+        unpack_round(wave, R0, R1, pairmode, 0u, 2u * (R1 - R0));
         K6_STAMP(5, 0);
 #ifdef MCRAW_DIAG
         if (threadIdx.x == 0 && blockIdx.x < K6_PROF_WG) {
@@ -1134,7 +1073,7 @@ void launch_k6_decode(const Plan6 *plans, const uint32_t *wg_tab, uint32_t stage
     const dim3 grid(nwg), block(DEC_T);
     const uint32_t nf = static_cast<uint32_t>(nframes);
     if (post.mode == 0u) {
-#if defined(MCRAW_DIAG) || defined(K6_PADENV) // occupancy experiments: extra LDS per workgroup (tools/k6_occ.sh)
+#ifdef MCRAW_DIAG // occupancy experiments: extra LDS per workgroup (tools/k6_occ.sh)
         static const uint32_t pad = getenv("MCRAW_K6_LDSPAD") ? static_cast<uint32_t>(atoi(getenv("MCRAW_K6_LDSPAD"))) : 0u;
         hipLaunchKernelGGL(k6_decode<0>, grid, block, pad, st, plans, wg_tab, stage0, look, tickets, epoch, nf, smax, post);
 #else

@@ -169,24 +169,10 @@ __device__ __forceinline__ Unpacked unpack8(const uint8_t *__restrict__ base, ui
 #ifndef MCRAW_SPEC_WARM
 #define MCRAW_SPEC_WARM 8192
 #endif
-// The kernel comes in two sizes (template parameters: threads per workgroup, 16-byte lines per thread and piece, records per
-// UNIT of the walk / decode pipeline, candidates in front of its pieces at which a speculative count starts):
-//   fat   512 threads, pieces of 32 KiB, 57 KB of LDS: the shortest chain -- what a batch runs when nothing else is on the chip;
-//   thin  256 threads, pieces of 12 KiB, 23 KB of LDS, one wave per SIMD: the footprint that fits beside the tile kernel's
-//         workgroups (a CU full of them has 10 KB of LDS and 192 VGPRs per SIMD to spare; one of them leaving makes room for
-//         one of these) -- what a batch runs whose k7_side hides behind the tile kernel of the batch in front (mcraw_abi.hip).
-#ifndef MCRAW_THIN_T
-#define MCRAW_THIN_T 256
-#endif
-#ifndef MCRAW_THIN_LPT
-#define MCRAW_THIN_LPT 3
-#endif
-#ifndef MCRAW_THIN_LCAP
-#define MCRAW_THIN_LCAP 256
-#endif
-#ifndef MCRAW_THIN_WARM
-#define MCRAW_THIN_WARM 4096
-#endif
+// (template parameters of the kernel: threads per workgroup, 16-byte lines per thread and piece, records per UNIT of the walk /
+// decode pipeline, candidates in front of its pieces at which a speculative count starts.  512 threads, pieces of 32 KiB, 57 KB
+// of LDS: the shortest chain.  Round 5 also built a THIN form -- 256 threads, pieces of 12 KiB, 23 KB of LDS -- that fits beside
+// the tile kernel's workgroups; what it was for did not pay, docs/lab_notes.md, and it is gone.)
 constexpr uint32_t SIDE_XL = 9;                             // lines behind the piece: 130 (reach of its last record) + 8 (read slack) bytes
 constexpr uint32_t SIDE_OUT = 0xFFu;                        // stride table: "behind the piece"
 constexpr uint32_t SIDE_DEAD = 0xFEu;                       // stride table: a record here would cross `len`
@@ -279,10 +265,6 @@ __global__ __launch_bounds__(SIDE_T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     //            one whose predecessor never speaks (workgroups started out of order and the chip is full) follows the chain
     //            from the stream's first record by itself.  Payload offsets are relative to the part's first item; k7_tiles adds
     //            the totals of the parts in front (Frame7::part_item, part_len).
-#ifdef MCRAW_THIN_PRIO
-    if (SIDE_T <= 256u) // the thin workgroups run beside the tile kernel's: their chain of dependent steps goes first at issue
-        __builtin_amdgcn_s_setprio(MCRAW_THIN_PRIO);
-#endif
     const uint32_t nfr = static_cast<uint32_t>(W.n7), nsb = PARTS ? W.nsplit[0] : 1u, nsr = PARTS ? W.nsplit[1] : 1u;
     const uint32_t bq = blockIdx.x / nfr, f = blockIdx.x - bq * nfr;
     const uint32_t s = bq < nsr ? 1u : 0u, part = s ? bq : bq - nsr, nsp = s ? nsr : nsb; // (the longer stream's parts first)
@@ -1313,15 +1295,6 @@ __global__ __launch_bounds__(256) void k7_tiles(const Work7 W, uint32_t total, u
     // span -> registers: 16-byte chunks lane, lane+64, ... (ITEM_SPAN + alignment head)
     constexpr uint32_t NV = (PAY_CHUNKS + 63u) / 64u;
     const __amdgpu_buffer_rsrc_t rs = frame_rsrc(I.in, I.len);
-#ifdef MCRAW_K7_LDSDMA
-    // The span from memory INTO the wave's LDS slice (buffer_load_dwordx4 ... lds: lane i's 16 bytes land at base + 16 i, which is
-    // the slice's own layout), no registers and no ds_write pass in between.  MEASURED, not shipped: docs/lab_notes.md, round 5.
-#pragma unroll
-    for (uint32_t c = 0; c < NV; c++)
-        if (ABL != 3 && lane + 64u * c < I.n16)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)(s_pay[wave] + 1024u * c), 16,
-                                                     static_cast<int>(I.base16 + (lane + 64u * c) * 16u), 0, 0, 2);
-#else
     uint4 v[NV];
 #pragma unroll
     for (uint32_t c = 0; c < NV; c++) {
@@ -1329,7 +1302,6 @@ __global__ __launch_bounds__(256) void k7_tiles(const Work7 W, uint32_t total, u
         if (ABL != 3 && lane + 64u * c < I.n16)
             v[c] = ld_b128_nt(rs, I.base16 + (lane + 64u * c) * 16u);
     }
-#endif
     uint32_t b = 0, r = 0;
     if (I.valid && lane < ITEM_BLOCKS && I.g * ITEM_BLOCKS + lane < I.nblk) {
         b = W.bits[I.meta + lane];
@@ -1358,13 +1330,11 @@ __global__ __launch_bounds__(256) void k7_tiles(const Work7 W, uint32_t total, u
         s_blk[wave][lane] = (I.head + ex) | (cls7_of(b) << 16);
         s_ref[wave][lane] = static_cast<uint16_t>(r);
     }
-#ifndef MCRAW_K7_LDSDMA
     uint4 *pay4 = reinterpret_cast<uint4 *>(s_pay[wave]);
 #pragma unroll
     for (uint32_t c = 0; c < NV; c++)
         if (lane + 64u * c < I.n16)
             pay4[lane + 64u * c] = v[c];
-#endif
     __syncthreads(); // (with loads that write the LDS in flight the compiler waits for them here: vmcnt(0) in front of the barrier)
 
 #pragma unroll
@@ -1394,15 +1364,13 @@ extern "C" uint32_t mcraw_tile_order(uint32_t b, uint32_t n, uint32_t runs)
     return runs ? xcd_chunked(b, n, runs) : xcd_remap(b, n);
 }
 
-void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st, bool thin)
+void launch_k7(const Work7 &W, uint32_t stage, hipStream_t st)
 {
     const uint32_t n7 = static_cast<uint32_t>(W.n7);
     switch (stage) {
     case MCRAW_K7_SIDE: {
         const dim3 sgrid(n7 * (W.nsplit[0] + W.nsplit[1]));
-        if (thin)
-            hipLaunchKernelGGL((k7_side<MCRAW_THIN_T, MCRAW_THIN_LPT, MCRAW_THIN_LCAP, MCRAW_THIN_WARM, true, false>), sgrid, dim3(MCRAW_THIN_T), 0, st, W);
-        else if (W.nsplit[0] + W.nsplit[1] > 2u && W.side_lastc)
+        if (W.nsplit[0] + W.nsplit[1] > 2u && W.side_lastc)
             hipLaunchKernelGGL((k7_side<MCRAW_SIDE_T, MCRAW_SIDE_LPT, MCRAW_SIDE_LCAP, MCRAW_SPEC_WARM, true, true>), sgrid, dim3(MCRAW_SIDE_T), 0, st, W);
         else if (W.nsplit[0] + W.nsplit[1] > 2u)
             hipLaunchKernelGGL((k7_side<MCRAW_SIDE_T, MCRAW_SIDE_LPT, MCRAW_SIDE_LCAP, MCRAW_SPEC_WARM, true, false>), sgrid, dim3(MCRAW_SIDE_T), 0, st, W);

@@ -191,6 +191,11 @@ struct Decoder::Impl {
             mcraw_frame f{}; // (the ticket's descriptor: lives as long as the ticket)
             mcraw_pool_ticket *ticket = nullptr;
         } dc;
+        // The last single-frame call's timestamp: a frame is read ahead only behind a call that walks the index -- the first frame
+        // of the file, or the successor of the frame the call before asked for.  A caller that jumps about then never has a
+        // payload read that it does not want (9 MB per call at UHD), nor waits at its next call for that read to end.
+        bool walked = false;
+        Timestamp last = 0;
     } ahead;
     // Both over: was the read good, did the frame decode?  (Whatever the answers, nothing is under way afterwards.)
     void settleAhead(bool &rdOk, bool &dcOk)
@@ -839,7 +844,17 @@ void Decoder::loadFramesImpl(const std::vector<Timestamp> &timestamps, std::vect
         frames[0].in = A.in[b].p;
         startRead(timestamps[0], b ^ 1);
     } else if (single) {
-        startRead(timestamps[0], 0);
+        const auto it = I.frameOffsets.find(timestamps[0]);
+        const bool first = it != I.frameOffsets.end() && it == I.frameOffsets.begin();
+        const bool next = A.walked && it != I.frameOffsets.end() && it != I.frameOffsets.begin() && std::prev(it)->first == A.last;
+        if (first || next)
+            startRead(timestamps[0], 0);
+    }
+    if (single) {
+        A.walked = true;
+        A.last = timestamps[0];
+    } else if (!direct) {
+        A.walked = false; // (a batch in between: the walk, if it is one, starts again)
     }
     std::future<void> reading = hitRd ? std::async(std::launch::deferred, []() {}) : std::async(std::launch::async, readChunk, size_t(0));
     std::vector<std::future<void>> copying(noutslots); // copy-out of the chunk that last used each output slot

@@ -5,6 +5,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstddef>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -15,6 +16,8 @@ namespace detail {
 
 // A few host threads that stay (per-frame callers: starting eight threads for every frame's copy-out cost more than the copy).
 // run(n, fn) calls fn(i) for i in [0, n) on the workers and the calling thread and returns when all are done; callers take turns.
+// An exception out of fn -- on any thread -- is caught where it is thrown, the remaining indices are still handed out (a worker
+// that stopped would leave the others' share undone), every thread is waited for, and the first exception is thrown again from run().
 class WorkerPool {
 public:
     explicit WorkerPool(unsigned workers)
@@ -43,17 +46,36 @@ public:
             n_ = n;
             next_.store(0);
             busy_ = threads_.size();
+            error_ = nullptr;
             gen_++;
         }
         cv_.notify_all();
-        for (size_t i = next_.fetch_add(1); i < n; i = next_.fetch_add(1))
-            fn(i);
-        std::unique_lock<std::mutex> lk(mu_);
-        done_.wait(lk, [this]() { return busy_ == 0; });
-        fn_ = nullptr;
+        work(fn, n);
+        std::exception_ptr err;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            done_.wait(lk, [this]() { return busy_ == 0; }); // (whatever happened: nobody calls fn any more behind this line)
+            fn_ = nullptr;
+            err = error_;
+            error_ = nullptr;
+        }
+        if (err)
+            std::rethrow_exception(err);
     }
 
 private:
+    void work(const std::function<void(size_t)> &fn, size_t n)
+    {
+        for (size_t i = next_.fetch_add(1); i < n; i = next_.fetch_add(1)) {
+            try {
+                fn(i);
+            } catch (...) {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (!error_)
+                    error_ = std::current_exception();
+            }
+        }
+    }
     void loop()
     {
         unsigned long long seen = 0;
@@ -69,8 +91,7 @@ private:
                 fn = fn_;
                 n = n_;
             }
-            for (size_t i = next_.fetch_add(1); i < n; i = next_.fetch_add(1))
-                (*fn)(i);
+            work(*fn, n);
             {
                 std::lock_guard<std::mutex> lk(mu_);
                 if (--busy_ == 0)
@@ -86,6 +107,7 @@ private:
     std::atomic<size_t> next_{0};
     unsigned long long gen_ = 0;
     bool quit_ = false;
+    std::exception_ptr error_; // the first exception of the run under way
 };
 
 } // namespace detail

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <numeric>
+#include <stdexcept>
 
 int main()
 {
@@ -33,6 +34,29 @@ int main()
         bad += wrong.load();
     }
     { WorkerPool idle(4); }
+    { // an exception out of the work -- on the calling thread or on a worker -- comes out of run(), once, after every index was
+      // handed out and every thread has stopped calling; the pool works afterwards
+        WorkerPool pool(4);
+        for (int round = 0; round < 50; round++) {
+            std::atomic<int> calls{0};
+            bool thrown = false;
+            try {
+                pool.run(16, [&](size_t i) {
+                    calls++;
+                    if (i == static_cast<size_t>(round % 16) || i == 15)
+                        throw std::runtime_error("slice failed");
+                });
+            } catch (const std::runtime_error &) {
+                thrown = true;
+            }
+            if (!thrown || calls.load() != 16)
+                bad++;
+            std::atomic<int> after{0};
+            pool.run(8, [&](size_t) { after++; });
+            if (after.load() != 8)
+                bad++;
+        }
+    }
     std::printf("wrong %ld\n", bad);
     return bad ? 1 : 0;
 }

@@ -12,6 +12,8 @@ import sys
 
 import pytest
 
+from motioncam_decoder_amd import build as B
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -42,12 +44,8 @@ print("ok")
 
 
 def test_lost_lookback_word_fails_one_frame_and_returns(tmp_path):
-    hipcc = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    csrc = os.path.join(ROOT, "motioncam_decoder_amd", "csrc")
     lib = str(tmp_path / "libmcraw_lost.so")
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-DMCRAW_INJECT_LOST",
-                    "-o", lib] + [os.path.join(csrc, f) for f in ("mcraw_abi.hip", "mcraw_pool.hip", "mcraw_type7.hip", "mcraw_type6.hip")]
-                   + ["-lpthread"], check=True, timeout=600)
+    B.build_variant(lib, ['-DMCRAW_INJECT_LOST'])
     env = dict(os.environ, MCRAW_LIB_PATH=lib)
     code = CHILD % {"root": ROOT, "tests": os.path.join(ROOT, "tests")}
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)

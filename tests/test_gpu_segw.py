@@ -12,17 +12,15 @@ import sys
 
 import pytest
 
+from motioncam_decoder_amd import build as B
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_all_type7_suites_with_every_stream_on_the_segment_walkers(tmp_path):
-    hipcc = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    csrc = os.path.join(ROOT, "motioncam_decoder_amd", "csrc")
     lib = str(tmp_path / "libmcraw_segw.so")
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-DMCRAW_FORCE_SEGW",
-                    "-o", lib] + [os.path.join(csrc, f) for f in ("mcraw_abi.hip", "mcraw_pool.hip", "mcraw_type7.hip", "mcraw_type6.hip")]
-                   + ["-lpthread"], check=True, timeout=600)
+    B.build_variant(lib, ['-DMCRAW_FORCE_SEGW'])
     env = dict(os.environ, MCRAW_LIB_PATH=lib)
     suites = ["test_gpu_parity.py", "test_gpu_fuzz.py", "test_gpu_negative.py", "test_encoder_variants.py", "test_gpu_properties.py"]
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"]

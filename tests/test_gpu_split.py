@@ -16,6 +16,8 @@ import sys
 import numpy as np
 import pytest
 
+from motioncam_decoder_amd import build as B
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SUITES = ["test_gpu_parity.py", "test_gpu_fuzz.py", "test_gpu_negative.py", "test_encoder_variants.py", "test_gpu_properties.py"]
@@ -41,12 +43,8 @@ def test_parts_whose_last_one_does_not_count():
 
 
 def _build(tmp_path, flag):
-    hipcc = os.environ.get("HIPCC") or shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    csrc = os.path.join(ROOT, "motioncam_decoder_amd", "csrc")
     lib = str(tmp_path / ("libmcraw_%s.so" % flag.lower()))
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-gpu-rdc", "-D" + flag,
-                    "-o", lib] + [os.path.join(csrc, f) for f in ("mcraw_abi.hip", "mcraw_pool.hip", "mcraw_type7.hip", "mcraw_type6.hip")]
-                   + ["-lpthread"], check=True, timeout=600)
+    B.build_variant(lib, ["-D" + flag])
     return lib
 
 

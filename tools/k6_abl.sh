@@ -1,7 +1,7 @@
 #!/bin/bash
 # gpurun -- 'bash tools/k6_abl.sh': what the legacy kernel's stages cost -- timing-only builds (-DK6_ABL=n: wrong pixels) beside the product
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-S="$R/motioncam_decoder_amd/csrc/mcraw_abi.hip $R/motioncam_decoder_amd/csrc/mcraw_pool.hip $R/motioncam_decoder_amd/csrc/mcraw_type7.hip $R/motioncam_decoder_amd/csrc/mcraw_type6.hip"
+S="$(ls $R/motioncam_decoder_amd/csrc/*.hip)"
 for a in ${K6_ABLS:-1 7 8 9}; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-gpu-rdc -DK6_ABL=$a "$@" -o /tmp/libabl$a.so $S -lpthread || exit 1
 done

@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 VARS=${VARS:-"3 4 6 8 16"}
 for V in $VARS; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-gpu-rdc -DMCRAW_WARM_SEGS=$V ${XDEF:-} -o /tmp/libw_$V.so $R/motioncam_decoder_amd/csrc/mcraw_abi.hip $R/motioncam_decoder_amd/csrc/mcraw_pool.hip $R/motioncam_decoder_amd/csrc/mcraw_type7.hip $R/motioncam_decoder_amd/csrc/mcraw_type6.hip -lpthread || exit 1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-gpu-rdc -DMCRAW_WARM_SEGS=$V ${XDEF:-} -o /tmp/libw_$V.so $(ls $R/motioncam_decoder_amd/csrc/*.hip) -lpthread || exit 1
 done
 for rep in 1 2; do for V in $VARS prev; do
   if [ $V = prev ]; then LIB=$R/motioncam_decoder_amd/lib/libmcraw_hip_prev.so; else LIB=/tmp/libw_$V.so; fi

@@ -3,7 +3,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 i=0
 for X in "" ${XDEFS:-}; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-gpu-rdc $X -o /tmp/libx_$i.so $R/motioncam_decoder_amd/csrc/mcraw_abi.hip $R/motioncam_decoder_amd/csrc/mcraw_pool.hip $R/motioncam_decoder_amd/csrc/mcraw_type7.hip $R/motioncam_decoder_amd/csrc/mcraw_type6.hip -lpthread || exit 1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-gpu-rdc $X -o /tmp/libx_$i.so $(ls $R/motioncam_decoder_amd/csrc/*.hip) -lpthread || exit 1
   i=$((i+1))
 done
 for rep in 1 2 3; do i=0; for X in "base" ${XDEFS:-}; do

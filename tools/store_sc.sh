@@ -2,7 +2,7 @@
 # gpurun -- 'bash tools/store_sc.sh': k7_tiles' output stores with other cache policies (-DMCRAW_STORE_POLICY: "sc1 nt" = the
 # product, "nt", "sc1", "sc0 sc1", "sc0 sc1 nt"), the headline leg in fresh processes, interleaved
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-S="$R/motioncam_decoder_amd/csrc/mcraw_abi.hip $R/motioncam_decoder_amd/csrc/mcraw_pool.hip $R/motioncam_decoder_amd/csrc/mcraw_type7.hip $R/motioncam_decoder_amd/csrc/mcraw_type6.hip"
+S="$(ls $R/motioncam_decoder_amd/csrc/*.hip)"
 POL=("sc1 nt" "nt" "sc1" "sc0 sc1" "sc0 sc1 nt")
 for k in 0 1 2 3 4; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-gpu-rdc "-DMCRAW_STORE_POLICY=\"${POL[$k]}\"" -o /tmp/libsc$k.so $S -lpthread || exit 1
