@@ -189,8 +189,8 @@ def frame_checksums(torch, comm, wl, nglobal):
 
 
 def run_timed(torch, comm, ctx, M, wl, args):
-    """Warm-up, per-kernel breakdown (untimed), then the timed rounds.  Returns (round times [s, max over
-    ranks], kernels_ms_bracketed, (k7_tiles ms summed over the timed rounds, launches), steps timed, ok)."""
+    """Warm-up, the timed rounds, then k7_side's time (untimed).  Returns (round times [s, max over ranks], {k7_side ms, the
+    XCD mapping, this rank's own ms per step}, (k7_tiles ms summed over the sampled launches of the timed rounds, launches), ok)."""
     from motioncam_decoder_amd import benchlib
     steps, warmup = args.steps, args.warmup
     nset = len(wl.desc_sets)
@@ -218,24 +218,26 @@ def run_timed(torch, comm, ctx, M, wl, args):
         ctx.decode_batch(wl.desc_sets[i % nset], mem=M.MEM_DEVICE, stream=streams[i % nset].cuda_stream, want_status=False)
         counted[0] += 1
 
-    times = benchlib.timed_rounds(step, torch.cuda.synchronize, comm, steps, max(0, warmup - 1), args.min_seconds)
+    own = []
+    times = benchlib.timed_rounds(step, torch.cuda.synchronize, comm, steps, max(0, warmup - 1), args.min_seconds, own=own)
     st = ctx.synchronize(wl.frames)
     ok = ok and all(s == 0 for s in st)
     for which in range(min(nset, steps)): # every buffer set the timed steps wrote
         ok = ok and wl.verify(torch, sorted({min(1, wl.frames - 1), wl.frames // 3, max(0, wl.frames - 2)}), which)
     tiles = ctx.kernel_ms("k7_tiles", reset=True) # (ms summed over warm-up + timed rounds, launches)
-    # untimed, behind the timed rounds: a few steps on one stream with EVERY kernel bracketed by events, for the per-kernel
-    # breakdown (an event pair costs the stream several microseconds: these figures are a little above the timed ones)
-    names = ("k7_side", "k7_tiles")
-    ctx.profile(True)
-    for i in range(4):
+    # untimed, behind the timed rounds: a few steps with k7_side between two event records (the tile kernel's time is the one
+    # sampled in the timed rounds: a bracket around every launch costs the stream several microseconds and made the tile
+    # kernel read longer than the whole step)
+    ctx.profile(only=("k7_side",))
+    for i in range(7):
         if i == 1: # the first step after the synchronise runs on an idle, down-clocked GPU
-            for k in M.KERNELS:
-                ctx.kernel_ms(k, reset=True)
+            ctx.kernel_ms("k7_side", reset=True)
         ctx.decode_batch(wl.descs, mem=M.MEM_DEVICE, stream=streams[0].cuda_stream, want_status=False)
     torch.cuda.synchronize()
-    kms = {k: ctx.kernel_ms(k, reset=True)[0] / 3.0 for k in names}
+    kms = {"k7_side": ctx.kernel_ms("k7_side", reset=True)[0] / 6.0}
     kms["xcd_runs"] = ctx.xcd_runs()  # the mapping of k7_tiles' workgroups the library measured as the faster one here
+    kms["own_ms_per_step"] = 1e3 * sorted(own)[len(own) // 2] / steps  # this rank's own median round (in front of the closing barrier)
+    ctx.profile(True)
     return times, kms, tiles, ok
 
 
@@ -448,6 +450,7 @@ def pcie_inclusive(M, L, ctx, wl, comm, link=None, nframes=240, reps=2, pack12=F
             err = e
         comm.barrier()
         t = comm.max([t_local])[0]                 # the job's rate is set by its slowest rank
+        own_rates = comm.gather(n / t_local if t_local < 1e8 else 0.0)
         ok = bool(comm.min([1.0 if ok else 0.0])[0] > 0.5)
         if not all_ok():
             return {"error": repr(err) if err else "another rank failed in the timed part of this leg"}
@@ -459,6 +462,9 @@ def pcie_inclusive(M, L, ctx, wl, comm, link=None, nframes=240, reps=2, pack12=F
                "note": "pinned host buffers in and out; sub-batches flow through upload stream / kernels / download stream; PCIe-bound"
                        + (("; %d-bit strips out (mcraw_ctx_set_post)" % bits) if bits else "")
                        + ("; all ranks at once" if world > 1 else "")}
+        if world > 1:
+            res["frames_per_s_by_rank"] = [round(v, 1) for v in own_rates]
+        res["status_words"] = {None: "undecided", 0: "fetched", 1: "sent"}[ctx.host_way()]
         if link:
             # time the two directions need at the rates this link showed with both directions busy
             t_link = max(in_b / (link["each_way_when_both_GBs"] * 1e9), n * out_bytes / (link["each_way_when_both_GBs"] * 1e9))
@@ -598,10 +604,11 @@ def post_stage(torch, ctx, M, L, wl, steps, bits=12):
                      "bytes twice and is slower still (these 12-bit frames saturate at 1023 on the way, like the oracle's)",
                  14: "ONE 16-byte store per lane and row in the frame's interior (round 5: the next row piece's first two bytes are fetched "
                      "across lanes and written by both lanes; 12 + 2 bytes per lane, round 4's form, touched every line twice: 1.24 -> 1.15 ms)"}[bits]
-        return {"stage": "black levels %s subtracted, rows as %d-bit strips" % (black, bits), "ms_per_step": round(1e3 * el / steps, 4),
-                "mpix_s": round(wl.pixels * steps / el / 1e6, 1), "tiles_ms_per_launch": round(tile_ms / max(tile_n, 1), 4),
-                "algorithmic_bytes_per_launch": wl.in_bytes + out_b, "achieved_gbs": round(ach, 1),
-                "frac": round(ach / HBM_PEAK_GBS, 4), "xcd_runs": ctx.xcd_runs(), "bit_exact": bool(ok), "bound": bound}
+        out = {"stage": "black levels %s subtracted, rows as %d-bit strips" % (black, bits), "ms_per_step": round(1e3 * el / steps, 4),
+               "mpix_s": round(wl.pixels * steps / el / 1e6, 1), "tiles_ms_per_launch": round(tile_ms / max(tile_n, 1), 4),
+               "algorithmic_bytes_per_launch": wl.in_bytes + out_b, "achieved_gbs": round(ach, 1),
+               "frac": round(ach / HBM_PEAK_GBS, 4), "xcd_runs": ctx.xcd_runs(), "bit_exact": bool(ok), "bound": bound}
+        return with_frac_profile(out, "post%d" % bits, "k7_tiles", wl.in_bytes + out_b)
     finally:
         ctx.set_post()
         ctx.profile(True)
@@ -635,7 +642,7 @@ def legacy_leg(torch, ctx, M, L, dev, n=32, w=4000, h=3000, nbits=12, sigma=12.0
     t = (time.perf_counter() - t0) / reps
     ctx.profile(only=("k6_decode",), every=4)
     ctx.kernel_ms("k6_decode", reset=True)
-    for _ in range(16):
+    for _ in range(96):  # (24 sampled launches)
         ctx.decode_batch(frames, want_status=False)
     torch.cuda.synchronize()
     kt, kn = ctx.kernel_ms("k6_decode", reset=True)
@@ -652,7 +659,8 @@ def legacy_leg(torch, ctx, M, L, dev, n=32, w=4000, h=3000, nbits=12, sigma=12.0
     out["algorithmic_bytes_per_batch"] = byts
     if kms["k6_decode"] > 0:
         out["frac"] = round(byts / (kms["k6_decode"] * 1e-3) / 1e9 / 8000.0, 4)
-    for tag in ("r05", "r04", "r03", "r02"):
+    with_frac_profile(out, "legacy", "k6_decode", byts)
+    for tag in ("r06", "r05", "r04", "r03", "r02"):
         try:
             with open(os.path.join(ROOT, "profiles", tag + "_legacy_traffic.json")) as f:
                 tj = json.load(f)
@@ -695,19 +703,23 @@ def config5_leg(torch, ctx, M, L, dev, n=120, w=7680, h=4320, nbits=12, sigma=12
         ctx.decode_batch(frames, want_status=False)
     torch.cuda.synchronize()
     t = (time.perf_counter() - t0) / reps
+    kms = {}
+    for kname, every, launches in (("k7_tiles", 2, 8), ("k7_side", 1, 4)):  # (one kernel at a time between event records, the tile kernel every 2nd launch)
+        ctx.profile(only=(kname,), every=every)
+        ctx.kernel_ms(kname, reset=True)
+        for _ in range(launches):
+            ctx.decode_batch(frames, want_status=False)
+        torch.cuda.synchronize()
+        kt, kn = ctx.kernel_ms(kname, reset=True)
+        kms[kname] = round(kt / max(kn, 1), 4)
     ctx.profile(True)
-    for k in M.KERNELS:
-        ctx.kernel_ms(k, reset=True)
-    for _ in range(3):
-        ctx.decode_batch(frames, want_status=False)
-    torch.cuda.synchronize()
-    kms = {k: round(ctx.kernel_ms(k, reset=True)[0] / 3.0, 4) for k in ("k7_side", "k7_tiles")}
     out = {"workload": "config 5, one rank's share: %d x %dx%d %d-bit type-7 frames, Nat" % (n, w, h, nbits), "ms_per_step": round(t * 1e3, 4),
            "steps_timed": reps, "mpix_s": round(n * w * h / t / 1e6, 1), "algorithmic_bytes_per_step": byts,
-           "step_frac": round(byts / t / 1e9 / HBM_PEAK_GBS, 4), "kernels_ms_bracketed": kms, "xcd_runs": ctx.xcd_runs(),
+           "step_frac": round(byts / t / 1e9 / HBM_PEAK_GBS, 4), "kernels_ms_per_step": kms, "xcd_runs": ctx.xcd_runs(),
            "side_parts": ctx.side_parts(), "bit_exact": bool(ok)}
     if kms["k7_tiles"] > 0:
         out["frac"] = round(byts / (kms["k7_tiles"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    with_frac_profile(out, "config5", "k7_tiles", byts)
     del tin, tout
     return out
 
@@ -772,22 +784,40 @@ def traffic_from_profile(workload_key, algorithmic_bytes=None):
     return None, None
 
 
-def profile_launch_ms(dist):
-    """Average k7_tiles launch of the committed rocprofv3 --kernel-trace --stats summary of this workload (profiles/rNN_<dist>_kernel_stats.csv,
-    the newest round), or (None, None)."""
+def profile_kernel_ms(workload, kernel="k7_tiles"):
+    """Average launch of `kernel` in the committed rocprofv3 --kernel-trace --stats summary of a workload
+    (profiles/rNN_<workload>_kernel_stats.csv of the newest round that has one), or (None, None).  Every leg of the line carries
+    the fraction this gives (`frac_profile`) beside the one its own events measure, so no leg prints a fraction that profiles/ does
+    not show."""
     import csv
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s_kernel_stats.csv" % dist)), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_%s_kernel_stats.csv" % workload)), reverse=True):
         try:
             with open(path) as f:
                 rows = list(csv.reader(line for line in f if not line.startswith("#")))
             hdr = rows[0]
+            best = None
             for r in rows[1:]:
-                if "k7_tiles" in r[hdr.index("Name")]:
-                    return float(r[hdr.index("AverageNs")]) * 1e-6, os.path.relpath(path, ROOT)
+                if kernel in r[hdr.index("Name")]:
+                    tot = float(r[hdr.index("TotalDurationNs")]) if "TotalDurationNs" in hdr else float(r[hdr.index("AverageNs")])
+                    if best is None or tot > best[0]:  # (several instances of a kernel: the one the workload spends its time in)
+                        best = (tot, float(r[hdr.index("AverageNs")]) * 1e-6)
+            if best:
+                return best[1], os.path.relpath(path, ROOT)
         except Exception:
             continue
     return None, None
+
+
+def with_frac_profile(out, workload, kernel, byts):
+    ms, path = profile_kernel_ms(workload, kernel)
+    out["frac_profile"] = round(byts / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms else None
+    out["frac_profile_source"] = ("%s: %s AverageNs %.0f" % (path, kernel, ms * 1e6)) if ms else None
+    return out
+
+
+def profile_launch_ms(dist):
+    return profile_kernel_ms(dist, "k7_tiles")
 
 
 def stub_main(args):
@@ -808,8 +838,10 @@ def stub_main(args):
     mine = shard.shard_frames(world * args.frames, rank, world)
     assert len(mine) == args.frames
     per_step = 0.002 * (1 + rank)  # the slower rank sets the job's time
-    times = benchlib.timed_rounds(lambda i: time.sleep(per_step), lambda: None, comm, args.steps, args.warmup, args.min_seconds)
+    own = []
+    times = benchlib.timed_rounds(lambda i: time.sleep(per_step), lambda: None, comm, args.steps, args.warmup, args.min_seconds, own=own)
     ok = bool(comm.min([1.0])[0] > 0.5)
+    per_rank = {"ms_per_step": [round(v, 4) for v in comm.gather(1e3 * sorted(own)[len(own) // 2] / args.steps)]} if world > 1 else None
     if comm.rank == 0:
         st = benchlib.round_stats(times, args.steps)
         pixels = world * args.frames * args.width * args.height
@@ -817,7 +849,7 @@ def stub_main(args):
                           "n_gpus": world, "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(st["median"], 4),
                           "ms_per_step_min": round(st["min"], 4), "ms_per_step_max": round(st["max"], 4), "rounds": st["rounds"],
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u16",
-                          "data": "stub: no decode (CPU rehearsal of the multi-rank protocol)", "bit_exact": ok,
+                          "data": "stub: no decode (CPU rehearsal of the multi-rank protocol)", "bit_exact": ok, "per_rank": per_rank,
                           "config": {"workload": "stub", "frames_per_gpu": args.frames}}), flush=True)
     if comm.dist:
         dist_mod.barrier()
@@ -963,6 +995,23 @@ def main():
                 extra["pool"] = {"error": repr(e)}
         comm.barrier()
 
+    # what an N > 1 line says about every rank (each figure a rank's own, in front of the closing barriers): a sub-linear curve
+    # can then be read -- one slow GPU, one NUMA node, one mapping of the tile kernel, one way home of the status words
+    per_rank = None
+    if world > 1:
+        r0 = results[args.dist]
+        tile_ms, tile_n = r0["tiles"]
+        per_rank = {
+            "ms_per_step": [round(v, 4) for v in comm.gather(r0["kms"]["own_ms_per_step"])],
+            "k7_tiles_avg_launch_ms": [round(v, 4) for v in comm.gather(tile_ms / max(tile_n, 1))],
+            "k7_side_ms": [round(v, 4) for v in comm.gather(r0["kms"]["k7_side"])],
+            "xcd_runs": [int(v) for v in comm.gather(r0["kms"].get("xcd_runs") if r0["kms"].get("xcd_runs") is not None else -1)],
+            "numa_node": [int(v) for v in comm.gather(numa["node"] if numa else -1)],
+            "host_way": [int(v) for v in comm.gather(ctx.host_way() if ctx.host_way() is not None else -1)],
+            "note": "by rank; ms_per_step: the rank's own median round, taken in front of the round's closing barrier (the line's "
+                    "ms_per_step is the max over ranks per round); xcd_runs / host_way: what the rank's context measured and chose "
+                    "(-1: nothing decided); pcie_inclusive*.frames_per_s_by_rank: every rank's own host-to-host rate",
+        }
     if rank == 0:
         def summarize(r):
             wl = r["wl"]
@@ -979,7 +1028,7 @@ def main():
                 "step_gbs": bytes_step / (st["median"] * 1e-3) / 1e9,
                 "bytes_per_launch": bytes_step,
                 "bpp": wl.bpp,
-                "kernels_ms_bracketed": r["kms"],  # untimed pass with every kernel bracketed
+                "kms": r["kms"],
             }
 
         s = summarize(results[args.dist])
@@ -1032,15 +1081,16 @@ def main():
                          "algorithmic_bytes_per_launch": round(s["bytes_per_launch"]),
                          "avg_launch_ms": round(s["tiles_ms_per_launch"], 4),
                          "launches_per_step": 1.0, "kernel_launches_per_step": 2,
-                         "xcd_runs": s["kernels_ms_bracketed"].get("xcd_runs"),
+                         "xcd_runs": s["kms"].get("xcd_runs"),
                          "xcd_recheck_share": "1 launch in 64 is timed, the chosen mapping and the other one in turn: 1 in 128 runs the mapping that "
                                               "was NOT chosen (+0 .. 8 % for that launch, < 0.07 % of the step)",
                          "timed_with": "HIP events on the launch stream around every 8th k7_tiles launch of the timed rounds"},
-            "kernels_ms_bracketed": {k: round(v, 4) for k, v in s["kernels_ms_bracketed"].items() if k != "xcd_runs"},
-            "kernels_ms_bracketed_note": "three UNTIMED steps behind the timed rounds with EVERY kernel between two event records (each "
-                                         "bracket costs the stream several microseconds, so these read above roofline.avg_launch_ms and "
-                                         "their sum above ms_per_step): a breakdown, not a timing",
+            "kernels_ms_per_step": {"k7_tiles": round(s["tiles_ms_per_launch"], 4), "k7_side": round(s["kms"]["k7_side"], 4)},
+            "kernels_ms_per_step_note": "k7_tiles: every 8th launch of the timed rounds between two event records (= roofline.avg_launch_ms); "
+                                        "k7_side: every launch of six untimed steps behind them; the rest of ms_per_step is two kernel boundaries",
         }
+        if world > 1:
+            out["per_rank"] = per_rank
         calib_after = box_calibration(torch, dev)
         out["box_calibration"] = {"before": calib, "after": calib_after,
                                   "note": "torch fill / copy of 1 GiB in this process, before and after the timed rounds: this box's own HBM yardstick"}
@@ -1053,9 +1103,10 @@ def main():
                                 "step_frac": round(s2["step_gbs"] / HBM_PEAK_GBS, 4),
                                 "algorithmic_bytes_per_launch": round(s2["bytes_per_launch"]), "avg_launch_ms": round(s2["tiles_ms_per_launch"], 4),
                                 "traffic": (lambda tv: round(tv) if tv else None)(traffic_from_profile(key2, s2["bytes_per_launch"])[0]),
-                                "kernels_ms_bracketed": {k: round(v, 4) for k, v in s2["kernels_ms_bracketed"].items() if k != "xcd_runs"},
-                                "xcd_runs": s2["kernels_ms_bracketed"].get("xcd_runs"),
+                                "kernels_ms_per_step": {"k7_tiles": round(s2["tiles_ms_per_launch"], 4), "k7_side": round(s2["kms"]["k7_side"], 4)},
+                                "xcd_runs": s2["kms"].get("xcd_runs"),
                                 "bit_exact": results[d]["ok"]}
+            with_frac_profile(out["also_" + d], d, "k7_tiles", s2["bytes_per_launch"])
         out.update(extra)
         if not args.no_cpu: # (rank 0 alone, at every N: the other ranks wait at the barrier below)
             try:

@@ -219,6 +219,10 @@ int mcraw_ctx_xcd_runs(mcraw_ctx *ctx);
  * of a geometry, re-checked by one timed launch in 64.  Returns 16 * (parts of the bits stream) + (parts of the refs stream) for
  * the geometry of the last such batch, -1 while measuring or when nothing was measured. */
 int mcraw_ctx_side_parts(mcraw_ctx *ctx);
+/* Host-memory batches (MCRAW_MEM_HOST): how the status words of a large batch come home -- 0: fetched when the batch is waited
+ * for, 1: written into pinned memory behind the kernels, -1: the context is still comparing the two on its own batches (which is
+ * faster depends on what else the process has done with the GPU; MCRAW_SHORT_WAY decides beforehand). */
+int mcraw_ctx_host_way(mcraw_ctx *ctx);
 
 /* Optional stage fused behind the decode, for consumers that take the mosaic further on the
  * device or ship it as a DNG strip (what example.cpp:80-92 hands to the DNG writer: the raw strip,

@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "mcraw_pool_size", "mcraw_pool_device", "mcraw_pool_numa_cpus", "mcraw_pool_ctx", "mcraw_pool_set_post",
     "mcraw_pool_host_alloc", "mcraw_pool_decode_batch", "mcraw_pool_decode_batch_async", "mcraw_pool_ticket_wait",
     "mcraw_pool_decode_batch_device", "mcraw_ctx_xcd_runs", "mcraw_pool_synchronize", "mcraw_tile_order",
-    "mcraw_ctx_last_serial", "mcraw_ctx_batch_status", "mcraw_ctx_errors", "mcraw_ctx_side_parts",
+    "mcraw_ctx_last_serial", "mcraw_ctx_batch_status", "mcraw_ctx_errors", "mcraw_ctx_side_parts", "mcraw_ctx_host_way",
 ]
 
 POST_BLACK, POST_PACK12, POST_PACK10, POST_PACK14 = 1, 2, 4, 8
@@ -159,6 +159,8 @@ def load():
     lib.mcraw_ctx_xcd_runs.argtypes = [C.c_void_p]
     lib.mcraw_ctx_side_parts.restype = C.c_int
     lib.mcraw_ctx_side_parts.argtypes = [C.c_void_p]
+    lib.mcraw_ctx_host_way.restype = C.c_int
+    lib.mcraw_ctx_host_way.argtypes = [C.c_void_p]
     lib.mcraw_pool_decode_batch_device.restype = C.c_int
     lib.mcraw_pool_decode_batch_device.argtypes = [C.c_void_p, C.POINTER(Frame), C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int32)]
     lib.mcraw_pool_decode_batch_async.restype = C.c_int
@@ -350,6 +352,11 @@ class Context:
         """(parts of the bits stream, parts of the refs stream) k7_side was measured to run fastest with, or None."""
         v = int(self._lib.mcraw_ctx_side_parts(self._h))
         return None if v < 0 else (v >> 4, v & 15)
+
+    def host_way(self):
+        """How the status words of large host-memory batches come home: 0 fetched, 1 sent behind the kernels, None: still comparing."""
+        v = int(self._lib.mcraw_ctx_host_way(self._h))
+        return None if v < 0 else v
 
     def last_serial(self):
         return int(self._lib.mcraw_ctx_last_serial(self._h))

@@ -147,12 +147,18 @@ class Comm:
     def sum(self, values):
         return self._reduce(values, self.dist.ReduceOp.SUM if self.dist else None)
 
+    def gather(self, value):
+        """Every rank's `value` (a number), by rank: one all-reduce of a one-hot vector."""
+        w, r = self.world, self.rank
+        return self.sum([float(value) if i == r else 0.0 for i in range(w)])
 
-def timed_rounds(step, sync, comm, steps, warmup, min_seconds=0.5, max_rounds=200):
+
+def timed_rounds(step, sync, comm, steps, warmup, min_seconds=0.5, max_rounds=200, own=None):
     """The bench.py protocol: `warmup` untimed steps, then rounds of EXACTLY `steps` steps, each round
     bracketed by barrier + sync on both sides.  The number of rounds is chosen (by the slowest rank,
     after the first round) so that the timed rounds cover at least `min_seconds`.  Returns the list of
-    round times in seconds, each already the MAX over ranks."""
+    round times in seconds, each already the MAX over ranks.  `own` (a list): this rank's own round times, taken when ITS
+    steps were done, in front of the closing barrier -- what the per-rank figures of an N > 1 line are made of."""
     for i in range(warmup):
         step(i)
     sync()
@@ -164,14 +170,17 @@ def timed_rounds(step, sync, comm, steps, warmup, min_seconds=0.5, max_rounds=20
         for i in range(steps):
             step(i)
         sync()
+        mine = time.perf_counter() - t0
         comm.barrier()
-        return time.perf_counter() - t0
+        return time.perf_counter() - t0, mine
 
-    first = comm.max([one_round()])[0]
+    first = comm.max([one_round()[0]])[0]
     rounds = int(min(max_rounds, max(1, math.ceil(min_seconds / max(first, 1e-9)))))
     rounds = int(comm.max([rounds])[0])  # every rank runs the same number
-    local = [one_round() for _ in range(rounds)]
-    return comm.max(local)
+    both = [one_round() for _ in range(rounds)]
+    if own is not None:
+        own.extend(m for _, m in both)
+    return comm.max([t for t, _ in both])
 
 
 def round_stats(times, steps):

@@ -186,6 +186,7 @@ void mcraw_ctx_destroy(mcraw_ctx *c)
         return;
     if (c->counted)
         g_ctx_on_device[c->device]--;
+    gate_forget(c);
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     auto release = [](Slot &s) {
@@ -518,6 +519,14 @@ int mcraw_ctx_side_parts(mcraw_ctx *c)
         return -1;
     const mcraw_ctx::SideTune &t = c->side_tunes[c->side_last];
     return t.cand[t.decided][0] * 16 + t.cand[t.decided][1];
+}
+
+int mcraw_ctx_host_way(mcraw_ctx *c)
+{
+    if (!c)
+        return -1;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return c->send_home;
 }
 
 int mcraw_ctx_profile_every(mcraw_ctx *c, int n)

@@ -330,8 +330,24 @@ size_t written_of(const mcraw_frame &f, int32_t status, uint32_t encH);
 int32_t public_status(int32_t st);
 int decode_device(mcraw_ctx *c, const mcraw_frame *frames, int n, hipStream_t user, size_t *written, int32_t *status_out);
 // ---- mcraw_hostmem.hip
-// (is this context the only one of the process on its device?  The short way of the pipeline is tuned for ONE stream of batches)
+// (is this context the only one of the process on its device?  The pipeline's scheduling is tuned for ONE stream of batches on a
+// GPU's copy engines; contexts that share a device share one count of the batches under way, DevGate)
 inline bool alone_on_device(const mcraw_ctx *c) { return !c->counted || g_ctx_on_device[c->device].load() <= 1; }
+// What the contexts of one device share (round 6; two contexts on one GPU -- a pool of two members on it -- used to fall back to
+// the pipeline's old scheduling, 2 277 against 2 940 UHD frames/s): the short batches of ALL of them that still have downloads
+// under way, as the `done` events of their last sub-batches (a batch is queued only when at most one other, of whatever context,
+// is still out), and which way home of the status words a context of this device measured as the faster one.
+struct DevGate {
+    struct Flight {
+        hipEvent_t done;
+        const mcraw_ctx *c;
+    };
+    std::mutex mu;
+    std::vector<Flight> flights;
+    int way = -1;
+};
+extern DevGate g_gate[64];
+void gate_forget(const mcraw_ctx *c); // (a context that goes away: none of its events may stay in the gate)
 constexpr size_t PIECE_BYTES = 4 * (96ull << 20); // a large host-memory batch is dealt out in pieces of this size (deal_host)
 int host_submit_part(mcraw_ticket *t, int first, int count);
 int host_submit(mcraw_ticket *t);

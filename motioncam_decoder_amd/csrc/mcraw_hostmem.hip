@@ -183,7 +183,31 @@ int host_submit_part(mcraw_ticket *t, int first, int count)
     return 0;
 }
 
-// Is this context the only one of the process on its device?  (Else: the long way for every batch.)
+DevGate g_gate[64];
+
+void gate_forget(const mcraw_ctx *c)
+{
+    if (c->device < 0 || c->device >= 64)
+        return;
+    DevGate &g = g_gate[c->device];
+    std::lock_guard<std::mutex> lk(g.mu);
+    g.flights.erase(std::remove_if(g.flights.begin(), g.flights.end(), [&](const DevGate::Flight &f) { return f.c == c; }), g.flights.end());
+}
+
+// Contexts that share their device: wait until at most one short batch of ANY of them still has downloads under way.  Called with
+// the gate locked; the batches that are over are dropped from the list on the way.
+static void gate_wait(DevGate &g)
+{
+    for (;;) {
+        g.flights.erase(std::remove_if(g.flights.begin(), g.flights.end(),
+                                       [](const DevGate::Flight &f) { return hipEventQuery(f.done) != hipErrorNotReady; }),
+                        g.flights.end());
+        (void)hipGetLastError();
+        if (g.flights.size() <= 1)
+            return;
+        (void)hipEventSynchronize(g.flights.front().done); // (the oldest one; its slot's event may have been recorded again since: then longer)
+    }
+}
 
 // Queue a host-memory batch (ticket->frames): returns when the last sub-batch is submitted.
 int host_submit(mcraw_ticket *t)
@@ -241,8 +265,15 @@ int host_submit(mcraw_ticket *t)
         int parts = 0;
         for (int f = 0; f < n && parts <= SHORT_PARTS; parts++)
             f += cut(f);
-        t->small = parts <= SHORT_PARTS && alone_on_device(c);
+        t->small = parts <= SHORT_PARTS;
         t->send = t->small && t->want_send == 1;
+    }
+    // (a device shared by several contexts: one count of the batches under way for all of them, held while this one is queued)
+    const bool shared = t->small && !alone_on_device(c) && c->device >= 0 && c->device < 64;
+    std::unique_lock<std::mutex> gate_lk;
+    if (shared) {
+        gate_lk = std::unique_lock<std::mutex>(g_gate[c->device].mu);
+        gate_wait(g_gate[c->device]);
     }
     while (t->small) {
         int others = 0;
@@ -297,6 +328,8 @@ int host_submit(mcraw_ticket *t)
         }
         first += count;
     }
+    if (shared && !t->parts.empty())
+        g_gate[c->device].flights.push_back({c->slots[t->parts.back().slot].done, c});
     return 0;
 }
 
@@ -368,6 +401,13 @@ void way_from_env(mcraw_ctx *c)
 {
     if (c->env_short_way >= 0 && c->send_home < 0)
         c->send_home = c->send_home_tickets = c->env_short_way;
+    // (a context that shares its device does not compare -- the others' traffic is in its times --: it takes what a context of
+    // this device found, if one has)
+    if (c->send_home < 0 && !alone_on_device(c) && c->device >= 0 && c->device < 64) {
+        std::lock_guard<std::mutex> lk(g_gate[c->device].mu);
+        if (g_gate[c->device].way >= 0)
+            c->send_home = c->send_home_tickets = g_gate[c->device].way;
+    }
 }
 
 // The way of a batch of more than one piece; *trial: it is one of the two that are compared (big_way_result when it is over).
@@ -402,6 +442,10 @@ void big_way_result(mcraw_ctx *c, int way, size_t total, double seconds)
     c->trial_rate[way] = total / seconds;
     if (way == 1) {
         c->send_home = c->trial_rate[1] > c->trial_rate[0] * 1.03 ? 1 : 0;
+        if (c->device >= 0 && c->device < 64) {
+            std::lock_guard<std::mutex> lk(g_gate[c->device].mu);
+            g_gate[c->device].way = c->send_home;
+        }
         if (c->env_trace)
             std::fprintf(stderr, "[mcraw] host-memory pipeline: status words fetched %.1f GB/s, sent home %.1f GB/s: %s from here on\n",
                          c->trial_rate[0] / 1e9, c->trial_rate[1] / 1e9, c->send_home ? "sent" : "fetched");
@@ -413,7 +457,7 @@ int deal_host(mcraw_ctx *c, const mcraw_frame *frames, int n, size_t *written, i
 {
     // (a piece is cut by bytes here and into sub-batches of up to 96 MB by host_submit, which ends one in front of the frame that
     // would not fit: four sub-batches' worth of bytes are five or six sub-batches, short by host_submit's count)
-    const size_t piece = alone_on_device(c) ? PIECE_BYTES : SIZE_MAX;
+    const size_t piece = PIECE_BYTES;
     int rc = 0, first = 0;
     while (first < n && rc == 0) {
         size_t bytes = 0;

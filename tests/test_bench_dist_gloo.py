@@ -40,6 +40,9 @@ def test_bench_protocol_world2_gloo():
     assert d["bit_exact"] is True
     px = 2 * 5 * 3840 * 2160
     assert abs(d["value"] - px / (d["ms_per_step"] * 1e-3) / 1e6) < 1.0   # whole-job rate over both ranks
+    # every rank's own time beside the max over ranks: the stub's rank 1 takes twice as long per step as its rank 0
+    own = d["per_rank"]["ms_per_step"]
+    assert len(own) == 2 and 1.9 <= own[0] < own[1] <= d["ms_per_step"] + 0.5 and own[1] > 3.9
 
 
 @pytest.mark.timeout(300)
