@@ -156,7 +156,6 @@ __device__ __forceinline__ bool look_get(const uint64_t *w, uint32_t epoch, uint
     *v = static_cast<uint32_t>(x);
     return static_cast<uint32_t>(x >> 32) == epoch;
 }
-
 // ---- fused post-decode stage (Post in mcraw_plan.h) ---------------------------------------------
 //
 // 8 consecutive samples of row y starting at an even column arrive as four dwords of (even column |

@@ -111,7 +111,8 @@ constexpr uint32_t ROWS_CAP = 256u * ROWS_CH; // records per round (typical: ~70
 static_assert(ROWS_CAP <= 1024u && ROWS_CAP % 2u == 0u, "the division-free row arithmetic of the unpack assumes at most 512 pairs per round");
 
 #ifndef K6_ABL
-#define K6_ABL 0 // timing experiments only (wrong pixels): 1 no stores, 2 no unpack, 3 no record lists, 4 load + stage only, 8 no ticket
+#define K6_ABL 0 // timing experiments only (wrong pixels): 1 no stores, 2 no unpack, 3 no record lists, 4 load + stage only, 8 no ticket,
+                 // 16 forty vector instructions more per unpack pass, 32 no look-back (record indices estimated), 33 one poll, not waited on
 #endif
 
 // ------------------------------------------------------------------ k6_decode
@@ -209,15 +210,17 @@ constexpr int K6_PROF_WG = 1 << 16;
 // [18 + w]: at wave w's end, its stores landed; [23], [24]: HW_ID, XCC_ID of wave 0; [25]: walk rounds of the resolving wave; [27 + w]: HW_ID of wave w
 constexpr int K6_PROF_N = 32;
 __device__ uint32_t g_k6_prof[K6_PROF_WG][K6_PROF_N];
+// (the stamps are kept in LDS and written at the workgroup's end: a store to memory per stamp made every later wait for the wave's
+// loads wait for that store's way out as well -- the phases behind a stamp read thousands of cycles too long)
 #define K6_STAMP(slot, who)                                                                                            \
     do {                                                                                                               \
-        if (threadIdx.x == (who) && blockIdx.x < K6_PROF_WG) {                                                         \
+        if (threadIdx.x == (who)) {                                                                                    \
             const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                              \
-            g_k6_prof[blockIdx.x][slot] = static_cast<uint32_t>(now_ - stamp_);                                        \
+            s_prof[slot] = static_cast<uint32_t>(now_ - stamp_);                                                       \
             stamp_ = now_;                                                                                             \
         }                                                                                                              \
     } while (0)
-#define K6_COUNT(slot, v) (blockIdx.x < K6_PROF_WG ? (void)(g_k6_prof[blockIdx.x][slot] = static_cast<uint32_t>(v)) : (void)0)
+#define K6_COUNT(slot, v) ((threadIdx.x & 63u) == 0u ? (void)(s_prof[slot] = static_cast<uint32_t>(v)) : (void)0)
 #else
 #define K6_STAMP(slot, who)
 #define K6_COUNT(slot, v)
@@ -268,6 +271,9 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
 
 #ifdef MCRAW_DIAG
     unsigned long long stamp_ = __builtin_amdgcn_s_memtime();
+    __shared__ uint32_t s_prof[K6_PROF_N];
+    if (threadIdx.x < K6_PROF_N)
+        s_prof[threadIdx.x] = 0u;
     if (threadIdx.x == 0 && blockIdx.x < K6_PROF_WG) {
         g_k6_prof[blockIdx.x][6] = static_cast<uint32_t>(stamp_);
         g_k6_prof[blockIdx.x][16] = static_cast<uint32_t>(__builtin_amdgcn_s_memrealtime());
@@ -685,15 +691,67 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
             // (a window of LBW segments per poll: the nearest segment that already holds a prefix is mostly less than ten back --
             // what lies between a segment's own count and its prefix is one look-back --, and a poll is LBW small requests to the
             // fabric: with 64 lanes polling, the polls were a quarter of the kernel's fetched bytes)
-#ifndef K6_LBW
-#define K6_LBW 16
-#endif
-            constexpr uint32_t LBW = K6_LBW;
+            constexpr uint32_t LBW = 16;
             int32_t jn = static_cast<int32_t>(seg) - 1; // nearest segment of the window (lane 0)
-            while (!lost) {
+            if (K6_ABL == 32 || K6_ABL == 33) // (no look-back -- the records land near their rows, by the frame's average record size; timing only)
+                base = static_cast<uint32_t>(static_cast<uint64_t>(nrec) * seg * (DEC_CH * CHUNK6) / len);
+            if (K6_ABL == 33) { // (... but ONE poll of the window's words, waited for and not looked at: what the reads cost without the waiting)
+                const int32_t k = jn - static_cast<int32_t>(lane);
+                uint32_t wv = 0;
+                const bool ok = lane < LBW && k >= 0 && look_get(res - seg + k, epoch, &wv);
+                if (__ballot(ok && wv == 0x12345678u) == 1ull)
+                    base++;
+            }
+            // The polls are SCALAR loads (round 6): the window's sixteen words in two s_load_dwordx16 that pass the scalar cache (glc).
+            // A vector load of the same words is queued behind everything this CU's waves have sent to memory -- seven workgroups'
+            // stores --, and what the kernel was bound by was this hand-off: without the look-back (record indices guessed)
+            // 0.27 ms, with vector polls 0.356, with scalar polls 0.31 - 0.32 (tools/ab6n.sh, docs/lab_notes.md).  A word that carries
+            // this launch's epoch is what its writer wrote, whatever way it came, so what such a poll finds can be relied on;
+            // what it does not find after SCALAR_POLLS6 polls is asked for by vector loads at device scope as before (measured:
+            // a frame whose segments run on all eight XCDs resolves by scalar polls alone -- the fallback is there because
+            // nothing documents that it must).  Windows that reach in front of the frame's first segment go the vector way too.
+            constexpr uint32_t SCALAR_POLLS6 = 32;
+            static_assert(LBW == 16, "the scalar poll reads the window as two s_load_dwordx16");
+            typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+            bool prefixed = false;
+            for (uint32_t polls = SCALAR_POLLS6; polls && jn >= static_cast<int32_t>(LBW) - 1 && K6_ABL != 32 && K6_ABL != 33; polls--) {
+                const uint64_t wa = reinterpret_cast<uint64_t>(res - seg + (jn - (static_cast<int32_t>(LBW) - 1))); // words of segments jn - 15 .. jn
+                const uint64_t wp = (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(wa >> 32)))) << 32) |
+                                    static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(wa)));
+                u32x16 lo16, hi16;
+                asm volatile("s_load_dwordx16 %0, %2, 0x0 glc\n\ts_load_dwordx16 %1, %2, 0x40 glc\n\ts_waitcnt lgkmcnt(0)"
+                             : "=s"(lo16), "=s"(hi16) : "s"(wp) : "memory");
+                uint32_t sum = 0u;
+                bool ok = true, found = false;
+#pragma unroll
+                for (int k = 0; k < static_cast<int>(LBW); k++) { // nearest segment first: word 15 - k of the window
+                    const int idx = 2 * (static_cast<int>(LBW) - 1 - k);
+                    const uint32_t pl = idx < 16 ? lo16[idx] : hi16[idx - 16], ep = idx < 16 ? lo16[idx + 1] : hi16[idx - 15];
+                    const bool valid = ep == epoch && (pl >> 30) != 0u;
+                    if (!found) {
+                        ok = ok && valid;
+                        sum += valid ? (pl >> 5) & 0xFFFFFFu : 0u;
+                        found = valid && (pl >> 30) == RES_PREFIX;
+                    }
+                }
+                if (!ok) { // not all published yet
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                base = min(base + sum, 0xFFFFFFu);
+                if (found) {
+                    prefixed = true;
+                    break;
+                }
+                jn -= static_cast<int32_t>(LBW);
+            }
+            while (!lost && !prefixed && K6_ABL != 32 && K6_ABL != 33) {
                 const int32_t k = jn - static_cast<int32_t>(lane);
                 w = RES_AGG << 30; // segments "before the frame": nothing, and never reached (segment 0 has a prefix)
-                const bool ok = lane < LBW && (k < 0 || (look_get(res - seg + k, epoch, &w) && (w >> 30) != 0u));
+                bool got = false;
+                if (lane < LBW && k >= 0)
+                    got = look_get(res - seg + k, epoch, &w);
+                const bool ok = lane < LBW && (k < 0 || (got && (w >> 30) != 0u));
                 const uint64_t okm = __ballot(ok), pm = __ballot(ok && (w >> 30) == RES_PREFIX);
                 const uint32_t np = pm ? static_cast<uint32_t>(__builtin_ctzll(pm)) : LBW; // lanes in front of the first prefix
                 const uint64_t need = np >= LBW ? (1ull << LBW) - 1ull : ((1ull << np) | ((1ull << np) - 1ull));
@@ -917,6 +975,15 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
             uint32_t va[4], vb[4];
             quad6u(bytes, roa, qt4, hd.sa, va);
             quad6u(bytes, rob, qt4, hd.sb, vb);
+#if K6_ABL == 16 // (timing experiment: forty vector instructions more per pass, the same memory accesses)
+            {
+                uint32_t d = va[0] ^ vb[3];
+#pragma unroll
+                for (int e = 0; e < 40; e++)
+                    asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(d) : "v"(va[1]), "v"(vb[2]));
+                va[0] ^= d & 0x10000u;
+            }
+#endif
             const uint32_t n = r0 + q;
             const uint32_t dy = WIDE ? (n >= ppr ? 1u : 0u) : mul_u24(n, m20) >> 20;
             const uint32_t x = (n - __umul24(dy, ppr)) * 32u + 8u * qt; // RawData_Legacy.cpp:479-486
@@ -993,6 +1060,9 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         }
         __builtin_amdgcn_s_waitcnt(0); // (the end stamp is taken when the wave's stores have landed)
         K6_END();
+        __syncthreads();
+        if (threadIdx.x < K6_PROF_N && blockIdx.x < K6_PROF_WG && (threadIdx.x < 6 || (threadIdx.x >= 8 && threadIdx.x < 16) || threadIdx.x == 25 || threadIdx.x == 26))
+            g_k6_prof[blockIdx.x][threadIdx.x] = s_prof[threadIdx.x];
 #endif
         return;
     }

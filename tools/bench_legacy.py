@@ -20,7 +20,7 @@ def main():
     ctx.profile(True)
     res = {}
     for name, w, h, nb, dist, sig in (("legacy_4000x3000_nat12", 4000, 3000, 12, 1, 12.0), ("legacy_1920x1080_u10", 1920, 1080, 10, 0, 0.0)):
-        n = 32
+        n = int(os.environ.get("N", "32"))
         imgs = [L.synth_image(w, h, nb, dist, sig, 6000 + i) for i in range(4)]
         bufs = [L.encode6(im) for im in imgs]
         tin = [torch.from_numpy(bufs[i % 4]).to(dev) for i in range(n)]
