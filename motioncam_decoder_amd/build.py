@@ -93,6 +93,18 @@ def build_variant(out, flags=()):
     return out
 
 
+# The -D builds that tests/ links on the GPU box (tests/test_gpu_split.py, test_gpu_segw.py, test_gpu_lookback_fault.py).
+TEST_VARIANTS = (["-DMCRAW_FORCE_SEGW"], ["-DMCRAW_INJECT_MUTE7"], ["-DMCRAW_INJECT_LOST"])
+
+
+def prebuild_test_variants():
+    """Compile the test variants' objects into lib/obj/ ahead of time: build_variant() on the GPU box then only links."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        for i, flags in enumerate(TEST_VARIANTS):
+            build_variant(os.path.join(d, "v%d.so" % i), flags)
+
+
 def build_hip(force=False):
     """lib/libmcraw_hip.so: one object per source (lib/obj/), then the link."""
     os.makedirs(LIB, exist_ok=True)

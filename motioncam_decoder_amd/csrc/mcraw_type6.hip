@@ -702,31 +702,31 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                 if (__ballot(ok && wv == 0x12345678u) == 1ull)
                     base++;
             }
-            // The polls are SCALAR loads (round 6): the window's sixteen words in two s_load_dwordx16 that pass the scalar cache (glc).
-            // A vector load of the same words is queued behind everything this CU's waves have sent to memory -- seven workgroups'
-            // stores --, and what the kernel was bound by was this hand-off: without the look-back (record indices guessed)
-            // 0.27 ms, with vector polls 0.356, with scalar polls 0.31 - 0.32 (tools/ab6n.sh, docs/lab_notes.md).  A word that carries
-            // this launch's epoch is what its writer wrote, whatever way it came, so what such a poll finds can be relied on;
-            // what it does not find after SCALAR_POLLS6 polls is asked for by vector loads at device scope as before (measured:
-            // a frame whose segments run on all eight XCDs resolves by scalar polls alone -- the fallback is there because
-            // nothing documents that it must).  Windows that reach in front of the frame's first segment go the vector way too.
+            // The first polls are SCALAR loads (round 6): the words of the eight segments in front in one s_load_dwordx16 that passes the
+            // scalar cache (glc).  A vector load of the same words is queued behind everything this CU's waves have sent to memory --
+            // seven workgroups' stores --, and what the kernel was bound by was this hand-off: without the look-back (record indices
+            // guessed) 0.27 ms, with vector polls 0.356, with scalar polls 0.30 - 0.31 (tools/ab6n.sh, docs/lab_notes.md).  A word
+            // that carries this launch's epoch is what its writer wrote, whatever way it came, so what such a poll finds can be
+            // relied on; what it does not find after SCALAR_POLLS6 polls is asked for by vector loads at device scope as before
+            // (measured: a frame whose segments run on all eight XCDs resolves by scalar polls alone -- the fallback is there
+            // because nothing documents that it must).  Windows that reach in front of the frame's first segment go the vector way too.
             constexpr uint32_t SCALAR_POLLS6 = 32;
-            static_assert(LBW == 16, "the scalar poll reads the window as two s_load_dwordx16");
+            constexpr int SW = 8; // segments per scalar poll: ONE s_load_dwordx16 (two of them for sixteen segments: 2.5 % slower, and
+                                  // 26 instead of 15 MB of polls per 380 MB of stream; four segments by s_load_dwordx8: the same as eight)
             typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
             bool prefixed = false;
-            for (uint32_t polls = SCALAR_POLLS6; polls && jn >= static_cast<int32_t>(LBW) - 1 && K6_ABL != 32 && K6_ABL != 33; polls--) {
-                const uint64_t wa = reinterpret_cast<uint64_t>(res - seg + (jn - (static_cast<int32_t>(LBW) - 1))); // words of segments jn - 15 .. jn
+            for (uint32_t polls = SCALAR_POLLS6; polls && jn >= SW - 1 && K6_ABL != 32 && K6_ABL != 33; polls--) {
+                const uint64_t wa = reinterpret_cast<uint64_t>(res - seg + (jn - (SW - 1))); // words of segments jn - SW + 1 .. jn
                 const uint64_t wp = (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(wa >> 32)))) << 32) |
                                     static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(wa)));
-                u32x16 lo16, hi16;
-                asm volatile("s_load_dwordx16 %0, %2, 0x0 glc\n\ts_load_dwordx16 %1, %2, 0x40 glc\n\ts_waitcnt lgkmcnt(0)"
-                             : "=s"(lo16), "=s"(hi16) : "s"(wp) : "memory");
+                u32x16 w16;
+                asm volatile("s_load_dwordx16 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(w16) : "s"(wp) : "memory");
                 uint32_t sum = 0u;
                 bool ok = true, found = false;
 #pragma unroll
-                for (int k = 0; k < static_cast<int>(LBW); k++) { // nearest segment first: word 15 - k of the window
-                    const int idx = 2 * (static_cast<int>(LBW) - 1 - k);
-                    const uint32_t pl = idx < 16 ? lo16[idx] : hi16[idx - 16], ep = idx < 16 ? lo16[idx + 1] : hi16[idx - 15];
+                for (int k = 0; k < SW; k++) { // nearest segment first: word SW - 1 - k of the window
+                    const int idx = 2 * (SW - 1 - k);
+                    const uint32_t pl = w16[idx], ep = w16[idx + 1];
                     const bool valid = ep == epoch && (pl >> 30) != 0u;
                     if (!found) {
                         ok = ok && valid;
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                     prefixed = true;
                     break;
                 }
-                jn -= static_cast<int32_t>(LBW);
+                jn -= SW;
             }
             while (!lost && !prefixed && K6_ABL != 32 && K6_ABL != 33) {
                 const int32_t k = jn - static_cast<int32_t>(lane);
