@@ -3,7 +3,7 @@
 in turn by contexts created under different environments.  (Fresh processes differ by +-4 % on the tile kernel alone, as the
 physical pages of their buffers fall; this tool takes that out of a comparison.)
 
-    gpurun -- 'python3 tools/ab_ctx.py inline:MCRAW_SIDE_CUS=0 side: "fat:MCRAW_SIDE_FAT=1" [--config 5] [--rounds 9] [--steps 20]'
+    gpurun -- 'python3 tools/ab_ctx.py auto: "split22:MCRAW_SIDE_SPLIT=2,2" "chunk16:MCRAW_XCD_CHUNK=16" [--config 5] [--rounds 9] [--steps 20]'
 """
 import argparse
 import os
