@@ -304,6 +304,15 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     const Plan6 *P = plans + f;
     const uint32_t nchunks = P->nchunks, nrec = P->nrec, len = P->len;
     const __amdgpu_buffer_rsrc_t rs = frame_rsrc(P->in, len);
+    // What the unpacking waves need of the plan, read HERE: left to the compiler, these four scalar loads and the division sit behind
+    // the workgroup's last barrier, on every wave's way from the record lists to its first store (worth 1 % at most: they hit the scalar cache).
+    uint32_t width = static_cast<uint32_t>(P->width), fast_store = P->fast_store, ppr = P->recs_per_row >> 1;
+    uint16_t *out = P->out;
+    // row arithmetic without per-lane division: pairs per row `ppr`; a round spans < 2 rows when
+    // ppr >= 512, otherwise n / ppr for n < 1024 is exact as (n * ceil(2^20 / ppr)) >> 20
+    const bool widerow = ppr >= 512u;
+    uint32_t m20 = widerow ? 0u : ((1u << 20) + ppr - 1u) / ppr;
+    asm volatile("" : "+s"(width), "+s"(fast_store), "+s"(ppr), "+s"(out), "+s"(m20)); // (values, not addresses to load from later)
     // the ticket takes a round trip to the frame's counter: start loading what it will almost certainly say
     // (workgroups start in order), and load again if it says otherwise
     if (tid == 0)
@@ -929,15 +938,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     const uint32_t e = lane <= ROWS_CH ? ent_of(wave * ROWS_CH + lane) : DEAD;
 
     // (the walk tables are dead: from here on their LDS holds the record lists)
-    const uint32_t width = static_cast<uint32_t>(P->width);
-    const bool fast = P->fast_store != 0u;
-    uint16_t *const out = P->out;
-
-    // row arithmetic without per-lane division: pairs per row `ppr`; a round spans < 2 rows when
-    // ppr >= 512, otherwise n / ppr for n < 1024 is exact as (n * ceil(2^20 / ppr)) >> 20
-    const uint32_t ppr = P->recs_per_row >> 1;
-    const bool widerow = ppr >= 512u;
-    const uint32_t m20 = widerow ? 0u : ((1u << 20) + ppr - 1u) / ppr;
+    const bool fast = fast_store != 0u;
 
     // Unpack the pairs of records [wlo, whi) (both even) of unpacking wave uw, listed in s_pos[uw]: four lanes per pair; of
     // its 2 * (whi - wlo) tasks, those in [tb, te).  What is the same for every task of a round -- the list's layout, whether a
