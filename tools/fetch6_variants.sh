@@ -1,3 +1,4 @@
+#!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 # gpurun -- 'bash tools/fetch6_variants.sh base cur <name> ...': FETCH_SIZE (x 2: gfx950) of k6_decode per launch for several builds of the library
 # (lib/libmcraw_hip_<name>.so; "cur" = the product), 32 x 12 MP legacy frames
