@@ -23,7 +23,8 @@ def main():
         n = int(os.environ.get("N", "32"))
         imgs = [L.synth_image(w, h, nb, dist, sig, 6000 + i) for i in range(4)]
         bufs = [L.encode6(im) for im in imgs]
-        tin = [torch.from_numpy(bufs[i % 4]).to(dev) for i in range(n)]
+        tin = [torch.from_numpy(bufs[i % 4]).to(dev) for i in range(4 if os.environ.get("DEDUP") else n)]  # DEDUP=1: four input buffers
+        tin = [tin[i % len(tin)] for i in range(n)]                                                       # for all frames (reads hit the caches)
         tout = torch.zeros(n * w * h * 2, dtype=torch.uint8, device=dev)
         descs = [(tin[i].data_ptr(), tin[i].numel(), w, h, 6, tout.data_ptr() + i * w * h * 2, w * h) for i in range(n)]
         frames = M.Context.make_frames(descs)
