@@ -105,9 +105,10 @@ __device__ __forceinline__ void quad6u(const uint8_t *__restrict__ bytes, uint32
 //
 // The list has two layouts: every record (up to ROWS_CAP / 2 per wave), or one entry per record PAIR -- the
 // position of the even record; the odd one starts where the even one ends, which the unpacking lane knows from
-// the even record's header -- so a round covers 1024 records in 1 KiB of LDS: all data but runs of 2-byte
-// records stays on the single-round path (4-byte records, 1-bit residuals of a nearly flat frame, are 1024 per wave).
-constexpr uint32_t ROWS_CAP = 256u * ROWS_CH; // records per round (typical: ~70 per chunk; worst case 512 per chunk -> 2 rounds)
+// the even record's header -- so a round covers 768 records in 772 bytes of LDS: all data but runs of records of 2 and 4
+// bytes (flat or clipped regions; 1-bit residuals of a nearly flat frame: 1024 records per wave) stays on the single-round path.
+// (Rounds 4-5: 1024 records in 1 KiB; round 6 gave a quarter of the lists for the eighth workgroup per CU, see k6_decode.)
+constexpr uint32_t ROWS_CAP = 192u * ROWS_CH; // records per round (typical: ~70 per chunk; worst case 512 per chunk -> 3 rounds)
 static_assert(ROWS_CAP <= 1024u && ROWS_CAP % 2u == 0u, "the division-free row arithmetic of the unpack assumes at most 512 pairs per round");
 
 #ifndef K6_ABL
@@ -119,7 +120,7 @@ static_assert(ROWS_CAP <= 1024u && ROWS_CAP % 2u == 0u, "the division-free row a
 constexpr uint32_t UNPACK_W = SEG_WAVES6;         // unpacking waves per workgroup
 constexpr uint32_t DEC_CH = UNPACK_W * ROWS_CH;   // chunks per workgroup
 // Four waves per workgroup: the last wave resolves the chain (the one in front of it the sure entry beside it), then all four unpack
-// their chunks.  Seven workgroups fit a CU: the kernel is a chain of latencies -- load, walk, look-back, lists, unpack --, and what
+// their chunks.  Eight workgroups fit a CU (round 6; seven until then): the kernel is a chain of latencies -- load, walk, look-back, lists, unpack --, and what
 // hides them is the number of segments in flight.  (Rounds 2-5 also built two-, five- and eight-wave workgroups and a form that
 // stages the stream by LDS-DMA, all slower: docs/lab_notes.md.)
 constexpr uint32_t DEC_T = 64 * UNPACK_W;
@@ -263,9 +264,14 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     // holding the even record only (up to ROWS_CAP records; the unpacking lane finds the odd one behind it)
     typedef uint16_t PosList[ROWS_CAP / 2 + 2];
     static_assert(sizeof(PosList) % 4u == 0u, "the lists are read as dwords");
-    __shared__ __attribute__((aligned(4))) PosList s_pos[UNPACK_W];
-    // entry of my chunks and of the one behind them (phase | first record << 8), and of every quarter of my chunks
-    __shared__ uint32_t s_ent[DEC_CH + 1], s_ent4[NQ6];
+    // (round 6: 20 352 bytes of LDS = EIGHT workgroups per CU.  The first wave's list lies in the staged front, which nobody reads
+    // once the chain is resolved, and a list holds 386 entries instead of 514: 3 - 9 % on natural and noisy frames, tools/ab6n.sh,
+    // tools/ab_shapes6.sh -- frames made of runs of 2-byte records take three rounds per wave instead of two and lose 10 %.)
+    __shared__ __attribute__((aligned(4))) PosList s_posN[UNPACK_W - 1];
+    static_assert(sizeof(PosList) <= FRONT6, "the first list fits the front");
+    auto pos_of = [&](uint32_t w) -> uint16_t * { return w == 0u ? reinterpret_cast<uint16_t *>(s_stage) : s_posN[w - 1u]; };
+    // entry of my chunks and of the one behind them (phase | first record << 8)
+    __shared__ uint32_t s_ent[DEC_CH + 1];
     __shared__ uint8_t s_fmap[32]; // (only for streams whose chains never meet) my entry phase -> my exit phase
     __shared__ uint32_t s_ticket, s_coop, s_front;
 
@@ -467,7 +473,11 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                 // ---- (re)walk the quarters of the lanes whose entry has changed
                 if (!careful) { // fast form: notes in registers
                     uint32_t Pw = act ? qb + 2u * a : qe, xc = Pw, cn = 0u;
-                    uint32_t nn[NOTES6 / 4u] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+                    // (the notes go straight to `nb`: a lane that walks its quarter starts them over; one that does not stands behind its
+                    // quarter from the first step on and notes nothing -- a working copy cost eight registers)
+#pragma unroll
+                    for (uint32_t g = 0; g < NOTES6 / 4u; g++)
+                        nb[g] = act ? 0u : nb[g];
                     bool more = true;
 #pragma unroll
                     for (uint32_t st = 0; st < NOTES6; st += 2u) {
@@ -475,12 +485,13 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                         for (uint32_t u = 0; u < 2u; u++) {
                             const uint32_t Pn = next6(s_stage, Pw);
                             const bool in = Pw < qe;
-                            nn[(st + u) >> 2] |= __builtin_amdgcn_ubfe(Pw - qb, 1u, 8u) << (8u * ((st + u) & 3u)); // (bytes behind a lane's last record are never used)
+                            nb[(st + u) >> 2] |= (in ? __builtin_amdgcn_ubfe(Pw - qb, 1u, 8u) : 0u) << (8u * ((st + u) & 3u));
                             cn += in ? 1u : 0u;
                             xc = in ? Pn : xc;
                             Pw = Pn;
                         }
                         Pw = min(Pw, CLAMP);
+                        asm volatile("" : "+v"(nb[st >> 2])); // (noted now: left to itself the compiler keeps the shifted positions of every step until the loop's exit)
                         if (!__any(Pw < qe)) {
                             more = false;
                             break;
@@ -503,9 +514,6 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                     if (act) {
                         x = (xc - qe) >> 1;
                         qn = cn;
-#pragma unroll
-                        for (uint32_t g = 0; g < NOTES6 / 4u; g++)
-                            nb[g] = nn[g];
                     }
                 } else { // segments that need the careful walk: counts only
                     uint32_t Pw = act ? qb + 2u * a : qe, t, n, cn = 0u;
@@ -713,7 +721,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
             }
             // The first polls are SCALAR loads (round 6): the words of the eight segments in front in one s_load_dwordx16 that passes the
             // scalar cache (glc).  A vector load of the same words is queued behind everything this CU's waves have sent to memory --
-            // seven workgroups' stores --, and what the kernel was bound by was this hand-off: without the look-back (record indices
+            // its workgroups' stores --, and what the kernel was bound by was this hand-off: without the look-back (record indices
             // guessed) 0.27 ms, with vector polls 0.356, with scalar polls 0.30 - 0.31 (tools/ab6n.sh, docs/lab_notes.md).  A word
             // that carries this launch's epoch is what its writer wrote, whatever way it came, so what such a poll finds can be
             // relied on; what it does not find after SCALAR_POLLS6 polls is asked for by vector loads at device scope as before
@@ -799,7 +807,6 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         const uint32_t ent4v = qp | (qi << 8);
         const uint32_t entv = inq && !lost ? (cph | (qi << 8)) : DEAD;                 // (lanes with ur == 0: chunk uj's)
         const uint32_t ent16 = full && !lost ? (aph | (endn << 8)) : DEAD;             // ... and of the chunk behind a full segment
-        s_ent4[lane] = ent4v;
         if (ur == 0u)
             s_ent[uj] = entv;
         if (lane == 0)
@@ -837,7 +844,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         const bool noted = coop && notes_ok && __ballot(rg.pairmode || rg.N + NOTES6 > ROWS_CAP / 2u) == 0ull;
         if (K6_ABL != 3 && noted) {
             const int32_t slot0 = static_cast<int32_t>(qi - rg.R0); // -1: an odd first record belongs to the previous wave's
-            uint16_t *lp = s_pos[uw] + slot0;                        // last pair, never listed
+            uint16_t *lp = pos_of(uw) + slot0;                        // last pair, never listed
             const uint32_t boff = j * CHUNK6 + r * (CHUNK6 / 4u);
             {
                 const uint32_t kb = qn & 7u, gp = qn >> 3;
@@ -893,7 +900,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                         if (((q.x | q.y | q.z | q.w) & 0x00F000F0u) == 0u) {
 #pragma unroll
                             for (uint32_t k = 0; k < 4u; k++)
-                                s_pos[uw][((idx - first) >> 1) + k] = static_cast<uint16_t>(p - base + 4u * k);
+                                pos_of(uw)[((idx - first) >> 1) + k] = static_cast<uint16_t>(p - base + 4u * k);
                             p += 16;
                             idx += 8u;
                             continue;
@@ -901,12 +908,12 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                     }
                     const uint32_t hb = static_cast<uint32_t>(*p) >> 4;
                     if ((idx & 1u) == 0u && idx >= first)
-                        s_pos[uw][(idx - first) >> 1] = static_cast<uint16_t>(p - base);
+                        pos_of(uw)[(idx - first) >> 1] = static_cast<uint16_t>(p - base);
                     idx++;
                     p += 2u + len6_of(hb);
                 }
             } else {
-                uint16_t *lp = s_pos[uw] + static_cast<int32_t>(idx - first); // [-1] for an odd first record:
+                uint16_t *lp = pos_of(uw) + static_cast<int32_t>(idx - first); // [-1] for an odd first record:
                 if (idx < first && p < pe) {                                   // skipped, see above
                     p += 2u + len6_of(static_cast<uint32_t>(*p) >> 4);
                     lp++;
@@ -918,7 +925,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                 }
                 // the walk of a wave's last quarter stops on the next wave's first record: the partner of my
                 // last record when my range ends on an even one (lp is then at an odd list index)
-                if (j == ROWS_CH - 1u && r == 3u && ((lp - s_pos[uw]) & 1))
+                if (j == ROWS_CH - 1u && r == 3u && ((lp - pos_of(uw)) & 1))
                     *lp = static_cast<uint16_t>(p - base);
             }
         }
@@ -940,7 +947,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     // (the walk tables are dead: from here on their LDS holds the record lists)
     const bool fast = fast_store != 0u;
 
-    // Unpack the pairs of records [wlo, whi) (both even) of unpacking wave uw, listed in s_pos[uw]: four lanes per pair; of
+    // Unpack the pairs of records [wlo, whi) (both even) of unpacking wave uw, listed in pos_of(uw): four lanes per pair; of
     // its 2 * (whi - wlo) tasks, those in [tb, te).  What is the same for every task of a round -- the list's layout, whether a
     // round can span more than two rows -- is decided once, outside the loop (a workgroup has one ready wave per SIMD most of
     // the time: every scalar branch inside the loop is paid in full).
@@ -950,8 +957,8 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         constexpr bool BY_PAIR = decltype(by_pair_t)::value, WIDE = decltype(wide_t)::value, FAST = decltype(fast_t)::value;
         const uint8_t *bytes = s_own + uw * (ROWS_CH * CHUNK6);
         const uint32_t pair0 = wlo >> 1;
-        const uint16_t *pairs = s_pos[uw];
-        const uint32_t *both = reinterpret_cast<const uint32_t *>(s_pos[uw]);
+        const uint16_t *pairs = pos_of(uw);
+        const uint32_t *both = reinterpret_cast<const uint32_t *>(pos_of(uw));
         const uint32_t y0 = pair0 / ppr, r0 = pair0 - y0 * ppr; // wave-uniform
         const uint32_t row0 = y0 * width;
         const uint32_t qt = (tb + lane) & 3u, qt4 = 4u * qt; // (t advances by 64)
@@ -1074,6 +1081,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     // a walker keeps its place from round to round (restarting at the chunk entry every round made a
     // run of 2-byte records cost rounds x 512 steps per lane)
     uint32_t pos = 2u * (e & 255u), idx = e >> 8;
+    uint16_t *const mylist = pos_of(wave);
     for (uint32_t base = 0; base < N; base += ROWS_CAP) {
         const uint32_t wlo = R0 + base, whi = min(R1, wlo + ROWS_CAP); // records of this round (both even)
         if (K6_ABL != 3 && walker) {
@@ -1089,7 +1097,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                     if (((q.x | q.y | q.z | q.w) & 0x00F000F0u) == 0u) {
 #pragma unroll
                         for (uint32_t k = 0; k < 4u; k++)
-                            s_pos[wave][((idx - wlo) >> 1) + k] = static_cast<uint16_t>(a + 4u * k);
+                            mylist[((idx - wlo) >> 1) + k] = static_cast<uint16_t>(a + 4u * k);
                         pos += 16u;
                         idx += 8u;
                         continue;
@@ -1099,7 +1107,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                 if (cs0 + off + nx >= len)
                     break; // k6_frame has already failed the frame if records are missing
                 if (idx >= wlo && (idx & 1u) == 0u)
-                    s_pos[wave][(idx - wlo) >> 1] = static_cast<uint16_t>(off + pos);
+                    mylist[(idx - wlo) >> 1] = static_cast<uint16_t>(off + pos);
                 pos = nx;
                 idx++;
             }
