@@ -270,8 +270,8 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     __shared__ __attribute__((aligned(4))) PosList s_posN[UNPACK_W - 1];
     static_assert(sizeof(PosList) <= FRONT6, "the first list fits the front");
     auto pos_of = [&](uint32_t w) -> uint16_t * { return w == 0u ? reinterpret_cast<uint16_t *>(s_stage) : s_posN[w - 1u]; };
-    // entry of my chunks and of the one behind them (phase | first record << 8)
-    __shared__ uint32_t s_ent[DEC_CH + 1];
+    // entry of my chunks and of the one behind them (phase | first record << 8), and of every quarter of my chunks
+    __shared__ uint32_t s_ent[DEC_CH + 1], s_ent4[NQ6];
     __shared__ uint8_t s_fmap[32]; // (only for streams whose chains never meet) my entry phase -> my exit phase
     __shared__ uint32_t s_ticket, s_coop, s_front;
 
@@ -807,6 +807,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         const uint32_t ent4v = qp | (qi << 8);
         const uint32_t entv = inq && !lost ? (cph | (qi << 8)) : DEAD;                 // (lanes with ur == 0: chunk uj's)
         const uint32_t ent16 = full && !lost ? (aph | (endn << 8)) : DEAD;             // ... and of the chunk behind a full segment
+        s_ent4[lane] = ent4v; // (the general path's walkers start from these)
         if (ur == 0u)
             s_ent[uj] = entv;
         if (lane == 0)
@@ -1077,37 +1078,38 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     if (!live)
         return;
     const uint8_t *bytes = s_own + wave * (ROWS_CH * CHUNK6);
-    const bool walker = lane < ROWS_CH && (e & 255u) != DEAD && c0 + lane < nchunks;
-    // a walker keeps its place from round to round (restarting at the chunk entry every round made a
-    // run of 2-byte records cost rounds x 512 steps per lane)
-    uint32_t pos = 2u * (e & 255u), idx = e >> 8;
+    // The lists of the general path: one lane per QUARTER chunk walks from where the chain enters its quarter (s_ent4: sixteen
+    // walks side by side per wave -- round 6; until then one lane per chunk: a wave of 2-byte records cost 64 steps a round).
+    // A walker keeps its place from round to round (restarting at the entry every round made a run of 2-byte records
+    // cost rounds x 128 steps per lane).
+    const uint32_t e4 = lane < 4u * ROWS_CH ? s_ent4[wave * (4u * ROWS_CH) + lane] : DEAD;
+    const bool walker = lane < 4u * ROWS_CH && (e4 & 255u) != DEAD && c0 + (lane >> 2) < nchunks;
+    const uint32_t qend = (lane + 1u) * QUART6; // (positions: bytes from the wave's first chunk)
+    uint32_t pos = lane * QUART6 + 2u * (e4 & 255u), idx = e4 >> 8;
     uint16_t *const mylist = pos_of(wave);
     for (uint32_t base = 0; base < N; base += ROWS_CAP) {
         const uint32_t wlo = R0 + base, whi = min(R1, wlo + ROWS_CAP); // records of this round (both even)
         if (K6_ABL != 3 && walker) {
-            const uint32_t off = lane * CHUNK6;
-            while (idx < whi && pos < CHUNK6) {
+            while (idx < whi && pos < qend) {
                 // Runs of 2-byte records (flat or clipped image regions) are what makes a wave land here:
                 // eight of them fill an aligned 16-byte line whose even bytes all have a zero high
                 // nibble -- one LDS read then lists four pairs instead of one record.
-                const uint32_t a = off + pos;
-                if ((a & 15u) == 0u && (idx & 1u) == 0u && pos + 16u <= CHUNK6 && idx >= wlo && idx + 8u <= whi &&
-                    cs0 + a + 16u < len) {
-                    const uint4 q = *reinterpret_cast<const uint4 *>(bytes + a);
+                if ((pos & 15u) == 0u && (idx & 1u) == 0u && idx >= wlo && idx + 8u <= whi && cs0 + pos + 16u < len) {
+                    const uint4 q = *reinterpret_cast<const uint4 *>(bytes + pos);
                     if (((q.x | q.y | q.z | q.w) & 0x00F000F0u) == 0u) {
 #pragma unroll
                         for (uint32_t k = 0; k < 4u; k++)
-                            mylist[((idx - wlo) >> 1) + k] = static_cast<uint16_t>(a + 4u * k);
+                            mylist[((idx - wlo) >> 1) + k] = static_cast<uint16_t>(pos + 4u * k);
                         pos += 16u;
                         idx += 8u;
                         continue;
                     }
                 }
-                const uint32_t nx = pos + 2u + len6_of(static_cast<uint32_t>(bytes[off + pos]) >> 4);
-                if (cs0 + off + nx >= len)
+                const uint32_t nx = pos + 2u + len6_of(static_cast<uint32_t>(bytes[pos]) >> 4);
+                if (cs0 + nx >= len)
                     break; // k6_frame has already failed the frame if records are missing
                 if (idx >= wlo && (idx & 1u) == 0u)
-                    mylist[(idx - wlo) >> 1] = static_cast<uint16_t>(off + pos);
+                    mylist[(idx - wlo) >> 1] = static_cast<uint16_t>(pos);
                 pos = nx;
                 idx++;
             }
