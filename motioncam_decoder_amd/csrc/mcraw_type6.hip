@@ -677,7 +677,7 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         g.live = c0 < nchunks && (e0 & 255u) != DEAD && g.R0 < g.R1;
         g.N = g.live ? g.R1 - g.R0 : 0u;
         g.lean = g.live && inner && g.N <= ROWS_CAP && c0 * CHUNK6 + STAGE < len;
-        g.pairmode = g.N > ROWS_CAP / 2u;
+        g.pairmode = g.N + NOTES6 > ROWS_CAP / 2u; // (the layout by records: as long as the notes' stores stay inside the list)
         return g;
     };
     auto range_of = [&](uint32_t w) { return range_from(w, ent_of(w * ROWS_CH), ent_of(w * ROWS_CH + ROWS_CH)); };
@@ -842,7 +842,9 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
         // (every quarter starts at least seven: a record has at most 34 bytes), taken from the lane behind it: what a lane
         // stores beyond its own records is then exactly what that lane stores there itself, and it does not matter which
         // of the two stores comes last.
-        const bool noted = coop && notes_ok && __ballot(rg.pairmode || rg.N + NOTES6 > ROWS_CAP / 2u) == 0ull;
+        // (a list by pairs holds every second note: up to ROWS_CAP - NOTES6 records per wave; round 6 -- until then the notes served
+        // the layout by records only, and a wave of more than 512 records was listed by a second walk along the chain: 12 % of the kernel)
+        const bool noted = coop && notes_ok && __ballot(rg.N + NOTES6 > (rg.pairmode ? ROWS_CAP : ROWS_CAP / 2u)) == 0ull;
         if (K6_ABL != 3 && noted) {
             const int32_t slot0 = static_cast<int32_t>(qi - rg.R0); // -1: an odd first record belongs to the previous wave's
             uint16_t *lp = pos_of(uw) + slot0;                        // last pair, never listed
@@ -866,22 +868,34 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
                     nb[2u * g + 1u] = gp == g ? static_cast<uint32_t>(m >> 32) : nb[2u * g + 1u];
                 }
             }
+            // by pairs: the records of even number only -- my notes par, par + 2, .. (par: whether my first record is an odd one) --, entry
+            // (slot0 + i) / 2 for note i; the neighbour's stores into my last group pick the same records by the same rule
+            const uint32_t par = static_cast<uint32_t>(slot0) & 1u;
+            uint16_t *const lp2 = pos_of(uw) + ((slot0 + static_cast<int32_t>(par)) >> 1);
 #pragma unroll
             for (uint32_t g = 0; g < NOTES6 / 8u; g++) {
                 if (g && __ballot(qn > 8u * g) == 0ull)
                     break;
                 if (qn > 8u * g) { // (at most seven entries behind a lane's last record: the next quarter's first seven)
+                    if (rg.pairmode) {
 #pragma unroll
-                    for (uint32_t i = 8u * g; i < 8u * g + 8u; i++) {
-                        const uint32_t v = boff + 2u * ((nb[i >> 2] >> (8u * (i & 3u))) & 255u);
-                        if (i > 0u || slot0 >= 0)
-                            lp[i] = static_cast<uint16_t>(v);
+                        for (uint32_t k = 0; k < 4u; k++) {
+                            const uint32_t v = boff + 2u * ((nb[2u * g + (k >> 1)] >> (8u * par + 16u * (k & 1u))) & 255u);
+                            lp2[4u * g + k] = static_cast<uint16_t>(v);
+                        }
+                    } else {
+#pragma unroll
+                        for (uint32_t i = 8u * g; i < 8u * g + 8u; i++) {
+                            const uint32_t v = boff + 2u * ((nb[i >> 2] >> (8u * (i & 3u))) & 255u);
+                            if (i > 0u || slot0 >= 0)
+                                lp[i] = static_cast<uint16_t>(v);
+                        }
                     }
                 }
             }
             // behind a wave's last record: the next wave's first one (the partner of the wave's last record when its range
-            // ends on an even one; a lane whose records end on a group boundary has stored nothing behind them)
-            if (j == ROWS_CH - 1u && r == 3u)
+            // ends on an even one; a lane whose records end on a group boundary has stored nothing behind them; by pairs: not listed)
+            if (j == ROWS_CH - 1u && r == 3u && !rg.pairmode)
                 lp[qn] = static_cast<uint16_t>(ROWS_CH * CHUNK6 + 2u * (enext_reg & 255u));
         } else if (K6_ABL != 3 && coop) {
             const uint32_t ej = ent4v, first = rg.R0;
@@ -942,8 +956,6 @@ __global__ __launch_bounds__(DEC_T) void k6_decode(const Plan6 *__restrict__ pla
     const uint32_t c0 = cfirst + wave * ROWS_CH, cs0 = c0 * CHUNK6;
     const uint32_t R0 = mine.R0, R1 = mine.R1, N = mine.N;
     const bool live = mine.live, pairmode = mine.pairmode;
-    // entries of my chunks (lane j) and of the chunk after them (lane ROWS_CH): the general path walks from them
-    const uint32_t e = lane <= ROWS_CH ? ent_of(wave * ROWS_CH + lane) : DEAD;
 
     // (the walk tables are dead: from here on their LDS holds the record lists)
     const bool fast = fast_store != 0u;
