@@ -201,9 +201,8 @@ def test_flat_frames_densest_chains(gpu_ctx):
 
 def test_legacy_frames_of_one_record_size_each_over_several_segments(gpu_ctx):
     # every record of a frame has the same size (header nibble forced): the lists of k6_decode's unpacking waves then hold
-    # 120 .. 2048 records per wave, on both sides of every threshold of the lean path -- single-round lists with and
-    # without the fifth wave's share of the tasks (384 tasks), one entry per record pair (512 records), several rounds
-    # (1024) -- and frames of 5 .. 40 segments, the last one partly filled
+    # 120 .. 2048 records per wave, on both sides of every threshold of the lean path -- every record listed (up to 352 records),
+    # one entry per record pair (up to 736), several rounds of 768 -- and frames of 5 .. 40 segments, the last one partly filled
     items, expect = [], []
     rng = np.random.default_rng(66)
     for nib in range(16):
@@ -215,6 +214,31 @@ def test_legacy_frames_of_one_record_size_each_over_several_segments(gpu_ctx):
         buf = L.encode6(img, np.full(nrec, nib, np.uint8))
         ret, out = L.oracle_decode6(buf, w, h)
         assert ret == w * h and np.array_equal(out, img)
+        items.append((6, w, h, buf))
+        expect.append((ret, out))
+    _check(gpu_ctx, items, expect)
+
+
+def test_legacy_frames_of_mixed_record_sizes_around_the_list_thresholds(gpu_ctx):
+    # round 6: a wave of k6_decode lists every record up to 352 records, every second one (from the quarter walks' notes) up to 736,
+    # and leaves the lean path above (its lanes then walk a quarter chunk each); frames whose records are drawn from two or three
+    # neighbouring sizes put the waves of ONE frame on both sides of each threshold, quarter by quarter
+    items, expect = [], []
+    rng = np.random.default_rng(606)
+    for nibs, w in (((4, 5, 6), 1504), ((3, 4, 5), 1280), ((2, 3), 1056), ((1, 2, 3), 2016), ((0, 1, 2), 992), ((0, 5), 1600), ((2, 12), 1184)):
+        h = 260
+        rpr = w // 32 * 2                                           # records per row (w is a multiple of 32)
+        nrec = rpr * h
+        run = rng.integers(1, 400, size=nrec)                      # sizes change in runs of 1 .. 400 records
+        idx = np.repeat(np.arange(nrec), run)[:nrec] % len(nibs)
+        nib = np.asarray(nibs, np.int64)[rng.permutation(len(nibs))][idx].reshape(h, w // 32, 2)
+        # record (y, g, p) holds the samples of columns 32 g + 2 i + p: residuals of nib[y, g, p] bits above a common reference
+        bits = np.repeat(nib, 16, axis=1).reshape(h, w // 32, 16, 2).reshape(h, w)
+        img = (100 + (rng.random((h, w)) * (1 << bits)).astype(np.int64)).astype(np.uint16)
+        buf = L.encode6(img)
+        ret, out = L.oracle_decode6(buf, w, h)
+        assert ret == w * h and np.array_equal(out, img)
+        assert 0.8 * nrec * (2 + 2 * min(nibs)) <= buf.size <= 1.2 * nrec * (2 + 2 * max(nibs)) + 64  # (the sizes came out as meant)
         items.append((6, w, h, buf))
         expect.append((ret, out))
     _check(gpu_ctx, items, expect)
